@@ -1,0 +1,114 @@
+"""ctypes bindings to the checkers used by the tests (test infrastructure).
+
+* ``oracle()``  -> oracle/liblamsa_oracle.so, our plain-C restatement (always buildable)
+* ``ref()``     -> oracle/_ref/liblamsa_ref.so, the reference itself compiled from
+                   /root/reference (only present where ``make -C oracle ref`` could run,
+                   or where the prebuilt .so travelled); ``None`` when absent.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class LoCigv(C.Structure):
+    _fields_ = [("c", C.POINTER(C.c_int32)), ("n", C.c_int), ("m", C.c_int)]
+
+
+class LoPara(C.Structure):
+    """Mirror of lo_para (oracle/lo.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("seed_len", "seed_step", "seed_inv", "per_aln_m", "first_loci_thd",
+                                          "SV_len_thd", "ske_max")] + [("ovlp_rat", C.c_float)] + \
+               [(n, C.c_int32) for n in ("bwt_seed_len", "bwt_max_len", "bwt_min_len", "split_len", "split_pen",
+                                          "res_mul_max", "hash_len", "hash_key_len", "hash_step", "hash_size",
+                                          "match_dis", "mismatch_thd", "ins_gapo", "ins_gape", "del_gapo", "del_gape",
+                                          "ins_ext_o", "ins_ext_e", "del_ext_o", "del_ext_e", "match", "mis")] + \
+               [("sc_mat", C.c_int8 * 25)] + \
+               [(n, C.c_int32) for n in ("band_w", "end_bonus", "zdrop")] + [("id_rate", C.c_float)] + \
+               [(n, C.c_int32) for n in ("read_type", "aln_mode", "supp_soft", "comm")]
+
+
+class RefPara(C.Structure):
+    """Mirror of lamsa_aln_para (reference src/lamsa_aln.h:386-436) for calling into liblamsa_ref.so."""
+    _fields_ = [("n_thread", C.c_int), ("seed_len", C.c_int), ("seed_step", C.c_int), ("seed_inv", C.c_int),
+                ("per_aln_m", C.c_int), ("first_loci_thd", C.c_int), ("SV_len_thd", C.c_int), ("ske_max", C.c_int),
+                ("ovlp_rat", C.c_float), ("bwt_seed_len", C.c_int), ("bwt_max_len", C.c_int), ("bwt_min_len", C.c_int),
+                ("fastest", C.c_int), ("split_len", C.c_int), ("split_pen", C.c_int), ("res_mul_max", C.c_int),
+                ("hash_len", C.c_int), ("hash_key_len", C.c_int), ("hash_step", C.c_int), ("hash_size", C.c_int),
+                ("supp_soft", C.c_uint8), ("comm", C.c_uint8), ("outp", C.c_void_p),
+                ("match_dis", C.c_int), ("mismatch_thd", C.c_int), ("del_thd", C.c_int), ("ins_thd", C.c_int),
+                ("frag_score_table", C.c_void_p),
+                ("ins_gapo", C.c_int), ("ins_gape", C.c_int), ("del_gapo", C.c_int), ("del_gape", C.c_int),
+                ("ins_ext_o", C.c_int), ("ins_ext_e", C.c_int), ("del_ext_o", C.c_int), ("del_ext_e", C.c_int),
+                ("match", C.c_int), ("mis", C.c_int), ("sc_mat", C.c_int8 * 25),
+                ("band_w", C.c_int), ("end_bonus", C.c_int), ("zdrop", C.c_int),
+                ("ed_rate", C.c_float), ("mis_rate", C.c_float), ("id_rate", C.c_float), ("mat_rate", C.c_float),
+                ("read_type", C.c_int), ("aln_mode", C.c_uint8)]
+
+
+_oracle = None
+_ref = False
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        L = C.CDLL(os.path.join(ORACLE_DIR, "liblamsa_oracle.so"))
+        L.lo_para_init.argtypes = [C.POINTER(LoPara)]
+        L.lo_para_finish.argtypes = [C.POINTER(LoPara)]
+        _oracle = L
+    return _oracle
+
+
+def ref():
+    """The compiled reference, or None."""
+    global _ref
+    if _ref is False:
+        p = os.path.join(ORACLE_DIR, "_ref", "liblamsa_ref.so")
+        _ref = C.CDLL(p) if os.path.exists(p) else None
+    return _ref
+
+
+READ_TYPES = {"default": 0, "pacbio": 1, "ont2d": 2}
+
+
+def lo_para(read_type="default", **over):
+    L = oracle()
+    P = LoPara()
+    L.lo_para_init(C.byref(P))
+    P.read_type = READ_TYPES[read_type]
+    for k, v in over.items():
+        setattr(P, k, v)
+    L.lo_para_finish(C.byref(P))
+    return P
+
+
+def ref_para(read_type="default", **over):
+    R = ref()
+    P = RefPara()
+    R.init_aln_para(C.byref(P))
+    P.read_type = READ_TYPES[read_type]
+    for k, v in over.items():
+        setattr(P, k, v)
+    R.lamsa_set_aln_mode(C.byref(P))
+    P.seed_inv = P.seed_step - P.seed_len
+    R.lamsa_fill_mat(P.match, P.mis, P.sc_mat)
+    return P
+
+
+def cig_list(v):
+    return [int(v.c[i]) for i in range(v.n)]
+
+
+def u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
