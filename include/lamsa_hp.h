@@ -1,0 +1,114 @@
+/*
+ * lamsa_hp.h -- C-ABI of the MI355X hot-path library (liblamsa_hp.so).
+ *
+ * This is the drop-in boundary for LAMSA's per-read seed-chain-extend path: the batch
+ * form of the reference's per-read worker
+ *     int lamsa_main_aln(thread_aux_t *aux)            reference src/lamsa_aln.c:825-891
+ * which the reference calls once per thread over a chunk of reads
+ * (src/lamsa_aln.c:1143-1162).  Stages (2) chaining, (3) gap-fill/extension and the
+ * second round (2')/(3') run on the GPU behind lamsa_hp_align_batch(); seeding,
+ * FASTA/FASTQ + GEM-map parsing, the BWT rescue (stage 4), result ranking and SAM
+ * output stay with the host caller, exactly as SURVEY.md section 8(b) draws the line.
+ *
+ * Plain pointers and sizes only; every buffer handed in is caller-owned host memory,
+ * every buffer handed out is callee-owned and valid until the next call on the same
+ * handle (or lamsa_hp_destroy).  One handle per GPU; a handle is not thread-safe.
+ * All entry points return 0 on success or a negative LAMSA_HP_E* code -- never exit(),
+ * unlike the reference (src/frag_check.c:173, src/bntseq.c:471, ...).
+ */
+#ifndef LAMSA_HP_H
+#define LAMSA_HP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMSA_HP_OK          0
+#define LAMSA_HP_ENODEV     -1   /* no usable HIP device / HIP runtime error            */
+#define LAMSA_HP_EINVAL     -2   /* malformed arguments                                  */
+#define LAMSA_HP_ENOMEM     -3   /* device allocation failed                             */
+#define LAMSA_HP_EKERNEL    -4   /* kernel launch / execution failure                    */
+
+/* per-read / per-job status bits (out arrays) */
+#define LAMSA_HP_ST_OVERFLOW   1  /* a device work buffer was too small; result invalid   */
+#define LAMSA_HP_ST_REFEXIT    2  /* input on which the reference itself exit(1)s         */
+
+/* Alignment parameters after presets: the fields of the reference's lamsa_aln_para
+ * (src/lamsa_aln.h:386-436) read on the hot path.  Fill with lamsa_hp_para_init() +
+ * overrides + lamsa_hp_para_finish(), which mirror init_aln_para (src/lamsa_aln.c:1281),
+ * lamsa_set_aln_mode (:1342) and lamsa_fill_mat (:1331). */
+typedef struct lamsa_hp_para {
+    int32_t seed_len, seed_step, seed_inv;
+    int32_t per_aln_m, first_loci_thd;
+    int32_t SV_len_thd, ske_max;
+    float   ovlp_rat;
+    int32_t bwt_seed_len, bwt_max_len, bwt_min_len;
+    int32_t split_len, split_pen, res_mul_max;
+    int32_t hash_len, hash_key_len, hash_step, hash_size;
+    int32_t match_dis, mismatch_thd;
+    int32_t ins_gapo, ins_gape, del_gapo, del_gape;      /* global DP   (ksw_global2)      */
+    int32_t ins_ext_o, ins_ext_e, del_ext_o, del_ext_e;  /* extension DP (ksw_extend_core) */
+    int32_t match, mis;
+    int32_t band_w, end_bonus, zdrop;
+    float   id_rate;
+    int32_t read_type;   /* 0 default, 1 pacbio, 2 ont2d (-T) */
+    int32_t aln_mode;    /* bit0 overlapping seeds, bit1 high indel error */
+} lamsa_hp_para;
+
+void lamsa_hp_para_init(lamsa_hp_para *p);
+void lamsa_hp_para_finish(lamsa_hp_para *p);
+
+/* Packed reference: the reference's .pac bytes (2 bit/base, base k at
+ * pac[k>>2] >> ((~k&3)<<1) & 3, src/bntseq.c:242) plus the contig table of .ann
+ * (bntann1_t.offset/.len, src/bntseq.h).  Replaces the (bntseq_t*, uint8_t *pac) pair
+ * handed to every worker (src/lamsa_aln.c:1135). */
+typedef struct lamsa_hp_ref {
+    const uint8_t *pac;       /* l_pac/4+1 bytes */
+    int64_t        l_pac;
+    int32_t        n_seqs;
+    const int64_t *seq_offset;/* [n_seqs] */
+    const int32_t *seq_len;   /* [n_seqs] */
+} lamsa_hp_ref;
+
+typedef struct lamsa_hp_handle lamsa_hp_handle;
+
+/* Replaces aux_dp_init + the index hand-over of lamsa_aln_core (src/lamsa_aln.c:969-984,
+ * 1130-1137): uploads parameters and the packed reference to HBM of `device_id`. */
+int  lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para, const lamsa_hp_ref *ref, int device_id);
+void lamsa_hp_destroy(lamsa_hp_handle *h);
+const char *lamsa_hp_last_error(const lamsa_hp_handle *h);
+
+/* ------------------------------------------------------------------------------------
+ * Batched banded affine-gap DP primitives:
+ *   kind 0: ksw_global2      src/ksw.c:543   (global gap penalties, band w)
+ *   kind 1: ksw_extend_core  src/ksw.c:667   (extension gap penalties, band w, h0)
+ *   kind 2: ksw_bi_extend    src/ksw.c:862   (lh0 = rh0 = h0; w ignored)
+ * Sequences are 1 byte/base codes 0..4; job i uses query seq[q_off[i] .. q_off[i]+qlen[i])
+ * and target seq[t_off[i] .. t_off[i]+tlen[i]).
+ * ---------------------------------------------------------------------------------- */
+typedef struct lamsa_hp_dp_jobs {
+    int32_t        n_jobs;
+    const uint8_t *seq;  int64_t seq_bytes;
+    const int64_t *q_off; const int32_t *qlen;
+    const int64_t *t_off; const int32_t *tlen;
+    const int32_t *kind, *w, *h0;
+} lamsa_hp_dp_jobs;
+
+typedef struct lamsa_hp_dp_out {       /* callee-owned, valid until the next call */
+    const int32_t *score;              /* kind 0/1: DP score; kind 2: return flag */
+    const int32_t *qle, *tle;          /* kind 1 only                             */
+    const int32_t *status;             /* LAMSA_HP_ST_* bits                      */
+    const int64_t *cig_off;            /* [n_jobs+1] into cigar[]                 */
+    const int32_t *cigar;              /* len<<4|op words, ops MIDNSH as in SAM   */
+} lamsa_hp_dp_out;
+
+int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *jobs, lamsa_hp_dp_out *out);
+
+/* Wall time in milliseconds of the kernel(s) of the most recent call on this handle,
+ * measured with HIP events on the stream the kernels ran on; n-th kernel of that call. */
+float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

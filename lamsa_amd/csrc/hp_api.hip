@@ -1,0 +1,233 @@
+// hp_api.hip -- C-ABI of liblamsa_hp.so (include/lamsa_hp.h) and the gfx950 kernels behind it.
+// HIP only: there is no CPU path in this library; every entry point fails with
+// LAMSA_HP_ENODEV when no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include "hp_dp_batch.h"
+
+using namespace hp;
+
+// ------------------------------------------------------------------ kernels
+// One wavefront (64 threads) per workgroup; a persistent grid pulls units from a queue head.
+__global__ __launch_bounds__(64) void k_dp_batch(DpBatchArgs a)
+{
+    const int slot = blockIdx.x;
+    for (;;) {
+        int job = 0;
+        if (wv::leader()) job = atomicAdd(a.counter, 1);
+        job = wv::uni(job);
+        if (job >= a.n_jobs) break;
+        dp_run_job(a, job, slot);
+    }
+}
+
+// ------------------------------------------------------------------ handle
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct lamsa_hp_handle {
+    int device = 0;
+    lamsa_hp_para para;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 256;
+    // reference in HBM
+    uint8_t *d_pac = nullptr; int64_t l_pac = 0; int32_t n_seqs = 0;
+    int64_t *d_seq_off = nullptr; int32_t *d_seq_len = nullptr;
+    // reusable device buffers
+    DevBuf in, out, slab, misc;
+    // host-side result storage (callee-owned outputs)
+    std::vector<int32_t> h_i32; std::vector<int64_t> h_i64; std::vector<int32_t> h_cig;
+    std::vector<int32_t> h_score, h_qle, h_tle, h_status;
+    float kernel_ms[4] = {0, 0, 0, 0};
+    std::string err;
+};
+
+#define HIPCHK(h, call, code) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return (code); } } while (0)
+
+extern "C" void lamsa_hp_para_init(lamsa_hp_para *P)
+{   // init_aln_para, reference src/lamsa_aln.c:1281-1329
+    memset(P, 0, sizeof(*P));
+    P->seed_len = P->seed_step = -1;
+    P->per_aln_m = 200; P->first_loci_thd = 2;
+    P->SV_len_thd = 10000; P->ske_max = 10; P->ovlp_rat = (float)0.7;
+    P->split_len = 100; P->split_pen = 10; P->res_mul_max = 10;
+    P->hash_key_len = 2; P->hash_size = 16;
+    P->bwt_seed_len = 19; P->bwt_max_len = 300;
+    P->match = P->mis = -1;
+    P->ins_gapo = P->del_gapo = P->ins_gape = P->del_gape = -1;
+    P->ins_ext_o = P->del_ext_o = P->ins_ext_e = P->del_ext_e = -1;
+    P->id_rate = -1; P->read_type = 0; P->band_w = -1; P->end_bonus = -1; P->zdrop = 100; P->aln_mode = 0;
+}
+
+static inline void dfl(int32_t &x, int v) { if (x < 0) x = v; }
+extern "C" void lamsa_hp_para_finish(lamsa_hp_para *P)
+{   // lamsa_set_aln_mode, reference src/lamsa_aln.c:1342-1420; seed_inv :1523
+    const int t = P->read_type;
+    const int ext_o = t == 1 ? 2 : (t == 2 ? 1 : 5), ext_e = t == 0 ? 2 : 1;
+    dfl(P->seed_step, t == 0 ? 100 : 25); dfl(P->seed_len, 50);
+    P->hash_len = t == 0 ? 10 : 8; P->hash_step = t == 0 ? 10 : 4;
+    P->bwt_min_len = t == 0 ? P->bwt_seed_len : (t == 1 ? 50 : 100);
+    dfl(P->match, 1); dfl(P->mis, t == 0 ? 3 : 1);
+    dfl(P->ins_gapo, t == 0 ? 5 : 1); dfl(P->ins_gape, t == 0 ? 2 : 1);
+    dfl(P->del_gapo, t == 0 ? 5 : 1); dfl(P->del_gape, t == 0 ? 2 : 1);
+    dfl(P->ins_ext_o, ext_o); dfl(P->ins_ext_e, ext_e); dfl(P->del_ext_o, ext_o); dfl(P->del_ext_e, ext_e);
+    if (P->id_rate < 0) P->id_rate = t == 0 ? (float)0.04 : (t == 1 ? (float)0.3 : (float)0.1);
+    dfl(P->band_w, t == 0 ? 10 : (t == 1 ? 200 : 100)); dfl(P->end_bonus, t == 0 ? 5 : 0);
+    P->match_dis = t == 0 ? 5 : (int)ceilf(P->seed_step * P->id_rate);
+    P->mismatch_thd = 10;
+    if (t != 0) P->aln_mode |= 2;
+    if (P->seed_step < P->seed_len) P->aln_mode |= 1;
+    P->seed_inv = P->seed_step - P->seed_len;
+}
+
+extern "C" int lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para, const lamsa_hp_ref *ref, int device_id)
+{
+    if (!out || !para) return LAMSA_HP_EINVAL;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device_id < 0 || device_id >= n_dev) return LAMSA_HP_ENODEV;
+    if (hipSetDevice(device_id) != hipSuccess) return LAMSA_HP_ENODEV;
+    lamsa_hp_handle *h = new lamsa_hp_handle();
+    h->device = device_id; h->para = *para;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return LAMSA_HP_ENODEV; }
+    if (ref && ref->pac) {
+        size_t pb = (size_t)(ref->l_pac / 4 + 1);
+        h->l_pac = ref->l_pac; h->n_seqs = ref->n_seqs;
+        if (hipMalloc((void **)&h->d_pac, pb + 16) != hipSuccess ||
+            hipMalloc((void **)&h->d_seq_off, sizeof(int64_t) * (size_t)(ref->n_seqs + 1)) != hipSuccess ||
+            hipMalloc((void **)&h->d_seq_len, sizeof(int32_t) * (size_t)(ref->n_seqs + 1)) != hipSuccess) { lamsa_hp_destroy(h); return LAMSA_HP_ENOMEM; }
+        hipMemcpy(h->d_pac, ref->pac, pb, hipMemcpyHostToDevice);
+        hipMemcpy(h->d_seq_off, ref->seq_offset, sizeof(int64_t) * (size_t)ref->n_seqs, hipMemcpyHostToDevice);
+        hipMemcpy(h->d_seq_len, ref->seq_len, sizeof(int32_t) * (size_t)ref->n_seqs, hipMemcpyHostToDevice);
+    }
+    *out = h;
+    return LAMSA_HP_OK;
+}
+
+extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->d_pac) hipFree(h->d_pac);
+    if (h->d_seq_off) hipFree(h->d_seq_off);
+    if (h->d_seq_len) hipFree(h->d_seq_len);
+    h->in.release(); h->out.release(); h->slab.release(); h->misc.release();
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char *lamsa_hp_last_error(const lamsa_hp_handle *h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 4) ? h->kernel_ms[which] : -1.f; }
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, lamsa_hp_dp_out *O)
+{
+    if (!h || !J || !O || J->n_jobs < 0) return LAMSA_HP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    const int n = J->n_jobs;
+    // capacities: a DP CIGAR has at most qlen+tlen words (+ slack for the S/H pair of sw_mid_fix)
+    std::vector<int64_t> cap_off((size_t)n + 1, 0);
+    size_t z_need = 4096;
+    for (int i = 0; i < n; ++i) {
+        int ql = J->qlen[i], tl = J->tlen[i];
+        if (ql < 0) ql = 0;
+        if (tl < 0) tl = 0;
+        if (J->q_off[i] < 0 || J->t_off[i] < 0 || J->q_off[i] + ql > J->seq_bytes || J->t_off[i] + tl > J->seq_bytes) { h->err = "dp job sequence out of range"; return LAMSA_HP_EINVAL; }
+        cap_off[i + 1] = cap_off[i] + ql + tl + 8;
+        // worst-case scratch of one job: H,E rows + row bounds + direction matrix + 3 temporary CIGARs (bi-extend)
+        size_t wmax = (size_t)(abs(ql - tl) + 3 > (J->kind[i] == 2 ? h->para.band_w : J->w[i]) ? abs(ql - tl) + 3 : (J->kind[i] == 2 ? h->para.band_w : J->w[i]));
+        size_t ncol = (size_t)ql < 2 * wmax + 1 ? (size_t)ql : 2 * wmax + 1;
+        size_t need = 2 * 4 * ((size_t)ql + 18) + 8 * ((size_t)tl + 17) + ncol * tl + 64 + 3 * 4 * ((size_t)ql + tl + 24) + 1024;
+        if (need > z_need) z_need = need;
+    }
+    const size_t slab_per_wave = al256(z_need);
+    int n_waves = h->n_cu * 8;
+    if (n_waves > n) n_waves = n > 0 ? n : 1;
+    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)64 << 30)) n_waves /= 2;
+
+    // ---- pack inputs into one upload
+    size_t o_seq = 0, o_qoff = al256((size_t)J->seq_bytes + 16), o_toff = o_qoff + al256(8 * (size_t)n), o_cap = o_toff + al256(8 * (size_t)n),
+           o_ql = o_cap + al256(8 * ((size_t)n + 1)), o_tl = o_ql + al256(4 * (size_t)n), o_kind = o_tl + al256(4 * (size_t)n),
+           o_w = o_kind + al256(4 * (size_t)n), o_h0 = o_w + al256(4 * (size_t)n), in_bytes = o_h0 + al256(4 * (size_t)n);
+    if (h->in.ensure(in_bytes)) { h->err = "hipMalloc(in)"; return LAMSA_HP_ENOMEM; }
+    size_t o_score = 0, o_qle = al256(4 * (size_t)n), o_tle = 2 * o_qle, o_st = 3 * o_qle, o_cn = 4 * o_qle, o_cig = 5 * o_qle, out_bytes = o_cig + al256(4 * (size_t)cap_off[n] + 16);
+    if (h->out.ensure(out_bytes)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
+    if (h->slab.ensure(slab_per_wave * (size_t)n_waves)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    if (h->misc.ensure(256)) { h->err = "hipMalloc(misc)"; return LAMSA_HP_ENOMEM; }
+    char *din = (char *)h->in.p, *dout = (char *)h->out.p;
+    hipStream_t s = h->stream;
+    if (n > 0) {
+        HIPCHK(h, hipMemcpyAsync(din + o_seq, J->seq, (size_t)J->seq_bytes, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_qoff, J->q_off, 8 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_toff, J->t_off, 8 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_cap, cap_off.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_ql, J->qlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_tl, J->tlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_kind, J->kind, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_w, J->w, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_h0, J->h0, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+    }
+    HIPCHK(h, hipMemsetAsync(h->misc.p, 0, 256, s), LAMSA_HP_EKERNEL);
+
+    DpBatchArgs a;
+    a.P = h->para; a.n_jobs = n;
+    a.seq = (const uint8_t *)(din + o_seq); a.q_off = (const int64_t *)(din + o_qoff); a.t_off = (const int64_t *)(din + o_toff);
+    a.qlen = (const int32_t *)(din + o_ql); a.tlen = (const int32_t *)(din + o_tl); a.kind = (const int32_t *)(din + o_kind);
+    a.w = (const int32_t *)(din + o_w); a.h0 = (const int32_t *)(din + o_h0);
+    a.score = (int32_t *)(dout + o_score); a.qle = (int32_t *)(dout + o_qle); a.tle = (int32_t *)(dout + o_tle);
+    a.status = (int32_t *)(dout + o_st); a.cig_n = (int32_t *)(dout + o_cn);
+    a.cig_cap_off = (const int64_t *)(din + o_cap); a.cig = (cig_t *)(dout + o_cig);
+    a.slab = (char *)h->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)h->misc.p;
+
+    HIPCHK(h, hipEventRecord(h->ev0, s), LAMSA_HP_EKERNEL);
+    if (n > 0) hipLaunchKernelGGL(k_dp_batch, dim3(n_waves), dim3(64), 0, s, a);
+    HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventRecord(h->ev1, s), LAMSA_HP_EKERNEL);
+
+    // ---- fetch results, compact the CIGARs
+    h->h_score.assign((size_t)n, 0); h->h_qle.assign((size_t)n, 0); h->h_tle.assign((size_t)n, 0); h->h_status.assign((size_t)n, 0);
+    std::vector<int32_t> cn((size_t)n, 0), raw((size_t)cap_off[n] + 4, 0);
+    if (n > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->h_score.data(), dout + o_score, 4 * (size_t)n, hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(h->h_qle.data(), dout + o_qle, 4 * (size_t)n, hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(h->h_tle.data(), dout + o_tle, 4 * (size_t)n, hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(h->h_status.data(), dout + o_st, 4 * (size_t)n, hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(cn.data(), dout + o_cn, 4 * (size_t)n, hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(raw.data(), dout + o_cig, 4 * (size_t)cap_off[n], hipMemcpyDeviceToHost, s), LAMSA_HP_EKERNEL);
+    }
+    HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
+    hipEventElapsedTime(&h->kernel_ms[0], h->ev0, h->ev1);
+    h->h_i64.assign((size_t)n + 1, 0);
+    h->h_cig.clear();
+    for (int i = 0; i < n; ++i) {
+        h->h_i64[i] = (int64_t)h->h_cig.size();
+        h->h_cig.insert(h->h_cig.end(), raw.begin() + cap_off[i], raw.begin() + cap_off[i] + cn[i]);
+    }
+    h->h_i64[n] = (int64_t)h->h_cig.size();
+    if (h->h_cig.empty()) h->h_cig.push_back(0);
+    O->score = h->h_score.data(); O->qle = h->h_qle.data(); O->tle = h->h_tle.data(); O->status = h->h_status.data();
+    O->cig_off = h->h_i64.data(); O->cigar = h->h_cig.data();
+    return LAMSA_HP_OK;
+}

@@ -1,0 +1,101 @@
+// hp_core.h -- per-wave context, bump arena, bounded CIGAR vectors, sequence views.
+// Device code (compiled by hipcc for gfx950; the tests also compile it with the CPU
+// lane emulation of tests/emu/hp/wave.h).  Wave-uniform unless a comment says otherwise.
+#pragma once
+#include <hp/wave.h>
+#include "../../include/lamsa_hp.h"
+
+namespace hp {
+
+typedef int32_t cig_t;                       // len<<4|op, signed like the reference (src/lamsa_aln.h:210)
+enum { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5 };
+enum { ST_OVERFLOW = LAMSA_HP_ST_OVERFLOW, ST_REFEXIT = LAMSA_HP_ST_REFEXIT };
+
+#define HP_NEG_INF (-0x40000000)             // MINUS_INF, src/ksw.c:504
+
+// Bump allocator over a slab of HBM owned by this wave.  Stack discipline via mark/release.
+struct Arena {
+    char *base; size_t cap, top;
+};
+HP_INL void arena_init(Arena &a, void *base, size_t cap) { a.base = (char *)base; a.cap = cap; a.top = 0; }
+HP_INL size_t arena_mark(const Arena &a) { return a.top; }
+HP_INL void arena_release(Arena &a, size_t m) { a.top = m; }
+
+struct Ctx {
+    const lamsa_hp_para *P;   // parameters (kernel argument copy)
+    Arena tmp;                // scratch slab of this wave
+    int status;               // ST_* bits for the unit (read / job) being processed
+};
+
+// returns nullptr (and flags overflow) when the slab is exhausted; callers must cope
+HP_INL void *arena_alloc(Ctx &cx, size_t bytes) {
+    size_t b = (bytes + 15) & ~(size_t)15;
+    if (cx.tmp.top + b > cx.tmp.cap) { cx.status |= ST_OVERFLOW; return nullptr; }
+    void *p = cx.tmp.base + cx.tmp.top;
+    cx.tmp.top += b;
+    return p;
+}
+
+// bounded CIGAR vector (storage elsewhere)
+struct CigV { cig_t *c; int n, cap; };
+HP_INL void cig_bind(CigV &v, cig_t *mem, int cap) { v.c = mem; v.n = 0; v.cap = mem ? cap : 0; }
+HP_INL bool cig_alloc(Ctx &cx, CigV &v, int cap) {
+    cig_t *m = (cig_t *)arena_alloc(cx, (size_t)cap * sizeof(cig_t));
+    cig_bind(v, m, cap);
+    return m != nullptr;
+}
+HP_INL void cig_raw_push(Ctx &cx, CigV &v, cig_t w) {
+    if (v.n >= v.cap) { cx.status |= ST_OVERFLOW; return; }
+    v.c[v.n++] = w;
+}
+// _push_cigar0, src/frag_check.h:136-151
+HP_INL void cig_push0(Ctx &cx, CigV &v, cig_t w) {
+    if (v.n > 0 && (v.c[v.n - 1] & 0xf) == (w & 0xf)) { v.c[v.n - 1] += (w >> 4) << 4; return; }
+    cig_raw_push(cx, v, w);
+}
+// _push_cigar1, src/frag_check.h:153-156
+HP_INL void cig_push1(Ctx &cx, CigV &v, cig_t w) { if ((w >> 4) == 0) return; cig_push0(cx, v, w); }
+// _push_cigar, src/frag_check.h:158-184 (first word merges; I+S and S+I fuse into S)
+HP_FN void cig_pushv(Ctx &cx, CigV &v, const cig_t *c, int n) {
+    if (n == 0) return;
+    int j = 0;
+    if (v.n > 0) {
+        cig_t last = v.c[v.n - 1];
+        if ((last & 0xf) == (c[0] & 0xf)) { v.c[v.n - 1] += (c[0] >> 4) << 4; j = 1; }
+        else if (((last & 0xf) == C_I && (c[0] & 0xf) == C_S) || ((last & 0xf) == C_S && (c[0] & 0xf) == C_I)) {
+            v.c[v.n - 1] = (((last >> 4) + (c[0] >> 4)) << 4) | C_S; j = 1;
+        }
+    }
+    if (v.n + (n - j) > v.cap) { cx.status |= ST_OVERFLOW; return; }
+    for (; j < n; ++j) v.c[v.n++] = c[j];
+}
+// _invert_cigar, src/frag_check.h:124
+HP_FN void cig_invert(cig_t *c, int n) {
+    for (int i = 0; i < n / 2; ++i) { cig_t t = c[i]; c[i] = c[n - 1 - i]; c[n - 1 - i] = t; }
+}
+// readInCigar (M,I,S) / refInCigar (M,D,H), src/frag_check.c:179,205
+HP_FN int cig_readlen(const cig_t *c, int n) {
+    int l = 0;
+    for (int i = 0; i < n; ++i) { int op = c[i] & 0xf; if (op == C_M || op == C_I || op == C_S) l += c[i] >> 4; }
+    return l;
+}
+HP_FN int cig_reflen(const cig_t *c, int n) {
+    int l = 0;
+    for (int i = 0; i < n; ++i) { int op = c[i] & 0xf; if (op == C_M || op == C_D || op == C_H) l += c[i] >> 4; }
+    return l;
+}
+
+// strided view of a base sequence (stride -1 = reversed), 1 byte/base codes 0..4
+struct Seq { const uint8_t *p; int stride; };
+HP_INL int seq_at(const Seq &s, int i) { return s.p[(long)i * s.stride]; }
+HP_INL Seq seq_fwd(const uint8_t *p) { Seq s; s.p = p; s.stride = 1; return s; }
+HP_INL Seq seq_rev(const uint8_t *p, int len) { Seq s; s.p = p + (len > 0 ? len - 1 : 0); s.stride = -1; return s; }
+
+// substitution score: lamsa_fill_mat, src/lamsa_aln.c:1331-1340 (N row/column = -1)
+HP_INL int sub_score(const lamsa_hp_para *P, int t, int q) { return (t > 3 || q > 3) ? -1 : (t == q ? P->match : -P->mis); }
+
+HP_INL int iabs(int x) { return x < 0 ? -x : x; }
+HP_INL int imin(int a, int b) { return a < b ? a : b; }
+HP_INL int imax(int a, int b) { return a > b ? a : b; }
+
+}  // namespace hp

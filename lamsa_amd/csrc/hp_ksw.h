@@ -1,0 +1,372 @@
+// hp_ksw.h -- banded affine-gap DP on one wavefront.
+//
+//   ksw_global   <- ksw_global2      reference src/ksw.c:543-653
+//   ksw_extend   <- ksw_extend_core  reference src/ksw.c:667-807
+//   ksw_extend_c/_r, sw_mid_fix, ksw_bi_extend <- src/ksw.c:809-926
+//
+// Parallelisation (this is not how the reference computes, only what it computes):
+// both recurrences take E(i+1,j) and F(i,j+1) from M(i,j) = H(i-1,j-1)+S, never from
+// H(i,j), so a row depends on the previous row only.  The 64 lanes own 64 consecutive
+// band columns of the current row; F along the row is a max-plus prefix scan with linear
+// decay (wv::scan_max_excl on M-oe_ins+j*e_ins); row maximum, the "last j among equals"
+// rule, and the band shrink of the extension routine are wave reductions / ballots.
+// Rows are processed strictly in order, which keeps the reference's per-row band
+// trimming, m==0 break, z-drop test and tie rules exact.  The single in-place H/E row is
+// kept (same stale-cell behaviour outside the band as the reference's eh[] array).
+// Scores are int32 like the reference.  No MFMA: this is max-plus, not a contraction.
+#pragma once
+#include "hp_core.h"
+
+namespace hp {
+
+// ---- traceback (src/ksw.c:638-649 and :792-801); rowb == nullptr: every band cell was written ----
+HP_FN void dp_backtrack(Ctx &cx, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out)
+{
+    int which = 0;
+    out.n = 0;
+    while (i >= 0 && k >= 0) {
+        int off = i > w ? i - w : 0;
+        int cell = 255;                                   // never-written cells read as 255 (src/ksw.c:707)
+        if (!rowb || (k >= rowb[2 * i] && k < rowb[2 * i + 1])) cell = z[(long)i * n_col + (k - off)];
+        which = cell >> (which << 1) & 3;
+        if (which == 0) { cig_push0(cx, out, 1 << 4 | C_M); --i; --k; }
+        else if (which == 1) { cig_push0(cx, out, 1 << 4 | C_D); --i; }
+        else { cig_push0(cx, out, 1 << 4 | C_I); --k; }
+    }
+    if (i >= 0) cig_push0(cx, out, (i + 1) << 4 | C_D);
+    if (k >= 0) cig_push0(cx, out, (k + 1) << 4 | C_I);
+    cig_invert(out.c, out.n);
+}
+
+#define HP_SCAN_IDENT (-0x7f000000)
+
+// ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
+HP_NOINL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
+                        int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
+{
+    if (out) out->n = 0;
+    if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
+    { int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }                   // :549
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
+    const size_t mark = arena_mark(cx.tmp);
+    int32_t *H = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 1));
+    int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 1));
+    uint8_t *z = out ? (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1) : nullptr;
+    if (!H || !E || (out && !z)) { arena_release(cx.tmp, mark); return 0; }
+    const lamsa_hp_para *P = cx.P;
+
+    for (int j0 = 0; j0 <= qlen; j0 += 64) {                               // first row, :569-572
+        WAVE_FOR(l) {
+            int j = j0 + l;
+            if (j <= qlen) { H[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : HP_NEG_INF); E[j] = HP_NEG_INF; }
+        }
+    }
+    wv::sync();
+    for (int i = 0; i < tlen; ++i) {
+        const int ti = seq_at(t, i);
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
+        int carryH = H[beg];          // H(i-1,beg-1), read before the in-place update below
+        int Fin = HP_NEG_INF;         // F(i,beg)
+        H[beg] = h1_init;             // eh[beg].h = H(i,beg-1)
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int nxt = j0 + 64;
+            const int carry_next = nxt <= qlen ? H[nxt] : 0;   // old value, lane 63 is about to overwrite it
+            wv::Lane<int> m, e, key;
+            WAVE_FOR(l) {
+                int j = j0 + l;
+                if (j < end) {
+                    int hm = l == 0 ? carryH : H[j];
+                    m[l] = hm + sub_score(P, ti, seq_at(q, j));
+                    e[l] = E[j];
+                    key[l] = m[l] - oe_ins + j * e_ins;
+                } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            wv::Lane<int> fnext;
+            WAVE_FOR(l) {
+                int j = j0 + l;
+                fnext[l] = 0;
+                if (j < end) {
+                    int f = Fin - l * e_ins;                               // F(i,j) carried in from the left
+                    if (l > 0) { int g = key[l] - (j - 1) * e_ins; f = g > f ? g : f; }
+                    int mm = m[l], ee = e[l], h, tt;
+                    int dir = mm >= ee ? 0 : 1; h = mm >= ee ? mm : ee;    // ties: M over E   :598-599
+                    dir = h >= f ? dir : 2;     h = h >= f ? h : f;        //       then over F :600-601
+                    tt = mm - oe_del; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;              // :603-607
+                    tt = mm - oe_ins; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4; else f = tt;                // :608-611
+                    E[j] = ee;
+                    H[j + 1] = h;                                          // eh[j+1].h = H(i,j)
+                    if (z) z[(long)i * n_col + (j - beg)] = (uint8_t)dir;
+                    fnext[l] = f;
+                }
+            }
+            Fin = wv::bcast(fnext, 63);
+            carryH = carry_next;
+        }
+        E[end] = HP_NEG_INF;                                               // :632
+        wv::sync();
+    }
+    const int score = H[qlen];
+    if (out) {
+        int i = tlen - 1;
+        int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;                 // :638
+        dp_backtrack(cx, z, nullptr, n_col, w, i, k, *out);
+    }
+    arena_release(cx.tmp, mark);
+    return score;
+}
+
+// ---- ksw_extend_core (src/ksw.c:667-807).  Uses the *extension* gap penalties. ----
+HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
+                        int *qle, int *tle, CigV *out)
+{
+    if (out) out->n = 0;
+    if (qle) *qle = 0;
+    if (tle) *tle = 0;
+    if (qlen < 0 || tlen < 0 || h0 <= 0) { cx.status |= ST_REFEXIT; return 0; }   // :672, assert :682
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = P->ins_ext_o, e_ins = P->ins_ext_e, o_del = P->del_ext_o, e_del = P->del_ext_e;
+    const int end_bonus = P->end_bonus, zdrop = P->zdrop;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    {   // adjust w, :696-704 (double arithmetic, truncation toward zero as in the reference)
+        int mx = P->match > 0 ? P->match : 0;               // max over the 5x5 matrix (N cells are -1)
+        if (-P->mis > mx) mx = -P->mis;
+        int max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        int max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const size_t mark = arena_mark(cx.tmp);
+    int32_t *H = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
+    int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
+    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
+    if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return 0; }
+
+    // first row, :692-694: h0, h0-oe_ins, then -e_ins per column while the previous cell is > e_ins
+    {
+        const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+        // H[j] = h1v - (j-1)*e_ins for 2 <= j <= jmax where jmax is the last j with H[j-1] > e_ins
+        for (int j0 = 0; j0 <= qlen + 1; j0 += 64) {
+            WAVE_FOR(l) {
+                int j = j0 + l;
+                if (j <= qlen + 1) {
+                    int v = 0;
+                    if (j == 0) v = h0;
+                    else if (j == 1) v = h1v;
+                    else if (j <= qlen) { int prev = h1v - (j - 2) * e_ins; if (prev > e_ins) v = prev - e_ins; }
+                    H[j] = v; E[j] = 0;
+                }
+            }
+        }
+    }
+    wv::sync();
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    for (int i = 0; i < tlen; ++i) {
+        const int ti = seq_at(t, i);
+        const int d_beg = i > w ? i - w : 0;
+        if (beg < i - w) beg = i - w;                                      // :718-720
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1_init;
+        if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+        else h1_init = 0;
+        rowb[2 * i] = beg; rowb[2 * i + 1] = end;
+        int carryH = H[beg];
+        int Fin = 0;
+        long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
+        int h_last = h1_init;           // H(i,end-1), or the first-column value when the row is empty
+        // band shrink bookkeeping (:775-778): nz(j) = eh[j].h != 0 || eh[j].e != 0 after this row
+        int first_nz = -1, last_nz = -1, prev_h_nz = h1_init != 0;
+        if (beg < end) H[beg] = h1_init; else H[end] = h1_init;            // eh[end].h = h1 when the row is empty (:758)
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int nxt = j0 + 64;
+            const int carry_next = nxt <= qlen + 1 ? H[nxt] : 0;
+            wv::Lane<int> m, e, key;
+            WAVE_FOR(l) {
+                int j = j0 + l;
+                if (j < end) {
+                    int hm = l == 0 ? carryH : H[j];
+                    int M = hm ? hm + sub_score(P, ti, seq_at(q, j)) : 0;   // :737
+                    int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+                    m[l] = M; e[l] = E[j]; key[l] = tt + j * e_ins;
+                } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            wv::Lane<int> fnext, hnz, enz;
+            wv::Lane<long long> rk;
+            WAVE_FOR(l) {
+                int j = j0 + l;
+                fnext[l] = 0; hnz[l] = 0; enz[l] = 0; rk[l] = -1;
+                if (j < end) {
+                    int f = Fin - l * e_ins;
+                    if (l > 0) { int g = key[l] - (j - 1) * e_ins; f = g > f ? g : f; }
+                    int M = m[l], ee = e[l], h, tt;
+                    int dir = M > ee ? 0 : 1; h = M > ee ? M : ee;          // ties: E over M   :738-739
+                    dir = h > f ? dir : 2;    h = h > f ? h : f;            //       F over both :740-741
+                    tt = M - oe_del; tt = tt > 0 ? tt : 0; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;               // :745-750
+                    tt = M - oe_ins; tt = tt > 0 ? tt : 0; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4; else f = tt;                 // :751-755
+                    E[j] = ee;
+                    H[j + 1] = h;
+                    z[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
+                    fnext[l] = f; hnz[l] = h != 0; enz[l] = ee != 0;
+                    rk[l] = ((long long)h << 32) | (unsigned)j;
+                }
+            }
+            Fin = wv::bcast(fnext, 63);
+            carryH = carry_next;
+            {
+                long long b = wv::reduce_max64(rk);
+                if (b > best) best = b;
+                const int cnt = end - j0 < 64 ? end - j0 : 64;            // active lanes
+                unsigned long long bh = wv::ballot(hnz), be = wv::ballot(enz);
+                // nz for index j0+l: E bit l | H bit (l-1); index j0+cnt (== end on the last chunk) gets H bit cnt-1
+                unsigned long long nzm = be | (bh << 1) | (unsigned long long)(prev_h_nz ? 1 : 0);
+                unsigned long long inrow = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+                if (first_nz < 0 && (nzm & inrow)) first_nz = j0 + __builtin_ctzll(nzm & inrow);
+                if (nzm & inrow) last_nz = j0 + 63 - __builtin_clzll(nzm & inrow);
+                prev_h_nz = (int)((bh >> (cnt - 1)) & 1);
+            }
+        }
+        // H(i,end-1): value of the last computed cell (needed for gscore / eh[end].h)
+        wv::sync();
+        if (beg < end) h_last = H[end];
+        E[end] = 0;                                                        // :758
+        const int jj = beg < end ? end : beg;                              // loop variable j after the row
+        if (jj == qlen) {                                                  // :759-762
+            max_ie = gscore > h_last ? max_ie : i;
+            gscore = gscore > h_last ? gscore : h_last;
+        }
+        int mrow = 0, mj = -1;
+        if (best >= 0) { mrow = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
+        if (mrow == 0) break;                                              // :763
+        if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+        else if (zdrop > 0) {                                              // :767-773
+            if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        // shrink the band for the next row, :775-778.  index `end` itself: eh[end].h = h_last, eh[end].e = 0
+        {
+            int nb = first_nz >= 0 ? first_nz : end;                       // first j in [beg,end) that is non-zero
+            int jl;                                                        // last j in [nb,end] that is non-zero, else nb-1
+            if (h_last != 0 && end >= nb) jl = end;
+            else if (last_nz >= nb && last_nz >= 0) jl = last_nz;
+            else jl = nb - 1;
+            beg = nb;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+    }
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    if (qle) *qle = k + 1;
+    if (tle) *tle = i + 1;
+    if (out) dp_backtrack(cx, z, rowb, n_col, w, i, k, *out);
+    arena_release(cx.tmp, mark);
+    return max;
+}
+
+// ksw_extend_c (src/ksw.c:809): 0 query-to-end, 1 target-to-end, 2 neither
+HP_INL int ksw_extend_c(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, int *qle, int *tle, CigV *out)
+{
+    ksw_extend(cx, qlen, q, tlen, t, w, h0, qle, tle, out);
+    if (*qle == qlen) return 0;
+    if (*tle == tlen) return 1;
+    return 2;
+}
+// ksw_extend_r (src/ksw.c:820): same on the reversed sequences (views, nothing is copied)
+HP_INL int ksw_extend_r(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, int *qre, int *tre, CigV *out)
+{
+    Seq rq, rt;
+    rq.p = q.p + (long)(qlen > 0 ? qlen - 1 : 0) * q.stride; rq.stride = -q.stride;
+    rt.p = t.p + (long)(tlen > 0 ? tlen - 1 : 0) * t.stride; rt.stride = -t.stride;
+    ksw_extend(cx, qlen, rq, tlen, rt, w, h0, qre, tre, out);
+    if (*qre == qlen) return 0;
+    if (*tre == tlen) return 1;
+    return 2;
+}
+
+// sw_mid_fix (src/ksw.c:841-860): appends to out
+HP_FN void sw_mid_fix(Ctx &cx, CigV &out, const cig_t *lc, int ln, const cig_t *rc, int rn,
+                      int qlen, Seq q, int lqe, int rqe, int tlen, Seq t, int lte, int rte)
+{
+    const lamsa_hp_para *P = cx.P;
+    int Sn = qlen - lqe - rqe, Hn = tlen - lte - rte, half = P->split_len / 2;
+    if (iabs(Sn) >= half || iabs(Hn) >= half || iabs(Sn - Hn) >= half || tlen < 0 || qlen < 0) {
+        cig_pushv(cx, out, lc, ln);
+        cig_push0(cx, out, (Sn << 4) | C_S);
+        cig_push0(cx, out, (Hn << 4) | C_H);
+        cig_pushv(cx, out, rc, rn);
+    } else {
+        const size_t mark = arena_mark(cx.tmp);
+        CigV g;
+        if (cig_alloc(cx, g, qlen + tlen + 2)) {
+            ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &g);
+            cig_pushv(cx, out, g.c, g.n);
+        }
+        arena_release(cx.tmp, mark);
+    }
+}
+
+// the single-precision test of src/ksw.c:881,900 -- evaluated without contraction
+HP_INL bool bi_near_diag(const lamsa_hp_para *P, int qlen, int tlen)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float a = __fmul_rn((float)tlen, P->id_rate);
+    float b = __fmul_rn(a, (float)(P->aln_mode & 2));
+    float c = __fadd_rn((float)P->split_len, b);
+#else
+    volatile float a = (float)tlen * P->id_rate;
+    volatile float b = a * (float)(P->aln_mode & 2);
+    volatile float c = (float)P->split_len + b;
+#endif
+    return (float)iabs(qlen - tlen) < c;
+}
+
+// ksw_bi_extend (src/ksw.c:862-926): result replaces out; returns the "gap exists" flag
+HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, int rh0, CigV &out)
+{
+    const lamsa_hp_para *P = cx.P;
+    out.n = 0;
+    if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }
+    const size_t mark = arena_mark(cx.tmp);
+    int ret = 0, res, lqe, lte, rqe, rte;
+    CigV L, R;
+    if (!cig_alloc(cx, L, qlen + tlen + 4) || !cig_alloc(cx, R, qlen + tlen + 4)) { arena_release(cx.tmp, mark); return 0; }
+    const int w = iabs(qlen - tlen) + 3 > P->band_w ? iabs(qlen - tlen) + 3 : P->band_w;   // :873
+    res = ksw_extend_c(cx, qlen, q, tlen, t, w, lh0, &lqe, &lte, &L);
+    if (res < 2) {                                                                          // :875-880
+        cig_pushv(cx, out, L.c, L.n);
+        cig_push1(cx, out, res == 0 ? ((tlen - lte) << 4) | C_D : ((qlen - lqe) << 4) | C_I);
+    } else if (bi_near_diag(P, qlen, tlen) && ((lqe << 1 > qlen) || (lte << 1 > tlen))) {   // :881-887
+        ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
+    } else {
+        res = ksw_extend_r(cx, qlen, q, tlen, t, w, rh0, &rqe, &rte, &R);
+        if (res < 2) {                                                                      // :892-899
+            cig_push1(cx, R, res == 0 ? ((tlen - rte) << 4) | C_D : ((qlen - rqe) << 4) | C_I);
+            cig_invert(R.c, R.n);
+            cig_pushv(cx, out, R.c, R.n);
+        } else if (bi_near_diag(P, qlen, tlen) && ((rqe << 1 > qlen) || (rte << 1 > tlen))) { // :900-906
+            ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
+        } else {
+            cig_invert(R.c, R.n);
+            sw_mid_fix(cx, out, L.c, L.n, R.c, R.n, qlen, q, lqe, rqe, tlen, t, lte, rte);
+            ret = (qlen - lqe - rqe) >= P->split_len ? 1 : 0;                                // :924
+        }
+    }
+    arena_release(cx.tmp, mark);
+    return ret;
+}
+
+}  // namespace hp

@@ -1,0 +1,153 @@
+"""ctypes binding of include/lamsa_hp.h (the C-ABI of lib/liblamsa_hp.so).
+
+Mirrors the reference's worker interface as the survey draws it:
+create(para, ref) / dp_batch / align_batch / destroy.  Fails loudly when the HIP library
+is missing -- there is deliberately no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblamsa_hp.so")
+
+_I32 = ("seed_len", "seed_step", "seed_inv", "per_aln_m", "first_loci_thd", "SV_len_thd", "ske_max")
+_I32b = ("bwt_seed_len", "bwt_max_len", "bwt_min_len", "split_len", "split_pen", "res_mul_max",
+         "hash_len", "hash_key_len", "hash_step", "hash_size", "match_dis", "mismatch_thd",
+         "ins_gapo", "ins_gape", "del_gapo", "del_gape", "ins_ext_o", "ins_ext_e", "del_ext_o", "del_ext_e",
+         "match", "mis", "band_w", "end_bonus", "zdrop")
+
+
+class HpPara(C.Structure):
+    """struct lamsa_hp_para"""
+    _fields_ = [(n, C.c_int32) for n in _I32] + [("ovlp_rat", C.c_float)] + [(n, C.c_int32) for n in _I32b] + \
+               [("id_rate", C.c_float), ("read_type", C.c_int32), ("aln_mode", C.c_int32)]
+
+
+class HpRef(C.Structure):
+    _fields_ = [("pac", C.c_void_p), ("l_pac", C.c_int64), ("n_seqs", C.c_int32),
+                ("seq_offset", C.c_void_p), ("seq_len", C.c_void_p)]
+
+
+class HpDpJobs(C.Structure):
+    _fields_ = [("n_jobs", C.c_int32), ("seq", C.c_void_p), ("seq_bytes", C.c_int64),
+                ("q_off", C.c_void_p), ("qlen", C.c_void_p), ("t_off", C.c_void_p), ("tlen", C.c_void_p),
+                ("kind", C.c_void_p), ("w", C.c_void_p), ("h0", C.c_void_p)]
+
+
+class HpDpOut(C.Structure):
+    _fields_ = [("score", C.POINTER(C.c_int32)), ("qle", C.POINTER(C.c_int32)), ("tle", C.POINTER(C.c_int32)),
+                ("status", C.POINTER(C.c_int32)), ("cig_off", C.POINTER(C.c_int64)), ("cigar", C.POINTER(C.c_int32))]
+
+
+EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
+           "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms")
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load liblamsa_hp.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise RuntimeError("HIP hot-path library missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+        L = C.CDLL(path)
+        L.lamsa_hp_para_init.argtypes = [C.POINTER(HpPara)]
+        L.lamsa_hp_para_finish.argtypes = [C.POINTER(HpPara)]
+        L.lamsa_hp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(HpPara), C.POINTER(HpRef), C.c_int]
+        L.lamsa_hp_create.restype = C.c_int
+        L.lamsa_hp_destroy.argtypes = [C.c_void_p]
+        L.lamsa_hp_last_error.argtypes = [C.c_void_p]
+        L.lamsa_hp_last_error.restype = C.c_char_p
+        L.lamsa_hp_dp_batch.argtypes = [C.c_void_p, C.POINTER(HpDpJobs), C.POINTER(HpDpOut)]
+        L.lamsa_hp_dp_batch.restype = C.c_int
+        L.lamsa_hp_last_kernel_ms.argtypes = [C.c_void_p, C.c_int]
+        L.lamsa_hp_last_kernel_ms.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+READ_TYPES = {"default": 0, "pacbio": 1, "ont2d": 2}
+
+
+def make_para(read_type="default", **over):
+    L = load_library()
+    P = HpPara()
+    L.lamsa_hp_para_init(C.byref(P))
+    P.read_type = READ_TYPES[read_type]
+    for k, v in over.items():
+        setattr(P, k, v)
+    L.lamsa_hp_para_finish(C.byref(P))
+    return P
+
+
+def pack_jobs(jobs):
+    """jobs: list of (query u8 array, target u8 array) -> (seq, q_off, qlen, t_off, tlen)."""
+    n = len(jobs)
+    q_off = np.zeros(n, np.int64); t_off = np.zeros(n, np.int64)
+    qlen = np.zeros(n, np.int32); tlen = np.zeros(n, np.int32)
+    parts, pos = [], 0
+    for i, (q, t) in enumerate(jobs):
+        q_off[i] = pos; qlen[i] = len(q); parts.append(q); pos += len(q)
+        t_off[i] = pos; tlen[i] = len(t); parts.append(t); pos += len(t)
+    seq = np.concatenate(parts + [np.zeros(16, np.uint8)]).astype(np.uint8) if parts else np.zeros(16, np.uint8)
+    return seq, q_off, qlen, t_off, tlen
+
+
+class LamsaHp:
+    """One handle per GPU (not thread-safe), like one worker's thread_aux_t in the reference."""
+
+    def __init__(self, para, ref=None, device=0):
+        self.L = load_library()
+        self.para = para
+        self._h = C.c_void_p()
+        self._keep = None
+        r = None
+        if ref is not None:
+            pac, l_pac, seq_off, seq_len = ref
+            pac = np.ascontiguousarray(pac, np.uint8); seq_off = np.ascontiguousarray(seq_off, np.int64)
+            seq_len = np.ascontiguousarray(seq_len, np.int32)
+            self._keep = (pac, seq_off, seq_len)
+            r = HpRef(pac.ctypes.data, int(l_pac), len(seq_len), seq_off.ctypes.data, seq_len.ctypes.data)
+        rc = self.L.lamsa_hp_create(C.byref(self._h), C.byref(para), C.byref(r) if r is not None else None, device)
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_create failed: %d (no usable MI355X / HIP device?)" % rc)
+
+    def close(self):
+        if self._h:
+            self.L.lamsa_hp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_kernel_ms(self, which=0):
+        return float(self.L.lamsa_hp_last_kernel_ms(self._h, which))
+
+    def dp_batch(self, jobs, kind, w, h0):
+        """Run DP jobs; returns dict(score, qle, tle, status, cigars=list of lists)."""
+        seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
+        n = len(jobs)
+        kind = np.ascontiguousarray(np.broadcast_to(kind, n), np.int32)
+        w = np.ascontiguousarray(np.broadcast_to(w, n), np.int32)
+        h0 = np.ascontiguousarray(np.broadcast_to(h0, n), np.int32)
+        J = HpDpJobs(n, seq.ctypes.data, int(len(seq)), q_off.ctypes.data, qlen.ctypes.data, t_off.ctypes.data,
+                     tlen.ctypes.data, kind.ctypes.data, w.ctypes.data, h0.ctypes.data)
+        O = HpDpOut()
+        rc = self.L.lamsa_hp_dp_batch(self._h, C.byref(J), C.byref(O))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_dp_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        score = np.ctypeslib.as_array(O.score, (n,)).copy() if n else np.zeros(0, np.int32)
+        qle = np.ctypeslib.as_array(O.qle, (n,)).copy() if n else np.zeros(0, np.int32)
+        tle = np.ctypeslib.as_array(O.tle, (n,)).copy() if n else np.zeros(0, np.int32)
+        st = np.ctypeslib.as_array(O.status, (n,)).copy() if n else np.zeros(0, np.int32)
+        off = np.ctypeslib.as_array(O.cig_off, (n + 1,)).copy()
+        tot = int(off[n])
+        cg = np.ctypeslib.as_array(O.cigar, (max(tot, 1),)).copy()
+        cigars = [cg[off[i]:off[i + 1]].tolist() for i in range(n)]
+        return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)

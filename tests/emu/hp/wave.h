@@ -1,0 +1,48 @@
+// CPU lane-emulation twin of lamsa_amd/csrc/dev/hp/wave.h -- TEST INFRASTRUCTURE ONLY.
+// It lets the *same kernel sources* (hp_*.h) be compiled by g++ so the `-m "not gpu"`
+// tests and ASan/UBSan can exercise the device algorithms on the CPU.  It is never
+// part of the shipped library: the C-ABI library is built from the HIP header only.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#define HP_FN  static
+#define HP_INL static inline
+#define HP_NOINL static
+
+namespace wv {
+
+constexpr int W = 64;
+
+template <class T> struct Lane {
+    T v[64];
+    T &operator[](int l) { return v[l]; }
+    const T &operator[](int l) const { return v[l]; }
+};
+
+#define WAVE_FOR(l) for (int l = 0; l < 64; ++l)
+
+HP_INL void sync() {}
+HP_INL bool leader() { return true; }
+HP_INL int uni(int v) { return v; }
+HP_INL long long uni64(long long v) { return v; }
+HP_INL int bcast(const Lane<int> &x, int src) { return x.v[src]; }
+HP_INL unsigned long long ballot(const Lane<int> &p) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (p.v[l]) m |= 1ull << l;
+    return m;
+}
+HP_INL int reduce_max(const Lane<int> &x) { int v = x.v[0]; for (int l = 1; l < 64; ++l) v = x.v[l] > v ? x.v[l] : v; return v; }
+HP_INL int reduce_sum(const Lane<int> &x) { int v = 0; for (int l = 0; l < 64; ++l) v += x.v[l]; return v; }
+HP_INL long long reduce_max64(const Lane<long long> &x) { long long v = x.v[0]; for (int l = 1; l < 64; ++l) v = x.v[l] > v ? x.v[l] : v; return v; }
+// exclusive prefix max over lanes; lane 0 receives `ident` (not folded into the others)
+HP_INL void scan_max_excl(Lane<int> &x, int ident) {
+    int run = 0;
+    for (int l = 0; l < 64; ++l) {
+        int cur = x.v[l];
+        x.v[l] = l == 0 ? ident : run;
+        run = l == 0 ? cur : (cur > run ? cur : run);
+    }
+}
+
+}  // namespace wv

@@ -1,0 +1,41 @@
+"""Readers for the committed golden fixtures (tests/golden/)."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+READ_TYPES = ("default", "pacbio", "ont2d")
+
+
+def dp_vectors():
+    """Yield (read_type, jobs, calls) with calls = list of (kind, w, h0, expected dict)."""
+    z = np.load(os.path.join(GOLD, "dp_vectors.npz"))
+    for rt in READ_TYPES:
+        ql, tl = z[rt + "_qlen"], z[rt + "_tlen"]
+        qo = np.concatenate([[0], np.cumsum(ql)]); to = np.concatenate([[0], np.cumsum(tl)])
+        jobs = [(z[rt + "_q"][qo[i]:qo[i + 1]].copy(), z[rt + "_t"][to[i]:to[i + 1]].copy()) for i in range(len(ql))]
+        calls = []
+        ci = 0
+        while "%s_c%d_kwh" % (rt, ci) in z:
+            k = "%s_c%d_" % (rt, ci)
+            kind, w, h0 = [int(x) for x in z[k + "kwh"]]
+            cn = z[k + "cign"]; co = np.concatenate([[0], np.cumsum(cn)])
+            cig = [z[k + "cig"][co[i]:co[i + 1]].tolist() for i in range(len(cn))]
+            calls.append((kind, w, h0, dict(score=z[k + "score"], qle=z[k + "qle"], tle=z[k + "tle"], cigars=cig)))
+            ci += 1
+        yield rt, jobs, calls
+
+
+def same_dp(exp, got, kind):
+    """Bit-exact comparison of two DP result dicts; returns list of mismatching job indices."""
+    bad = []
+    for i in range(len(exp["cigars"])):
+        ok = int(exp["score"][i]) == int(got["score"][i]) and list(exp["cigars"][i]) == list(got["cigars"][i])
+        if kind == 1:
+            ok = ok and int(exp["qle"][i]) == int(got["qle"][i]) and int(exp["tle"][i]) == int(got["tle"][i])
+        if "status" in got and int(got["status"][i]) != 0:
+            ok = False
+        if not ok:
+            bad.append(i)
+    return bad

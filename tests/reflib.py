@@ -112,3 +112,98 @@ def cig_list(v):
 def u8(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+# ---------------------------------------------------------------- DP helpers (oracle / reference / CPU emulation)
+KIND_GLOBAL, KIND_EXTEND, KIND_BI = 0, 1, 2
+
+
+def oracle_dp(jobs, P, kind, w, h0):
+    """Run DP jobs through the plain-C oracle.  Returns the same dict shape as LamsaHp.dp_batch."""
+    L = oracle()
+    n = len(jobs)
+    kind = np.broadcast_to(kind, n); w = np.broadcast_to(w, n); h0 = np.broadcast_to(h0, n)
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32)
+    cigars = []
+    for i, (q, t) in enumerate(jobs):
+        ql, tl = len(q), len(t)
+        _q, qp = u8(q if ql else np.zeros(1, np.uint8)); _t, tp = u8(t if tl else np.zeros(1, np.uint8))
+        v = LoCigv(); L.lo_cigv_init(C.byref(v))
+        a, b = C.c_int(0), C.c_int(0)
+        if kind[i] == KIND_GLOBAL:
+            score[i] = L.lo_ksw_global(ql, qp, tl, tp, P.sc_mat, P.del_gapo, P.del_gape, P.ins_gapo, P.ins_gape, int(w[i]), C.byref(v))
+        elif kind[i] == KIND_EXTEND:
+            score[i] = L.lo_ksw_extend(ql, qp, tl, tp, P.sc_mat, int(w[i]), int(h0[i]), C.byref(P), C.byref(a), C.byref(b), C.byref(v))
+            qle[i], tle[i] = a.value, b.value
+        else:
+            score[i] = L.lo_ksw_bi_extend(ql, qp, tl, tp, int(h0[i]), int(h0[i]), C.byref(P), C.byref(v))
+        cigars.append(cig_list(v))
+        L.lo_cigv_free(C.byref(v))
+    return dict(score=score, qle=qle, tle=tle, status=np.zeros(n, np.int32), cigars=cigars)
+
+
+def ref_dp(jobs, P, kind, w, h0):
+    """Same through the compiled reference (ksw_global2 / ksw_extend_core / ksw_bi_extend)."""
+    R = ref()
+    n = len(jobs)
+    kind = np.broadcast_to(kind, n); w = np.broadcast_to(w, n); h0 = np.broadcast_to(h0, n)
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32)
+    cigars = []
+    for i, (q, t) in enumerate(jobs):
+        ql, tl = len(q), len(t)
+        _q, qp = u8(q if ql else np.zeros(1, np.uint8)); _t, tp = u8(t if tl else np.zeros(1, np.uint8))
+        nc, mc = C.c_int(0), C.c_int(0); cg = C.POINTER(C.c_int32)()
+        a, b = C.c_int(0), C.c_int(0)
+        if kind[i] == KIND_GLOBAL:
+            score[i] = R.ksw_global2(ql, qp, tl, tp, 5, P.sc_mat, P.del_gapo, P.del_gape, P.ins_gapo, P.ins_gape, int(w[i]), C.byref(nc), C.byref(cg))
+        elif kind[i] == KIND_EXTEND:
+            score[i] = R.ksw_extend_core(ql, qp, tl, tp, 5, P.sc_mat, int(w[i]), int(h0[i]), C.byref(P), C.byref(a), C.byref(b), C.byref(cg), C.byref(nc), C.byref(mc))
+            qle[i], tle[i] = a.value, b.value
+        else:
+            score[i] = R.ksw_bi_extend(ql, qp, tl, tp, 5, P.sc_mat, int(h0[i]), int(h0[i]), C.byref(P), C.byref(cg), C.byref(nc), C.byref(mc))
+        cigars.append([int(cg[k]) for k in range(nc.value)])
+    return dict(score=score, qle=qle, tle=tle, status=np.zeros(n, np.int32), cigars=cigars)
+
+
+_emu = None
+EMU_DIR = os.path.join(ROOT, "tests", "_build")
+
+
+def emu():
+    """The device sources compiled against the CPU lane emulation (tests/emu)."""
+    global _emu
+    if _emu is None:
+        os.makedirs(EMU_DIR, exist_ok=True)
+        out = os.path.join(EMU_DIR, "libhp_emu.so")
+        srcs = [os.path.join(ROOT, "tests", "emu", "emu_api.cpp")]
+        deps = srcs + [os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
+            [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                            "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "lamsa_amd", "csrc"),
+                            "-Wall", "-Wno-unused-function", "-o", out] + srcs, check=True)
+        _emu = C.CDLL(out)
+    return _emu
+
+
+def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
+    """Run DP jobs through the emulated device code (same kernel sources, CPU lanes)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from lamsa_amd.hp import pack_jobs
+    E = emu()
+    n = len(jobs)
+    seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
+    kind = np.ascontiguousarray(np.broadcast_to(kind, n), np.int32)
+    w = np.ascontiguousarray(np.broadcast_to(w, n), np.int32)
+    h0 = np.ascontiguousarray(np.broadcast_to(h0, n), np.int32)
+    cap = np.zeros(n + 1, np.int64)
+    cap[1:] = np.cumsum(qlen.astype(np.int64) + tlen + 8)
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32)
+    st = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(int(cap[n]) + 4, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    E.emu_dp_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 15 + [C.c_size_t]
+    E.emu_dp_batch(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), p(kind), p(w), p(h0),
+                   p(score), p(qle), p(tle), p(st), p(cn), p(cap), p(cig), slab_bytes)
+    cigars = [cig[cap[i]:cap[i] + cn[i]].tolist() for i in range(n)]
+    return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)

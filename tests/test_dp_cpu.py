@@ -1,0 +1,102 @@
+"""CPU-side checks of the banded-DP rows:
+the oracle against the reference's golden vectors (and against the reference itself when
+oracle/_ref is present), and the device kernel sources, compiled with the CPU lane
+emulation, against the oracle.  Integer work: everything is bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import dpjobs
+import goldenlib
+import reflib
+
+ERR = {"default": (0.01, 0.01, 0.01), "pacbio": (0.015, 0.09, 0.045), "ont2d": (0.04, 0.04, 0.04)}
+
+
+def test_oracle_matches_golden_dp_vectors():
+    n = 0
+    for rt, jobs, calls in goldenlib.dp_vectors():
+        P = reflib.lo_para(rt)
+        for kind, w, h0, exp in calls:
+            got = reflib.oracle_dp(jobs, P, kind, w, h0)
+            assert goldenlib.same_dp(exp, got, kind) == [], (rt, kind, w, h0)
+            n += len(jobs)
+    assert n > 2000
+
+
+@pytest.mark.skipif(reflib.ref() is None, reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_oracle_matches_reference_live(rt):
+    lp, rp = reflib.lo_para(rt), reflib.ref_para(rt)
+    jobs = dpjobs.make_jobs(900 + len(rt), 150, 350, ERR[rt])
+    for kind, w, h0 in ((0, lp.band_w, 0), (1, lp.band_w, 50), (1, 300, 19), (2, 0, 100)):
+        assert goldenlib.same_dp(reflib.ref_dp(jobs, rp, kind, w, h0), reflib.oracle_dp(jobs, lp, kind, w, h0), kind) == []
+
+
+def test_params_match_reference_presets():
+    # values of src/lamsa_aln.c:1342-1420 / lamsa_aln.h:15-90
+    d, p, o = reflib.lo_para("default"), reflib.lo_para("pacbio"), reflib.lo_para("ont2d")
+    assert (d.seed_step, d.seed_len, d.band_w, d.match_dis, d.mis, d.ins_gapo, d.end_bonus, d.aln_mode) == (100, 50, 10, 5, 3, 5, 5, 0)
+    assert (p.seed_step, p.band_w, p.match_dis, p.ins_ext_o, p.hash_len, p.hash_step, p.aln_mode) == (25, 200, 8, 2, 8, 4, 3)
+    assert (o.seed_step, o.band_w, o.match_dis, o.ins_ext_o, o.bwt_min_len, o.aln_mode) == (25, 100, 3, 1, 100, 3)
+    assert list(d.sc_mat)[:6] == [1, -3, -3, -3, -1, -3] and list(d.sc_mat)[20:] == [-1] * 5
+
+
+def hp_para_like(rt):
+    """lamsa_hp_para filled without the HIP library (host logic mirror for the emulation tests)."""
+    from lamsa_amd.hp import HpPara
+    lp = reflib.lo_para(rt)
+    P = HpPara()
+    for name, _ in HpPara._fields_:
+        setattr(P, name, getattr(lp, name))
+    return P
+
+
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_emulated_kernels_match_oracle(rt):
+    lp, P = reflib.lo_para(rt), hp_para_like(rt)
+    jobs = dpjobs.make_jobs(31 + len(rt), 120, 330, ERR[rt])
+    for kind, w, h0 in ((0, lp.band_w, 0), (0, 3, 0), (1, lp.band_w, 50), (1, lp.band_w, 8), (2, 0, 100), (2, 0, lp.hash_len * lp.match)):
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == []
+
+
+def test_emulated_kernels_edge_cases():
+    lp, P = reflib.lo_para("ont2d"), hp_para_like("ont2d")
+    rng = np.random.default_rng(5)
+    e = np.zeros(0, np.uint8)
+    t200 = rng.integers(0, 4, 200, dtype=np.uint8)
+    jobs = [(e, e), (e, t200[:7]), (t200[:7], e), (t200[:1], t200[:1]), (t200, t200), (np.full(30, 4, np.uint8), t200[:30]),
+            (t200[:130], t200[:64]), (t200[:64], t200[:65]), (t200[:129], t200[:128])]
+    for kind, w, h0 in ((0, 100, 0), (0, 1, 0), (1, 100, 50), (1, 2, 1), (2, 0, 100)):
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == []
+
+
+def test_emulated_kernels_long_extension():
+    # the rare-but-huge job of frag_head/tail_bound_fix: query ~ a whole read
+    lp, P = reflib.lo_para("ont2d"), hp_para_like("ont2d")
+    rng = np.random.default_rng(9)
+    t = rng.integers(0, 4, 3100, dtype=np.uint8)
+    q = dpjobs.mutate(rng, t[:3000], 0.04, 0.04, 0.04)
+    jobs = [(q, t)]
+    for kind, w, h0 in ((1, 100, 50), (2, 0, 100)):
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == []
+
+
+def test_cabi_library_exports_declared_symbols():
+    """The product library loads and exports every symbol include/lamsa_hp.h declares (no compute without a GPU)."""
+    import re
+    from lamsa_amd import hp
+    hdr = open(os.path.join(reflib.ROOT, "include", "lamsa_hp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # declarations only, not prose
+    declared = set(re.findall(r"\b(lamsa_hp_[a-z0-9_]+)\s*\(", hdr))
+    L = hp.load_library()
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), name
+    # host logic of the boundary: parameter presets agree with the oracle's
+    for rt in ("default", "pacbio", "ont2d"):
+        a, b = hp.make_para(rt), reflib.lo_para(rt)
+        for name, _ in hp.HpPara._fields_:
+            assert getattr(a, name) == getattr(b, name), (rt, name)

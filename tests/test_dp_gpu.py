@@ -1,0 +1,66 @@
+"""GPU parity tests of the batched banded-DP kernels through the C-ABI (lamsa_hp_dp_batch):
+HIP result == oracle == golden vectors of the reference, bit for bit."""
+import numpy as np
+import pytest
+
+import dpjobs
+import goldenlib
+import reflib
+
+pytestmark = pytest.mark.gpu
+
+ERR = {"default": (0.01, 0.01, 0.01), "pacbio": (0.015, 0.09, 0.045), "ont2d": (0.04, 0.04, 0.04)}
+
+
+@pytest.fixture(scope="module")
+def handles():
+    from lamsa_amd import hp
+    hs = {rt: hp.LamsaHp(hp.make_para(rt)) for rt in ("default", "pacbio", "ont2d")}
+    yield hs
+    for h in hs.values():
+        h.close()
+
+
+def test_hip_matches_golden_dp_vectors(handles):
+    n = 0
+    for rt, jobs, calls in goldenlib.dp_vectors():
+        for kind, w, h0, exp in calls:
+            got = handles[rt].dp_batch(jobs, kind, w, h0)
+            assert goldenlib.same_dp(exp, got, kind) == [], (rt, kind, w, h0)
+            n += len(jobs)
+    assert n > 2000
+
+
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_hip_matches_oracle_fuzz(handles, rt):
+    lp = reflib.lo_para(rt)
+    jobs = dpjobs.make_jobs(4000 + len(rt), 1500, 600, ERR[rt])
+    for kind, w, h0 in ((0, lp.band_w, 0), (0, 2, 0), (1, lp.band_w, 50), (1, lp.band_w, lp.hash_len * lp.match), (2, 0, 100)):
+        got = handles[rt].dp_batch(jobs, kind, w, h0)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (rt, kind, w, h0)
+
+
+def test_hip_edge_cases(handles):
+    lp = reflib.lo_para("ont2d")
+    rng = np.random.default_rng(5)
+    e = np.zeros(0, np.uint8)
+    t200 = rng.integers(0, 4, 200, dtype=np.uint8)
+    jobs = [(e, e), (e, t200[:7]), (t200[:7], e), (t200[:1], t200[:1]), (t200, t200), (np.full(30, 4, np.uint8), t200[:30]),
+            (t200[:130], t200[:64]), (t200[:64], t200[:65]), (t200[:129], t200[:128])]
+    for kind, w, h0 in ((0, 100, 0), (0, 1, 0), (1, 100, 50), (1, 2, 1), (2, 0, 100)):
+        got = handles["ont2d"].dp_batch(jobs, kind, w, h0)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == []
+    assert handles["ont2d"].dp_batch([], 0, 10, 0)["cigars"] == []
+
+
+def test_hip_whole_read_extension(handles):
+    """Maximum-size jobs: 10 kbp / w=100 and 20 kbp / w=200 extensions (traceback 2 MB / 8 MB)."""
+    for rt, L, sub in (("ont2d", 10000, (0.04, 0.04, 0.04)), ("pacbio", 20000, (0.01, 0.09, 0.05))):
+        lp = reflib.lo_para(rt)
+        rng = np.random.default_rng(L)
+        t = rng.integers(0, 4, L + 200, dtype=np.uint8)
+        q = dpjobs.mutate(rng, t[:L], *sub)
+        jobs = [(q, t), (q[:L // 2], t[:L // 2 + 300])]
+        for kind, w, h0 in ((1, lp.band_w, 50), (2, 0, 100)):
+            got = handles[rt].dp_batch(jobs, kind, w, h0)
+            assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (rt, kind)
