@@ -39,3 +39,26 @@ def same_dp(exp, got, kind):
         if not ok:
             bad.append(i)
     return bad
+
+
+SCENARIOS = ("c1_perfect", "c2_pacbio", "c3_ont", "c4_pb20k", "c5_sv", "c6_edge")
+
+
+def stage_scenario(name, tmpdir):
+    """Materialise a whole-path fixture in tmpdir (the GEM map is stored gzipped).
+    Returns (ref_prefix, reads_path, args list, golden SAM text without @PG)."""
+    import gzip
+    import shutil
+    d = os.path.join(GOLD, name)
+    for ext in (".ann", ".amb", ".pac"):
+        shutil.copy(os.path.join(GOLD, "ref", "ref.fa" + ext), os.path.join(tmpdir, "ref.fa" + ext))
+    shutil.copy(os.path.join(d, "reads.fa"), os.path.join(tmpdir, "reads.fa"))
+    with gzip.open(os.path.join(d, "reads.fa.seed.gem.map.gz"), "rb") as f, open(os.path.join(tmpdir, "reads.fa.seed.gem.map"), "wb") as g:
+        g.write(f.read())
+    args = open(os.path.join(d, "args.txt")).read().split()
+    gold = open(os.path.join(d, "golden_R0.sam")).read()
+    return os.path.join(tmpdir, "ref.fa"), os.path.join(tmpdir, "reads.fa"), args, gold
+
+
+def strip_pg(text):
+    return "".join(l + "\n" for l in text.split("\n") if l and not l.startswith("@PG"))
