@@ -104,6 +104,56 @@ typedef struct lamsa_hp_dp_out {       /* callee-owned, valid until the next cal
 
 int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *jobs, lamsa_hp_dp_out *out);
 
+
+/* ------------------------------------------------------------------------------------
+ * The hot path proper: stages (2) sparse-DP chaining (frag_line_BCC, src/lamsa_dp_con.c:1305),
+ * (3) gap-fill / split extension (frag_check, src/frag_check.c:856), and the second round
+ * (2')/(3') on the read regions left uncovered (frag_line_remain :1252), for a batch of reads.
+ * Replaces the loop body of lamsa_main_aln (src/lamsa_aln.c:857-871) for every read of a
+ * chunk; the inputs are what the reference keeps in lamsa_seq_t / map_msg / map_t
+ * (src/lamsa_aln.c:782-795, src/lamsa_aln.h:230-245), laid out as struct-of-arrays.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lamsa_hp_batch {
+    int32_t        n_reads;
+    const int64_t *read_off;   /* [n_reads+1] into read_seq                                  */
+    const uint8_t *read_seq;   /* 1 byte/base codes 0..4 (nst_nt4_table, src/bntseq.c:20)    */
+    const int32_t *seed_all;   /* [n_reads] number of seeds of the read (APP->seed_all)      */
+    const int32_t *last_len;   /* [n_reads] APP->last_len                                    */
+    const int64_t *seed_off;   /* [n_reads+1]: read r owns seed slots [seed_off[r], seed_off[r+1]) = m_msg[0..seed_out) */
+    const int32_t *seed_id;    /* [n_slots] 1-based seed index (map_msg.seed_id)             */
+    const int64_t *hit_off;    /* [n_slots+1]: slot s owns hits [hit_off[s], hit_off[s+1]) = map[0..map_n) */
+    const int64_t *h_pos;      /* [n_hits] map_t.offset (1-based leftmost reference coord)   */
+    const int32_t *h_chr;      /* map_t.nchr (1-based contig id)                             */
+    const int8_t  *h_strand;   /* map_t.nstrand (+1 / -1)                                    */
+    const int16_t *h_nm;       /* map_t.NM                                                   */
+    const int16_t *h_len_dif;  /* map_t.len_dif                                              */
+    const int32_t *h_cig_off;  /* start of the seed CIGAR in cig[]                           */
+    const uint8_t *h_cig_n;    /* its length in words                                        */
+    const int32_t *cig;        /* seed CIGAR words (already reversed for '-' hits, src/gem_parse.c:267) */
+    int64_t        n_cig;
+} lamsa_hp_batch;
+
+/* Results: one int32 stream per read (callee-owned, valid until the next call):
+ *   [0] status bits (LAMSA_HP_ST_*)  [1] lines of round 1 (a_res[0].l_n)  [2] lines of round 2 (a_res[1].l_n)
+ *   per line : line_score, tol_score, tol_NM, n_res (= cur_res_n+1, 0 when every record was dropped)
+ *   per res  : offset_lo, offset_hi, chr, nstrand (1 '+', 0 '-'), score (AS), NM, cigar_n, cigar words...
+ * i.e. the fields of line_aln_res / res_t (src/frag_check.h:46-73) that aln_res_output and
+ * rearr_aln_res consume. */
+typedef struct lamsa_hp_result {
+    const int32_t *stream; int64_t stream_words;
+    const int64_t *read_off;      /* [n_reads] start of read r's stream */
+    const int32_t *read_len;      /* [n_reads] its length in words      */
+    const int32_t *read_status;   /* [n_reads] LAMSA_HP_ST_* bits       */
+} lamsa_hp_result;
+
+int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_hp_result *res);
+
+/* The same in two steps, so that a caller can keep a batch resident in HBM and overlap or
+ * repeat the compute: upload copies the batch to the device, run aligns the resident batch
+ * (res may be NULL: results stay on the device and are not fetched). */
+int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch);
+int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
+
 /* Wall time in milliseconds of the kernel(s) of the most recent call on this handle,
  * measured with HIP events on the stream the kernels ran on; n-th kernel of that call. */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);

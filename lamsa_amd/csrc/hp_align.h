@@ -1,0 +1,180 @@
+// hp_align.h -- one read on one wavefront: stages (2) chaining, (3) gap-fill / extension, and the
+// second round (2')/(3') on the uncovered read regions -- the body of the reference's per-read
+// worker lamsa_main_aln (src/lamsa_aln.c:857-871), minus stage (4)/(5)/(6) which stay on the host.
+#pragma once
+#include "hp_fill.h"
+
+namespace hp {
+
+// ---- covered intervals of the first round and the regions they leave uncovered ----
+// push_reg_res (lamsa_aln.c:571), aln_sort_reg (:477), aln_merg_reg (:499), get_remain_reg (:550)
+HP_FN void regs_push(ReadCtx &r, Regs &G, int cap, const Rec &rec)
+{
+    if (G.n >= cap) { r.cx.status |= ST_OVERFLOW; return; }
+    const cig_t *c = rec.cig.c; const int n = rec.cig.n, k = G.n;
+    const int reflen = cig_reflen(c, n);
+    G.rb[k].chr = G.re[k].chr = rec.chr; G.rb[k].is_rev = G.re[k].is_rev = 1 - rec.nstrand;
+    if (rec.nstrand == 1) {
+        G.beg[k] = (c[0] & 0xf) == C_S ? (c[0] >> 4) + 1 : 1;
+        G.end[k] = (c[n - 1] & 0xf) == C_S ? r.L - (c[n - 1] >> 4) : r.L;
+        G.rb[k].pos = rec.offset; G.re[k].pos = rec.offset + reflen - 1;
+    } else {
+        G.beg[k] = (c[n - 1] & 0xf) == C_S ? (c[n - 1] >> 4) + 1 : 1;
+        G.end[k] = (c[0] & 0xf) == C_S ? r.L - (c[0] >> 4) : r.L;
+        G.re[k].pos = rec.offset; G.rb[k].pos = rec.offset + reflen - 1;
+    }
+    ++G.n;
+}
+
+HP_NOINL void regs_remain(ReadCtx &r, Regs &G, int min_thd, int max_thd)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    G.m = 0;
+    if (G.n == 0) {
+        if (min_thd < r.L && r.L <= max_thd) { G.r_beg[0] = 1; G.r_end[0] = r.L; G.r_bs[0] = G.r_bn[0] = G.r_es[0] = G.r_en[0] = 0; G.m = 1; }
+        return;
+    }
+    for (int i = 1; i < G.n; ++i) {                        // stable sort by beg
+        const int b = G.beg[i], e = G.end[i]; const RegB rb = G.rb[i], re = G.re[i];
+        int k = i - 1;
+        while (k >= 0 && G.beg[k] > b) { G.beg[k + 1] = G.beg[k]; G.end[k + 1] = G.end[k]; G.rb[k + 1] = G.rb[k]; G.re[k + 1] = G.re[k]; --k; }
+        G.beg[k + 1] = b; G.end[k + 1] = e; G.rb[k + 1] = rb; G.re[k + 1] = re;
+    }
+    // merge neighbours closer than bwt_seed_len; a merged group is the index range [gs, ge) of the sorted intervals,
+    // its ref_beg / ref_end lists are exactly rb[gs..ge) / re[gs..ge)
+    int gs = 0, g_beg = G.beg[0], g_end = G.end[0];
+    int prev_gs = -1, prev_ge = -1, prev_end = 0, first = 1;
+    for (int i = 1; i <= G.n; ++i) {
+        if (i < G.n && G.beg[i] - g_end - 1 < P->bwt_seed_len) { if (G.end[i] > g_end) g_end = G.end[i]; continue; }
+        // group [gs, i) is final
+        if (first) {
+            if (g_beg > min_thd && g_beg - 1 <= max_thd) { const int m = G.m++; G.r_beg[m] = 1; G.r_end[m] = g_beg - 1; G.r_bs[m] = 0; G.r_bn[m] = 0; G.r_es[m] = gs; G.r_en[m] = i - gs; }
+            first = 0;
+        } else if (g_beg - prev_end > min_thd && g_beg - 1 - prev_end <= max_thd) {
+            const int m = G.m++; G.r_beg[m] = prev_end + 1; G.r_end[m] = g_beg - 1; G.r_bs[m] = prev_gs; G.r_bn[m] = prev_ge - prev_gs; G.r_es[m] = gs; G.r_en[m] = i - gs;
+        }
+        prev_gs = gs; prev_ge = i; prev_end = g_end;
+        if (i < G.n) { gs = i; g_beg = G.beg[i]; g_end = G.end[i]; }
+    }
+    if (r.L - prev_end > min_thd && r.L - prev_end <= max_thd) {
+        const int m = G.m++; G.r_beg[m] = prev_end + 1; G.r_end[m] = r.L; G.r_bs[m] = prev_gs; G.r_bn[m] = prev_ge - prev_gs; G.r_es[m] = 0; G.r_en[m] = 0;
+    }
+}
+
+// ---- result stream (hp_batch.h) ----
+struct OutBuf { int32_t *w; int n, cap; };
+HP_INL void out_put(Ctx &cx, OutBuf &o, int32_t v) { if (o.n < o.cap) o.w[o.n++] = v; else cx.status |= ST_OVERFLOW; }
+
+HP_FN void out_line(Ctx &cx, OutBuf &o, const LineRes &la)
+{
+    out_put(cx, o, la.line_score); out_put(cx, o, la.tol_score); out_put(cx, o, la.tol_NM); out_put(cx, o, la.cur_res_n + 1);
+    for (int j = 0; j <= la.cur_res_n; ++j) {
+        const Rec &rec = la.rec[j];
+        out_put(cx, o, (int32_t)(rec.offset & 0xffffffffll)); out_put(cx, o, (int32_t)(rec.offset >> 32));
+        out_put(cx, o, rec.chr); out_put(cx, o, rec.nstrand); out_put(cx, o, rec.score); out_put(cx, o, rec.NM); out_put(cx, o, rec.cig.n);
+        if (o.n + rec.cig.n <= o.cap) { for (int k = 0; k < rec.cig.n; ++k) o.w[o.n + k] = rec.cig.c[k]; o.n += rec.cig.n; }
+        else cx.status |= ST_OVERFLOW;
+    }
+}
+
+// frag_check over all lines of one round (frag_check.c:886-955) + get_reg (lamsa_aln.c:597) for round 1
+HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap, int scale)
+{
+    Ctx &cx = r.cx;
+    const size_t mark = arena_mark(cx.tmp);
+    const int cur_cap = (2 * r.L + 512) * scale;
+    LineRes *la = (LineRes *)arena_alloc(cx, sizeof(LineRes));
+    cig_t *cur_buf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)cur_cap);
+    cig_t *rec_buf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(cur_cap + 4 * HP_REC_MAX));
+    if (!la || !cur_buf || !rec_buf) { arena_release(cx.tmp, mark); return; }
+    for (int j = 0; j < F.n; ++j) {
+        if (!fill_line(r, F, j, *la, cur_buf, cur_cap, rec_buf, cur_cap + 4 * HP_REC_MAX)) break;
+        out_line(cx, o, *la);
+        if (G && la->tol_score >= 0) for (int k = 0; k <= la->cur_res_n; ++k) regs_push(r, *G, reg_cap, la->rec[k]);
+    }
+    arena_release(cx.tmp, mark);
+}
+
+// ---- the per-read entry point ----
+HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
+{
+    ReadCtx r;
+    r.cx.P = &a.P; r.cx.status = 0;
+    arena_init(r.cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
+    r.ref = a.ref;
+    const BatchIn &in = a.in;
+    r.L = (int)(in.read_off[rd + 1] - in.read_off[rd]);
+    r.read = in.read_seq + in.read_off[rd];
+    r.seed_all = in.seed_all[rd]; r.last_len = in.last_len[rd];
+    const int64_t s0 = in.seed_off[rd];
+    r.seed_out = (int)(in.seed_off[rd + 1] - s0);
+    r.seed_id = in.seed_id + s0; r.hit_off = in.hit_off + s0;
+    r.hb = r.hit_off[0];
+    r.H = (int)(r.hit_off[r.seed_out] - r.hb);
+    r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
+    r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
+    r.flip = false; r.cur_read = r.read; r.rc_ready = false;
+    Ctx &cx = r.cx;
+    const int H = r.H;
+    // read-lifetime allocations
+    const int out_cap = 64 + 12 * r.L * a.scale;
+    OutBuf o; o.n = 0; o.cap = out_cap;
+    o.w = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)out_cap);
+    r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
+    int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 13 * (size_t)(H + 1));
+    int8_t *nb = (int8_t *)arena_alloc(cx, 3 * (size_t)(H + 1));
+    const int reg_cap = 256 * a.scale;
+    Regs G; G.n = 0; G.m = 0;
+    G.beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)reg_cap); G.end = G.beg + reg_cap;
+    G.rb = (RegB *)arena_alloc(cx, sizeof(RegB) * 2 * (size_t)reg_cap); G.re = G.rb + reg_cap;
+    G.r_beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 6 * (size_t)(reg_cap + 2));
+    G.r_end = G.r_beg + (reg_cap + 2); G.r_bs = G.r_end + (reg_cap + 2); G.r_bn = G.r_bs + (reg_cap + 2); G.r_es = G.r_bn + (reg_cap + 2); G.r_en = G.r_es + (reg_cap + 2);
+    int n0_pos = 1, n1_pos = 2;
+    if (o.w && r.rc_read && nm && nb && G.beg && G.rb && G.r_beg) {
+        const int c = H + 1;
+        r.n_score = nm; r.n_NM = nm + c; r.n_from = nm + 2 * c; r.n_in_de = nm + 3 * c; r.n_son_n = nm + 4 * c; r.n_first = nm + 5 * c;
+        r.n_last = nm + 6 * c; r.n_next = nm + 7 * c; r.n_max_score = nm + 8 * c; r.n_max_NM = nm + 9 * c; r.n_max_node = nm + 10 * c;
+        r.n_node_n = nm + 11 * c; r.n_seed = nm + 12 * c;
+        r.n_dp_flag = nb; r.n_match_flag = (uint8_t *)(nb + c); r.n_son_flag = (uint8_t *)(nb + 2 * c);
+        for (int s = 0; s < r.seed_out; ++s) {                  // slot of every hit
+            const int b = hoff(r, s), e = hoff(r, s + 1);
+            for (int k0 = b; k0 < e; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < e) r.n_seed[k] = s; } }
+        }
+        wv::sync();
+        out_put(cx, o, 0); out_put(cx, o, 0); out_put(cx, o, 0);
+        // round 1: frag_line_BCC + frag_check + get_reg   (lamsa_aln.c:857-865)
+        {
+            const size_t mark = arena_mark(cx.tmp);
+            FLines F;
+            if (chain_first(r, F) && F.n > 0) { o.w[n0_pos] = F.n; fill_round(r, F, o, &G, reg_cap, a.scale); }
+            arena_release(cx.tmp, mark);
+        }
+        // round 2: frag_line_remain + frag_check          (lamsa_aln.c:867-871)
+        if (!(cx.status & (ST_REFEXIT | ST_OVERFLOW))) {
+            const size_t mark = arena_mark(cx.tmp);
+            regs_remain(r, G, a.P.seed_len, r.L);
+            FLines F;
+            if (chain_remain(r, G, F) && F.n > 0) { o.w[n1_pos] = F.n; fill_round(r, F, o, nullptr, 0, a.scale); }
+            arena_release(cx.tmp, mark);
+        }
+    }
+    // publish: reserve the exact size in the global arena, copy with all lanes
+    const int st = cx.status;
+    int n_words = (st & (ST_REFEXIT | ST_OVERFLOW)) || !o.w ? 3 : o.n;
+    unsigned long long off = 0;
+    if (wv::leader()) off = atomicAdd(a.out.cursor, (unsigned long long)n_words);
+    off = (unsigned long long)wv::uni64((long long)off);
+    if ((int64_t)(off + (unsigned long long)n_words) <= a.out.stream_cap) {
+        int32_t *dst = a.out.stream + off;
+        if (n_words == 3 && (!o.w || (st & (ST_REFEXIT | ST_OVERFLOW)))) { dst[0] = st; dst[1] = 0; dst[2] = 0; }
+        else {
+            o.w[0] = st;
+            wv::sync();
+            for (int b = 0; b < n_words; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < n_words) dst[i] = o.w[i]; } }
+        }
+        a.out.read_out_off[rd] = (int64_t)off; a.out.read_out_len[rd] = n_words;
+    } else { a.out.read_out_off[rd] = -1; a.out.read_out_len[rd] = 0; }
+    a.out.read_status[rd] = st;
+}
+
+}  // namespace hp

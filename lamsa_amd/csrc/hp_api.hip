@@ -26,40 +26,7 @@ __global__ __launch_bounds__(64) void k_dp_batch(DpBatchArgs a)
     }
 }
 
-// ------------------------------------------------------------------ handle
-struct DevBuf {
-    void *p = nullptr; size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 4 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct lamsa_hp_handle {
-    int device = 0;
-    lamsa_hp_para para;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int n_cu = 256;
-    // reference in HBM
-    uint8_t *d_pac = nullptr; int64_t l_pac = 0; int32_t n_seqs = 0;
-    int64_t *d_seq_off = nullptr; int32_t *d_seq_len = nullptr;
-    // reusable device buffers
-    DevBuf in, out, slab, misc;
-    // host-side result storage (callee-owned outputs)
-    std::vector<int32_t> h_i32; std::vector<int64_t> h_i64; std::vector<int32_t> h_cig;
-    std::vector<int32_t> h_score, h_qle, h_tle, h_status;
-    float kernel_ms[4] = {0, 0, 0, 0};
-    std::string err;
-};
-
-#define HIPCHK(h, call, code) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return (code); } } while (0)
+#include "hp_handle.h"
 
 extern "C" void lamsa_hp_para_init(lamsa_hp_para *P)
 {   // init_aln_para, reference src/lamsa_aln.c:1281-1329
@@ -123,10 +90,12 @@ extern "C" int lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para,
     return LAMSA_HP_OK;
 }
 
+extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h);
 extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    lamsa_hp_release_state_(h);
     if (h->d_pac) hipFree(h->d_pac);
     if (h->d_seq_off) hipFree(h->d_seq_off);
     if (h->d_seq_len) hipFree(h->d_seq_len);
@@ -140,7 +109,6 @@ extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
 extern "C" const char *lamsa_hp_last_error(const lamsa_hp_handle *h) { return h ? h->err.c_str() : "null handle"; }
 extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 4) ? h->kernel_ms[which] : -1.f; }
 
-static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, lamsa_hp_dp_out *O)
 {

@@ -1,0 +1,856 @@
+// hp_chain.h -- sparse-DP chaining of seed hits into lines on one wavefront
+// (reference src/lamsa_dp_con.c + src/lamsa_heap.c).
+//
+//   edge_flag      <- get_fseed_dis             lamsa_dp_con.c:596
+//   dp_update      <- frag_dp_update            :701   predecessor scan spread over the 64 lanes
+//   min_extend     <- frag_min_extend           :1031  candidate scan spread over the 64 lanes
+//   branch_track / cut_branch / best_son <- :873,:831,:808   (pointer chasing, wave-uniform)
+//   mini_line      <- frag_mini_dp_line         :1068
+//   multi_line     <- frag_mini_dp_multi_line   :923
+//   set_bound      <- line_set_bound(1)         :425,:496 (minus E_LB/E_RB, which nothing reads)
+//   build_flines   <- frag_dp_path              :1152 (+ line_filter_overlap :568)
+//   chain_first    <- frag_line_BCC             :1305
+//   chain_remain   <- frag_line_remain          :1252
+//
+// Targets are processed strictly in the reference's order (the son_flag side effect of a
+// chosen predecessor is visible to later targets, :718-720/:754), only the scan over the
+// predecessors of one target is parallel: lanes evaluate 64 predecessors at a time and a
+// wave reduction picks the winner by (score desc, NM asc, scan order asc), with the
+// "first '-' strand match precursor wins outright" rule (:726-733) as a second reduction.
+// Nodes are struct-of-arrays in the wave's HBM slab; sons are intrusive linked lists.
+#pragma once
+#include "hp_batch.h"
+
+namespace hp {
+
+enum { F_MATCH = 0, F_SPLIT_MATCH = 1, F_MISMATCH = 2, F_MATCH_THD = 2, F_LONG_MISMATCH = 3, F_INSERT = 4, F_DELETE = 5,
+       F_CHR_DIF = 6, F_REVERSE = 7, F_UNCONNECT = 8, F_UNMATCH = 9, F_INIT = 20 };
+enum { MIN_FLAG = 1, MULTI_FLAG = 2, UNLIMITED_FLAG = 3, WHOLE_FLAG = 4, TRACKED_FLAG = 5 };
+enum { L_MERGB = 0, L_NMERG = 1, L_MERGH = 2, L_INTER = 4, L_DUMP = 8 };
+
+HP_INL int score_table(int flag) { return flag <= 3 ? 1 : (flag <= 7 ? -3 : -6); }   // f_BCC_score_table, lamsa_aln.c:177
+
+// limits of the packed reduction key in dp_update (checked on the host before launch)
+#define HP_MAX_SLOTS 16383
+#define HP_MAX_HITS_PER_SEED 16383
+
+// one read being aligned by this wave
+struct ReadCtx {
+    Ctx cx;
+    RefView ref;
+    int L, seed_all, seed_out, last_len, H;
+    const uint8_t *read;        // forward read, codes 0..4
+    uint8_t *rc_read; bool rc_ready;   // reverse complement, filled on first use (frag_check.c:922-925)
+    const uint8_t *cur_read;    // strand-appropriate read of the line being filled
+    bool flip;                  // seed ids flipped (k -> seed_all+1-k) while a '-' line is filled (frag_check.c:926,953)
+    const int32_t *seed_id;     // [seed_out]
+    const int64_t *hit_off;     // [seed_out+1], global; local hit index = global - hb
+    int64_t hb;
+    const int64_t *h_pos; const int32_t *h_chr, *h_cig_off; const int16_t *h_nm, *h_len_dif;
+    const int8_t *h_strand; const uint8_t *h_cig_n; const int32_t *cig;
+    // chaining DP cells (frag_dp_node, lamsa_aln.h:352-373), indexed by local hit index
+    int32_t *n_score, *n_NM, *n_from, *n_in_de, *n_son_n, *n_first, *n_last, *n_next;
+    int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
+    int8_t *n_dp_flag; uint8_t *n_match_flag, *n_son_flag;
+};
+
+HP_INL int hoff(const ReadCtx &r, int x) { return (int)(r.hit_off[x] - r.hb); }
+HP_INL int mapn(const ReadCtx &r, int x) { return (int)(r.hit_off[x + 1] - r.hit_off[x]); }
+HP_INL int sid(const ReadCtx &r, int x) { int s = r.seed_id[x]; return r.flip ? r.seed_all + 1 - s : s; }
+HP_INL int nx(const ReadCtx &r, int node) { return node < 0 ? -1 : r.n_seed[node]; }
+
+// ---------------------------------------------------------------- edge classification (get_fseed_dis, :596-634)
+HP_INL int edge_flag(const ReadCtx &r, int pre, int cur)
+{
+    if (pre < 0 || cur < 0) return F_MATCH;
+    if (pre == cur) return F_MATCH;
+    const int xp = r.n_seed[pre], xc = r.n_seed[cur];
+    if (xp == xc) return F_UNCONNECT;
+    const int sp = r.h_strand[pre];
+    if (r.h_chr[cur] != r.h_chr[pre] || r.h_strand[cur] != sp) return F_CHR_DIF;
+    const lamsa_hp_para *P = r.cx.P;
+    const int idp = sid(r, xp), idc = sid(r, xc), did = iabs(idp - idc);
+    if (did * P->seed_step < P->seed_len) return F_UNCONNECT;
+    const int64_t exp = r.h_pos[pre] + (int64_t)(sp * (idc - idp) * P->seed_step);
+    const int64_t act = r.h_pos[cur];
+    const int dis = (int)((int64_t)sp * ((idp < idc) ? (act - exp) : (exp - act))
+                          - ((sp * (idp - idc) < 0) ? r.h_len_dif[pre] : r.h_len_dif[cur]));
+    const int mat_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
+    if (dis <= mat_dis && dis >= -mat_dis) {
+        if (did == 1) return F_MATCH;
+        if (did <= 3 * P->mismatch_thd) return F_MISMATCH;
+        return F_LONG_MISMATCH;
+    }
+    if (dis > mat_dis && dis < P->SV_len_thd) return F_DELETE;
+    if ((dis < -mat_dis && dis >= 0 - (did * P->seed_step - P->seed_len)) ||
+        (dis < -(P->split_len / 2) && dis >= -P->SV_len_thd)) return F_INSERT;
+    return F_UNCONNECT;
+}
+
+// ---------------------------------------------------------------- node helpers
+HP_INL void node_set(ReadCtx &r, int n, int from, int score, int NM, int match_flag, int dp_flag)
+{   // fnode_set, :636
+    r.n_son_flag[n] = F_INIT; r.n_from[n] = from; r.n_score[n] = score; r.n_NM[n] = NM;
+    r.n_match_flag[n] = (uint8_t)match_flag; r.n_dp_flag[n] = (int8_t)dp_flag;
+    r.n_node_n[n] = 1; r.n_in_de[n] = 0; r.n_son_n[n] = 0; r.n_first[n] = -1; r.n_last[n] = -1;
+    r.n_max_score[n] = score; r.n_max_NM[n] = NM; r.n_max_node[n] = n;
+}
+HP_FN void node_per_init(ReadCtx &r, int n, int from, int dp_flag)
+{   // frag_dp_per_init, :766
+    if (from < 0) { node_set(r, n, from, 1, r.h_nm[n], F_MATCH, dp_flag); return; }
+    int flag = edge_flag(r, from, n);
+    if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, n, from, 2 + score_table(flag), r.h_nm[n] + r.h_nm[from], flag, dp_flag);
+    else r.n_dp_flag[n] = (int8_t)(0 - dp_flag);
+}
+HP_INL void add_son(ReadCtx &r, int fa, int son)
+{   // fnode_add_son, :683 (append keeps insertion order, which get_max_son depends on)
+    ++r.n_in_de[fa];
+    r.n_next[son] = -1;
+    if (r.n_son_n[fa] == 0) r.n_first[fa] = son; else r.n_next[r.n_last[fa]] = son;
+    r.n_last[fa] = son;
+    ++r.n_son_n[fa];
+}
+
+// ---------------------------------------------------------------- frag_dp_update, :701-764
+HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
+{
+    const int x = r.n_seed[t];
+    const int lo = hoff(r, start_slot), hi = hoff(r, x);
+    const int t_NM = r.n_NM[t];
+    int max_from = r.n_from[t], max_score = r.n_score[t], max_NM = t_NM, max_flag = r.n_dp_flag[t];
+    long long best_key = -1;          // (cand+32768) << 47 | (524287-NM) << 28 | (POSMAX-pos)
+    int neg_pos = 0x7fffffff;         // scan position of the first '-' strand match precursor
+    const int POSMAX = (1 << 28) - 1;
+    for (int base = hi - 1; base >= lo; base -= 64) {
+        wv::Lane<long long> key;
+        wv::Lane<int> negp;
+        WAVE_FOR(l) {
+            const int p = base - l;
+            key[l] = -1; negp[l] = -0x7fffffff;
+            if (p >= lo && r.n_dp_flag[p] == dp_flag) {
+                const int sp = r.h_strand[p];
+                if (!(sp == 1 && r.n_son_flag[p] <= F_MATCH_THD)) {            // '+': already has a match son, :718-720
+                    const int flag = edge_flag(r, p, t);
+                    if (flag != F_UNCONNECT && flag != F_CHR_DIF) {
+                        const int i = r.n_seed[p], j = p - hoff(r, i);
+                        const int pos = ((x - 1 - i) << 14) | j;                  // scan order: seeds descending, hits ascending
+                        const int cand = r.n_score[p] + 1 + score_table(flag);
+                        const int nm = r.n_NM[p] + t_NM;
+                        if (sp == -1 && flag <= F_MATCH_THD) negp[l] = -pos;      // '-': first match precursor wins, :726-733
+                        key[l] = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+                    }
+                }
+            }
+        }
+        const int np = -wv::reduce_max(negp);
+        const long long bk = wv::reduce_max64(key);
+        if (np < neg_pos) neg_pos = np;
+        if (bk > best_key) best_key = bk;
+        if (neg_pos != 0x7fffffff && base - 64 >= lo && r.n_seed[base - 64] < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
+    }
+    if (neg_pos != 0x7fffffff) {
+        const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = hoff(r, i) + j;
+        const int flag = edge_flag(r, p, t);
+        max_from = p; max_score = r.n_score[p] + 1 + score_table(flag); max_flag = flag; max_NM = r.n_NM[p] + t_NM;
+    } else if (best_key >= 0) {
+        const int pos = POSMAX - (int)(best_key & POSMAX);
+        const int nm = 524287 - (int)((best_key >> 28) & 524287);
+        const int cand = (int)(best_key >> 47) - 32768;
+        if (cand > max_score || (cand == max_score && nm < max_NM)) {
+            const int i = x - 1 - (pos >> 14), j = pos & 16383, p = hoff(r, i) + j;
+            max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag(r, p, t);
+        }
+    }
+    if (max_from != r.n_from[t]) {
+        r.n_son_flag[max_from] = (uint8_t)max_flag;
+        r.n_from[t] = max_from; r.n_score[t] = max_score; r.n_NM[t] = max_NM; r.n_match_flag[t] = (uint8_t)max_flag;
+        r.n_node_n[t] = r.n_node_n[max_from] + 1;
+        add_son(r, max_from, t);
+    }
+    wv::sync();
+}
+
+// ---------------------------------------------------------------- frag_min_extend for one MIN hit, :1031-1066
+// For every seed with more than min_n hits, the first hit (ascending) that is match-class
+// colinear with `m` joins the MIN pass.  Lanes scan all hits; "first within its seed" is a
+// segmented ballot.  The result is a set union, so the order over MIN hits is irrelevant.
+HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
+{
+    const int xm = r.n_seed[m];
+    int carry_seed = -1, carry_found = 0;
+    for (int base = 0; base < r.H; base += 64) {
+        wv::Lane<int> q, seg;
+        WAVE_FOR(l) {
+            const int k = base + l;
+            q[l] = 0; seg[l] = 0;
+            if (k < r.H) {
+                const int s = r.n_seed[k];
+                int st = hoff(r, s) - base; seg[l] = st > 0 ? st : 0;
+                if (s != xm && mapn(r, s) > min_n) {
+                    const int f = s < xm ? edge_flag(r, k, m) : edge_flag(r, m, k);
+                    q[l] = (f == F_MATCH || f == F_MISMATCH || f == F_LONG_MISMATCH);
+                }
+            }
+        }
+        const unsigned long long qb = wv::ballot(q);
+        WAVE_FOR(l) {
+            const int k = base + l;
+            if (k < r.H && q[l]) {
+                const int s = r.n_seed[k];
+                unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
+                if (earlier == 0 && !(s == carry_seed && carry_found)) r.n_dp_flag[k] = MIN_FLAG;
+            }
+        }
+        const int klast = base + 63 < r.H ? base + 63 : r.H - 1;
+        const int s_last = r.n_seed[klast];
+        int st = hoff(r, s_last) - base; st = st > 0 ? st : 0;
+        const int found_here = (qb >> st) != 0;
+        carry_found = found_here || (carry_seed == s_last && carry_found);
+        carry_seed = s_last;
+    }
+    wv::sync();
+}
+
+// ---------------------------------------------------------------- end-node stack / bounded heaps (lamsa_heap.c)
+struct NScore { int32_t *node, *score, *NM; int min_score_thd, max_n, node_n, cap; };
+
+HP_INL bool ns_alloc(Ctx &cx, NScore &ns, int cap, int max_n)
+{
+    ns.node = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(cap + 1));
+    ns.score = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(cap + 1));
+    ns.NM = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(cap + 1));
+    ns.cap = cap; ns.max_n = max_n; ns.node_n = 0; ns.min_score_thd = 0;
+    return ns.node && ns.score && ns.NM;
+}
+HP_INL int ns_pop(NScore &ns, int *score, int *NM)
+{   // node_pop (LIFO), lamsa_heap.c:5; returns -1 when empty
+    if (ns.node_n < 1) return -1;
+    --ns.node_n;
+    *score = ns.score[ns.node_n]; *NM = ns.NM[ns.node_n];
+    return ns.node[ns.node_n];
+}
+HP_INL void ns_swap(NScore &ns, int a, int b)
+{
+    int t = ns.node[a]; ns.node[a] = ns.node[b]; ns.node[b] = t;
+    t = ns.score[a]; ns.score[a] = ns.score[b]; ns.score[b] = t;
+    t = ns.NM[a]; ns.NM[a] = ns.NM[b]; ns.NM[b] = t;
+}
+HP_FN void ns_min_sift(NScore &ns, int i)
+{   // node_min_heap: score ascending, NM descending, lamsa_heap.c:151
+    for (;;) {
+        int l = 2 * i + 1, rr = 2 * (i + 1), m = i;
+        if (l < ns.node_n && (ns.score[l] < ns.score[i] || (ns.score[l] == ns.score[i] && ns.NM[l] > ns.NM[i]))) m = l;
+        if (rr < ns.node_n && (ns.score[rr] < ns.score[m] || (ns.score[rr] == ns.score[m] && ns.NM[rr] > ns.NM[m]))) m = rr;
+        if (m == i) return;
+        ns_swap(ns, i, m); i = m;
+    }
+}
+HP_FN void ns_minpos_sift(NScore &ns, int i)
+{   // node_minpos_heap, lamsa_heap.c:100
+    for (;;) {
+        int l = 2 * i + 1, rr = 2 * (i + 1), m = i;
+        if (l < ns.node_n && ns.node[l] < ns.node[i]) m = l;
+        if (rr < ns.node_n && ns.node[rr] < ns.node[m]) m = rr;
+        if (m == i) return;
+        ns_swap(ns, i, m); i = m;
+    }
+}
+HP_FN int ns_extract_minpos(NScore &ns)
+{   // lamsa_heap.c:126
+    if (ns.node_n < 1) return -1;
+    int m = ns.node[0];
+    --ns.node_n;
+    ns.node[0] = ns.node[ns.node_n]; ns.score[0] = ns.score[ns.node_n]; ns.NM[0] = ns.NM[ns.node_n];
+    ns_minpos_sift(ns, 0);
+    return m;
+}
+// heap_add_node, lamsa_dp_con.c:44: -1 stored, -2 rejected, else the evicted line index
+HP_FN int ns_add_bounded(NScore &ns, int node, int score, int NM)
+{
+    if (ns.node_n < ns.max_n) {
+        ns.score[ns.node_n] = score; ns.NM[ns.node_n] = NM; ns.node[ns.node_n++] = node;
+        if (ns.node_n == ns.max_n) for (int i = (ns.node_n - 1) / 2; i >= 0; --i) ns_min_sift(ns, i);
+        return -1;
+    }
+    if (ns.score[0] < score || (ns.score[0] == score && ns.NM[0] > NM)) {
+        int ret = ns.node[0];
+        ns.score[0] = score; ns.NM[0] = NM; ns.node[0] = node;
+        ns_min_sift(ns, 0);
+        return ret;
+    }
+    return -2;
+}
+HP_FN void ns_add_end(ReadCtx &r, NScore &ns, int score, int NM, int node)
+{   // node_add_score, lamsa_dp_con.c:786
+    if (score < ns.min_score_thd) return;
+    if (ns.node_n >= ns.cap) { r.cx.status |= ST_OVERFLOW; return; }
+    ns.score[ns.node_n] = score; ns.NM[ns.node_n] = NM; ns.node[ns.node_n++] = node;
+    r.n_dp_flag[node] = TRACKED_FLAG;
+    for (int t = r.n_from[node]; t >= 0; t = r.n_from[t]) r.n_dp_flag[t] = TRACKED_FLAG;
+}
+
+// ---------------------------------------------------------------- forest -> disjoint paths
+HP_FN int best_son(ReadCtx &r, int f)
+{   // get_max_son, :808
+    int max_score = 0, max_NM = 0, max_dis = 0, flag_thd = F_INIT, max = -1;
+    const int x = r.n_seed[f];
+    for (int s = r.n_first[f], c = 0; c < r.n_son_n[f] && s >= 0; s = r.n_next[s], ++c) {
+        const int mf = r.n_match_flag[s], sx = r.n_seed[s];
+        if (mf <= flag_thd && (r.n_max_score[s] > max_score || (r.n_max_score[s] == max_score && (sx - x < max_dis || r.n_max_NM[s] < max_NM)))) {
+            max = s; max_score = r.n_max_score[s]; max_NM = r.n_max_NM[s]; max_dis = sx - x;
+            if (mf <= F_MATCH_THD) flag_thd = F_MATCH_THD;
+        }
+    }
+    return max;
+}
+HP_FN void detach(ReadCtx &r, int s, int max_node, NScore &ns)
+{   // :842-847 / :851-857 / :893-899
+    r.n_from[s] = -1;
+    r.n_max_score[s] -= (r.n_score[s] - 1);
+    r.n_max_NM[s] -= (r.n_NM[s] - r.h_nm[s]);
+    r.n_node_n[max_node] -= (r.n_node_n[s] - 1);
+    ns_add_end(r, ns, r.n_max_score[s], r.n_max_NM[s], max_node);
+}
+HP_FN void cut_branch(ReadCtx &r, int f, NScore &ns)
+{   // :831-870
+    const int keep = best_son(r, f);
+    if (keep < 0) { r.cx.status |= ST_REFEXIT; r.n_in_de[f] = 0; return; }
+    for (int s = r.n_first[f], c = 0, nn = r.n_son_n[f]; c < nn && s >= 0; ++c) {
+        const int nxt = r.n_next[s];
+        if (s != keep) detach(r, s, r.n_max_node[s], ns);
+        s = nxt;
+    }
+    if (r.n_score[f] > r.n_max_score[keep]) {        // negative edge
+        r.n_in_de[keep] = -1;
+        detach(r, keep, r.n_max_node[keep], ns);
+        r.n_son_n[f] = 0; r.n_first[f] = r.n_last[f] = -1;
+        r.n_max_node[f] = f; r.n_max_score[f] = r.n_score[f]; r.n_max_NM[f] = r.n_NM[f];
+    } else {
+        r.n_son_n[f] = 1; r.n_first[f] = r.n_last[f] = keep; r.n_next[keep] = -1;
+        r.n_max_node[f] = r.n_max_node[keep]; r.n_max_score[f] = r.n_max_score[keep]; r.n_max_NM[f] = r.n_max_NM[keep];
+    }
+    r.n_in_de[f] = 0;
+}
+HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
+{   // branch_track_new, :873-920
+    int max_score, max_NM, max_node;
+    r.n_in_de[n] = -1;
+    if (r.n_son_n[n] == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = r.n_score[n]; max_NM = r.n_max_NM[n] = r.n_NM[n]; }
+    else { max_node = r.n_max_node[n]; max_score = r.n_max_score[n]; max_NM = r.n_max_NM[n]; }
+    int fa = r.n_from[n];
+    while (fa >= 0) {
+        if (r.n_son_n[fa] == 1) {
+            if (r.n_score[fa] > max_score) {         // negative edge
+                const int s = r.n_first[fa];
+                r.n_in_de[s] = -1;
+                detach(r, s, max_node, ns);
+                r.n_son_n[fa] = 0; r.n_first[fa] = r.n_last[fa] = -1;
+                max_score = r.n_score[fa]; max_NM = r.n_NM[fa]; max_node = fa;
+            }
+            r.n_max_score[fa] = max_score; r.n_max_NM[fa] = max_NM; r.n_max_node[fa] = max_node; r.n_in_de[fa] = -1;
+            fa = r.n_from[fa];
+        } else {
+            --r.n_in_de[fa];
+            if (r.n_in_de[fa] == 0) cut_branch(r, fa, ns);
+            return;
+        }
+    }
+    ns_add_end(r, ns, max_score, max_NM, max_node);
+}
+
+// ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150
+// left / right are node indices (left may be -1 = START); right_x is right's slot, which may be the
+// virtual slot seed_out (then right < 0 and _tail == 0).  Returns the number of nodes written to line[].
+HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+{
+    const int head = _head ? left : -1;
+    const int left_x = nx(r, left), head_x = nx(r, head);
+    const int left_NM = left < 0 ? 0 : r.h_nm[left];
+    int old_score, old_NM;
+    if (_tail == 0) { old_score = 1; old_NM = left_NM; }
+    else { old_score = 2 + score_table(r.n_match_flag[right]); old_NM = left_NM + r.h_nm[right]; }
+    const int dp_flag = MULTI_FLAG;
+    for (int k = hoff(r, left_x + 1), e = hoff(r, right_x); k < e; ++k)
+        if (r.n_dp_flag[k] == dp_flag || r.n_dp_flag[k] == 0 - dp_flag) node_per_init(r, k, head, dp_flag);
+    wv::sync();
+    for (int k = hoff(r, left_x + 2), e = hoff(r, right_x); k < e; ++k)      // callers guarantee left_x + 2 <= right_x
+        if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, left_x + 1, dp_flag);
+    int max_score, max_NM = 0, max_n = 0, max_node = head;
+    if (_tail == 0) {
+        max_score = old_score;
+        for (int i = right_x - 1; i > left_x; --i)
+            for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k) {
+                if (r.n_dp_flag[k] != dp_flag) continue;
+                if (r.n_score[k] > max_score || (r.n_score[k] == max_score && r.n_NM[k] < max_NM)) {
+                    max_score = r.n_score[k]; max_NM = r.n_NM[k]; max_node = k; max_n = r.n_node_n[k];
+                }
+            }
+    } else {
+        r.n_from[right] = head; r.n_score[right] = old_score; r.n_NM[right] = old_NM; r.n_node_n[right] = 1;
+        wv::sync();
+        dp_update(r, right, left_x + 1, dp_flag);
+        max_score = r.n_score[right]; max_NM = r.n_NM[right]; max_node = r.n_from[right]; max_n = r.n_node_n[right] - 1;
+    }
+    int cur = max_node, node_i = max_n - 1;
+    while (nx(r, cur) != head_x) {
+        if (node_i < 0) { r.cx.status |= ST_REFEXIT; return 0; }     // "[frag mini dp] BUG" exit, :1140
+        line[node_i--] = cur;
+        cur = r.n_from[cur];
+    }
+    if (node_i >= 0) { r.cx.status |= ST_REFEXIT; return 0; }
+    *de_score += max_score - old_score;
+    *de_NM += max_NM - old_NM;
+    return max_n;
+}
+
+// ---------------------------------------------------------------- lines
+struct LSet {
+    int32_t *pool; int pool_cap;          // node indices of all lines, back to back
+    int32_t *start, *len, *lb, *rb, *mf, *mh, *ls, *bs, *nm;   // per line (L_LB..L_NM, lamsa_aln.h:139-149)
+    int32_t *rank, *sel;                  // line_rank / line_select_rank
+    int n, cap;
+};
+HP_FN bool lset_alloc(Ctx &cx, LSet &L, int pool_cap, int line_cap)
+{
+    L.pool = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(pool_cap + 8));
+    int32_t *m = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 11 * (size_t)(line_cap + 1));
+    if (!L.pool || !m) return false;
+    const int c = line_cap + 1;
+    L.start = m; L.len = m + c; L.lb = m + 2 * c; L.rb = m + 3 * c; L.mf = m + 4 * c; L.mh = m + 5 * c;
+    L.ls = m + 6 * c; L.bs = m + 7 * c; L.nm = m + 8 * c; L.rank = m + 9 * c; L.sel = m + 10 * c;
+    L.pool_cap = pool_cap; L.cap = line_cap; L.n = 0;
+    return true;
+}
+HP_INL int firstx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.pool[L.start[l]]]; }
+HP_INL int lastx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.pool[L.start[l] + L.len[l] - 1]]; }
+
+HP_FN void sort_endpos(ReadCtx &r, LSet &L, int ls, int len, int32_t *tmp_pos)
+{   // line_sort_endpos, :12 -- end slot descending, stable (insertion sort; the goldens come from glibc's merge sort)
+    for (int i = 0; i < len; ++i) { L.rank[ls + i] = ls + i; tmp_pos[i] = lastx(r, L, ls + i); }
+    for (int i = 1; i < len; ++i) {
+        int p = tmp_pos[i], li = L.rank[ls + i], k = i - 1;
+        while (k >= 0 && tmp_pos[k] < p) { tmp_pos[k + 1] = tmp_pos[k]; L.rank[ls + k + 1] = L.rank[ls + k]; --k; }
+        tmp_pos[k + 1] = p; L.rank[ls + k + 1] = li;
+    }
+    for (int i = 0; i < len; ++i) L.sel[L.rank[ls + i]] = ls + i;
+}
+
+HP_FN int line_merge(ReadCtx &r, LSet &L, int a, int b, float ovlp_r)
+{   // :69-112
+    int s1, e1, s2, e2, s, e, hi;
+    s2 = firstx(r, L, a); e2 = lastx(r, L, a);
+    if (L.mf[b] & L_NMERG) { hi = b; s1 = firstx(r, L, b); e1 = lastx(r, L, b); }
+    else { hi = L.mh[b]; s1 = L.lb[hi]; e1 = L.rb[hi]; }
+    s = s2 > s1 ? s2 : s1; e = e2 < e1 ? e2 : e1;
+    const float rat1 = (float)((double)(e - s + 1) / (double)(e1 - s1 + 1));
+    const float rat2 = (float)((double)(e - s + 1) / (double)(e2 - s2 + 1));
+    if (rat1 < ovlp_r && rat2 < ovlp_r) { L.mf[a] = L_NMERG; return 0; }
+    if (L.ls[a] <= L.ls[b] / 2 || L.ls[a] <= L.bs[b] / 2) {
+        L.lb[hi] = s1; L.rb[hi] = e1; L.mf[hi] = L_MERGH;
+        L.mf[a] = L_MERGB | L_DUMP; L.mh[a] = hi;
+        return 1;
+    }
+    L.lb[hi] = s1 + s2 - s; L.rb[hi] = e1 + e2 - e; L.mf[hi] = L_MERGH;
+    L.mf[a] = L_MERGB; L.mh[a] = hi;
+    if (L.bs[b] > L.bs[a]) L.bs[a] = L.bs[b];
+    return 1;
+}
+
+// best + secondaries of one cluster mb[0..mbn) (line indices); winners to mf[0..*mfn) when mf != nullptr
+HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, int per_max_multi, int32_t *tri_n, int32_t *mf, int *mfn)
+{   // shared tail of line_filter (:166-235) and line_filter1 (:346-400)
+    int b_score = 0, s_score = 0;
+    for (int j = 0; j < mbn; ++j) {
+        const int y = L.ls[mb[j]];
+        if (y > b_score) { s_score = b_score; b_score = y; } else if (y > s_score) s_score = y;
+    }
+    if (mfn) *mfn = 1;
+    if (s_score >= b_score / 2) {
+        const size_t mark = arena_mark(r.cx.tmp);
+        NScore ns;
+        if (!ns_alloc(r.cx, ns, per_max_multi + 1, per_max_multi)) { arena_release(r.cx.tmp, mark); return; }
+        for (int j = 0; j < mbn; ++j) {
+            const int li = mb[j];
+            if (L.ls[li] >= b_score / 2) {
+                int ret = ns_add_bounded(ns, li, L.ls[li], L.nm[li]);
+                if (ret == -2) { L.mf[li] |= L_DUMP; if (tri_n) tri_n[li] = 0; }
+                else if (ret != -1) { L.mf[ret] |= L_DUMP; if (tri_n) tri_n[ret] = 0; }
+            } else { L.mf[li] |= L_DUMP; if (tri_n) tri_n[li] = 0; }
+        }
+        for (int i = (ns.node_n - 1) / 2; i >= 0; --i) ns_minpos_sift(ns, i);
+        const int m_head = ns_extract_minpos(ns);
+        L.mf[m_head] = L_MERGH;
+        int min_l = firstx(r, L, m_head), max_r = lastx(r, L, m_head);
+        if (mf) { if (L.ls[m_head] == b_score) mf[0] = m_head; mf[(*mfn)++] = m_head; }
+        int body;
+        while ((body = ns_extract_minpos(ns)) != -1) {
+            L.mf[body] = L_MERGB; L.mh[body] = m_head;
+            min_l = imin(min_l, firstx(r, L, body)); max_r = imax(max_r, lastx(r, L, body));
+            if (mf) { if (L.ls[body] == b_score) mf[0] = body; mf[(*mfn)++] = body; }
+        }
+        L.lb[m_head] = imin(firstx(r, L, m_head), min_l);
+        L.rb[m_head] = imax(lastx(r, L, m_head), max_r);
+        arena_release(r.cx.tmp, mark);
+    } else {
+        for (int j = 0; j < mbn; ++j) {
+            const int li = mb[j];
+            if (L.ls[li] == b_score) { L.mf[li] = L_NMERG; if (mf) { mf[0] = li; mf[(*mfn)++] = li; } }
+            else { L.mf[li] |= L_DUMP; if (tri_n) tri_n[li] = 0; }
+        }
+    }
+}
+
+struct Trig { int32_t *n1, *n2, *off, *cnt; int cap, used; };   // inter-triggers per line (trig_node, lamsa_aln.h:326)
+
+HP_FN void dump_edge_cluster(LSet &L, int ls, int len, const int32_t *mf_row, int mfn_row)
+{   // :289-297 / :306-314
+    for (int i = 1; i < mfn_row; ++i) {
+        L.mf[mf_row[i]] = L_DUMP;
+        for (int _j = ls; _j < ls + len; ++_j) {
+            const int j = L.rank[_j];
+            if (!(L.mf[j] & L_NMERG) && !(L.mf[j] & L_MERGH) && !(L.mf[j] & L_DUMP) && L.mh[j] == mf_row[i]) L.mf[j] = L_DUMP;
+        }
+    }
+}
+
+// line_filter (:122-319) when trg != nullptr, line_filter1 (:321-404) otherwise
+HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int per_max_multi)
+{
+    const size_t mark = arena_mark(r.cx.tmp);
+    // clusters are runs in rank order: cl_off[c] .. cl_off[c+1] index into mb[]; winners of cluster c at mfv[c*?]
+    int32_t *mb = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    int32_t *cl_off = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 2));
+    int32_t *cl_nm = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));      // 1: "not merged" cluster (y == -2)
+    int32_t *mfv = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(2 * len + 2));  // winners: cluster c at mfv[cl_off[c]+c ..]
+    int32_t *mfn = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    if (!mb || !cl_off || !cl_nm || !mfv || !mfn) { arena_release(r.cx.tmp, mark); return; }
+    int m_i = -1, nb = 0;
+    for (int _i = ls; _i < ls + len; ++_i) {
+        const int i = L.rank[_i];
+        if (L.mf[i] & L_DUMP) continue;
+        if (trg) {
+            if (L.mf[i] & L_NMERG) { ++m_i; cl_off[m_i] = nb; cl_nm[m_i] = 1; mb[nb++] = i; }
+            else if (L.mf[i] & L_MERGH) { ++m_i; cl_off[m_i] = nb; cl_nm[m_i] = 0; mb[nb++] = i; }
+            else { if (m_i < 0) { r.cx.status |= ST_REFEXIT; arena_release(r.cx.tmp, mark); return; } mb[nb++] = i; }
+        } else {
+            if (L.mf[i] & L_NMERG) continue;
+            if (L.mf[i] & L_MERGH) { ++m_i; cl_off[m_i] = nb; cl_nm[m_i] = 0; mb[nb++] = i; }
+            else { if (m_i < 0) { r.cx.status |= ST_REFEXIT; arena_release(r.cx.tmp, mark); return; } mb[nb++] = i; }
+        }
+    }
+    cl_off[m_i + 1] = nb;
+    for (int c = 0; c <= m_i; ++c) {
+        int32_t *mf = mfv + cl_off[c] + c;             // room for (cluster size + 1) entries
+        const int mbn = cl_off[c + 1] - cl_off[c];
+        if (!trg) { pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, nullptr, nullptr, nullptr); continue; }
+        if (cl_nm[c]) { mf[0] = mb[cl_off[c]]; mfn[c] = 1; continue; }
+        int n = 1;
+        pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, trg->cnt, mf, &n);
+        mfn[c] = n;
+        for (int ii = 1; ii < n; ++ii) {               // inter-lines (candidate inversions), :236-273
+            const int j = mf[ii], _j = L.sel[j];
+            for (int k = 0; k < trg->cnt[j]; ++k) {
+                int head = -1;
+                const int n1 = trg->n1[trg->off[j] + k], n2 = trg->n2[trg->off[j] + k];
+                for (int _l = _j + 1; _l < ls + len; ++_l) {
+                    const int l = L.rank[_l];
+                    if ((L.mf[l] & 0x3) != 0) break;
+                    if (firstx(r, L, l) > r.n_seed[n1] && lastx(r, L, l) < r.n_seed[n2]) {
+                        const int mfl = r.n_match_flag[n2];
+                        if (mfl == F_MISMATCH || mfl == F_LONG_MISMATCH) {
+                            const int s = L.pool[L.start[l]], e = L.pool[L.start[l] + L.len[l] - 1];
+                            const int st = r.h_strand[s];
+                            if (st == r.h_strand[n1] || r.h_chr[s] != r.h_chr[n1] ||
+                                st * r.h_pos[s] < st * r.h_pos[n2] || st * r.h_pos[e] > st * r.h_pos[n1]) continue;
+                            L.mf[l] = L_INTER;
+                            if (head == -1) { L.mf[l] |= L_NMERG; head = l; }
+                            else { L.mf[l] |= L_MERGB; L.mh[l] = head; L.mf[head] = L_INTER | L_MERGH; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (trg && m_i > 0) {                              // :279-316
+        int a = mfv[cl_off[0] + 0], b = mfv[cl_off[1] + 1];
+        if (lastx(r, L, a) - firstx(r, L, a) < 2 && lastx(r, L, b) - firstx(r, L, b) >= 2) dump_edge_cluster(L, ls, len, mfv + cl_off[0], mfn[0]);
+        a = mfv[cl_off[m_i] + m_i]; b = mfv[cl_off[m_i - 1] + m_i - 1];
+        if (lastx(r, L, a) - firstx(r, L, a) < 2 && lastx(r, L, b) - firstx(r, L, b) >= 2) dump_edge_cluster(L, ls, len, mfv + cl_off[m_i] + m_i, mfn[m_i]);
+    }
+    arena_release(r.cx.tmp, mark);
+}
+
+// line_set_bound (:425) / line_set_bound1 (:496) up to line_remove (:406)
+HP_NOINL int set_bound(ReadCtx &r, LSet &L, int ls, int len, Trig *trg)
+{
+    if (len <= 0) return len;
+    const size_t mark = arena_mark(r.cx.tmp);
+    int32_t *tmp = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    if (!tmp) return 0;
+    sort_endpos(r, L, ls, len, tmp);
+    arena_release(r.cx.tmp, mark);
+    L.mf[L.rank[ls]] = L_NMERG;
+    for (int i = 1; i < len; ++i) line_merge(r, L, L.rank[ls + i], L.rank[ls + i - 1], r.cx.P->ovlp_rat);
+    line_filter(r, L, ls, len, trg, r.cx.P->ske_max);
+    int cur = ls;
+    for (int _l = ls; _l < ls + len; ++_l) { const int l = L.rank[_l]; if (!(L.mf[l] & L_DUMP)) L.rank[cur++] = l; }
+    return cur - ls;
+}
+
+// ---------------------------------------------------------------- lines -> fragments (frag_dp_path, :1152)
+struct FLines {
+    int n, nfrag;
+    int32_t *line_score, *left_bound, *right_bound, *frag_off;   // per line (frag_off has n+1 entries)
+    int32_t *fr_seed_off;                                         // per fragment (+1)
+    int32_t *fr_seed;                                             // node indices, fragment seeds in the reference's order
+};
+
+HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
+{
+    F.n = 0; F.nfrag = 0;
+    if (line_n == 0) return true;
+    int tot = 0;
+    for (int _l = 0; _l < line_n; ++_l) tot += L.len[L.rank[_l]];
+    int32_t *m = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(4 * (line_n + 1) + (tot + 2) + tot + 4));
+    if (!m) return false;
+    F.line_score = m; F.left_bound = m + (line_n + 1); F.right_bound = m + 2 * (line_n + 1); F.frag_off = m + 3 * (line_n + 1);
+    F.fr_seed_off = m + 4 * (line_n + 1); F.fr_seed = F.fr_seed_off + (tot + 2);
+    const lamsa_hp_para *P = r.cx.P;
+    if (P->aln_mode & 1) {                              // line_filter_overlap, :568-594
+        for (int _i = 0; _i < line_n; ++_i) {
+            const int li = L.rank[_i];
+            int32_t *ni = L.pool + L.start[li]; const int ll = L.len[li];
+            int last_i = 0;
+            for (int j = 1; j < ll - 1; ++j) {
+                const int c = ni[j], p = ni[last_i];
+                const int st = r.h_strand[c];
+                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.n_match_flag[c] != F_INSERT) ni[j] = -1;
+                else last_i = j;
+            }
+            if (ll - 1 != last_i) {
+                const int c = ni[ll - 1], p = ni[last_i];
+                const int st = r.h_strand[c];
+                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.n_match_flag[c] != F_INSERT) ni[last_i] = -1;
+            }
+        }
+    }
+    int nf = 0, ns = 0;
+    for (int _l = 0; _l < line_n; ++_l) {
+        const int li = L.rank[_l];
+        const int32_t *ln = L.pool + L.start[li]; const int ll = L.len[li];
+        F.frag_off[_l] = nf;
+        int pre = ln[ll - 1], cur;
+        F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre;              // FRAG_END: a new fragment opens with its last seed
+        F.right_bound[_l] = r.seed_all + 1;
+        for (int i = ll - 1; i > 0; --i) {
+            cur = pre;
+            if (ln[i - 1] < 0) continue;
+            pre = ln[i - 1];
+            const int mf = r.n_match_flag[cur];
+            if (mf == F_INSERT || mf == F_DELETE || mf == F_MISMATCH || mf == F_LONG_MISMATCH) { ++nf; F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre; }
+            else if (mf == F_MATCH) F.fr_seed[ns++] = pre;
+            else { r.cx.status |= ST_REFEXIT; return false; }          // "[frag dp path] Error: Unknown flag", :1223
+        }
+        ++nf;
+        F.left_bound[_l] = 0;
+        F.line_score[_l] = L.ls[li];
+    }
+    F.frag_off[line_n] = nf; F.fr_seed_off[nf] = ns;
+    F.n = line_n; F.nfrag = nf;
+    return true;
+}
+
+// ---------------------------------------------------------------- round 1: frag_line_BCC, :1305-1445
+HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    const int seed_out = r.seed_out, H = r.H;
+    F.n = 0; F.nfrag = 0;
+    int min_n = P->first_loci_thd, min_exist = 0, min_num = 0;
+    for (int i = 0; i < seed_out; ++i) if (mapn(r, i) <= min_n) { min_exist = 1; ++min_num; }    // :1315-1323
+    const bool all_min = (!min_exist || min_num * 3 < seed_out);                                 // :1324-1331
+    for (int base = 0; base < H; base += 64) {
+        WAVE_FOR(l) {
+            const int k = base + l;
+            if (k < H) node_set(r, k, -1, 1, r.h_nm[k], F_MATCH, (all_min || mapn(r, r.n_seed[k]) <= min_n) ? MIN_FLAG : MULTI_FLAG);
+        }
+    }
+    wv::sync();
+    if (all_min) min_n = P->per_aln_m;
+    if (min_n != P->per_aln_m) {                                                                  // :1335-1343
+        for (int i = 0; i < seed_out; ++i) {
+            if (mapn(r, i) > min_n) continue;
+            for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k) min_extend(r, k, min_n);
+        }
+    }
+    for (int k = seed_out > 1 ? hoff(r, 1) : H; k < H; ++k)                                       // main pass, :1345-1350
+        if (r.n_dp_flag[k] == MIN_FLAG) dp_update(r, k, 0, MIN_FLAG);
+
+    NScore ns;
+    if (!ns_alloc(r.cx, ns, H + 1, 0)) return false;
+    ns.min_score_thd = 2;
+    for (int i = seed_out - 1; i >= 0; --i)                                                       // :1356-1361
+        for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
+            if (r.n_dp_flag[k] == MIN_FLAG && r.n_in_de[k] == 0) branch_track(r, k, ns);
+
+    const int o_l = ns.node_n;
+    LSet L;
+    Trig T;
+    if (!lset_alloc(r.cx, L, 2 * H + o_l + 16, o_l)) return false;
+    T.cap = 2 * H + 2 * o_l + 16; T.used = 0;
+    T.n1 = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)T.cap);
+    T.n2 = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)T.cap);
+    T.off = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(o_l + 1));
+    T.cnt = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(o_l + 1));
+    int32_t *_line = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 2));
+    if (!T.n1 || !T.n2 || !T.off || !T.cnt || !_line) return false;
+    int l_i = 0, next_start = 0, line_score = 0, line_NM = 0;
+#define HP_TRIG_PUSH(a, b) do { if (T.used < T.cap) { T.n1[T.used] = (a); T.n2[T.used] = (b); ++T.used; ++T.cnt[l_i]; } else r.cx.status |= ST_OVERFLOW; } while (0)
+    for (;;) {                                                                                    // :1370-1432
+        int max_node = ns_pop(ns, &line_score, &line_NM);
+        if (max_node < 0) break;
+        // pool never overflows: every node joins at most one line (TRACKED), plus one slack slot per line
+        int32_t *ln = L.pool + next_start;
+        int node_i = 0, mini_len, last_n, right, left;
+        T.off[l_i] = T.used; T.cnt[l_i] = 0;
+        if (r.n_seed[max_node] < seed_out - 1) {                      // beyond the chain end
+            mini_len = mini_line(r, max_node, -1, seed_out, _line, &line_score, &line_NM, 1, 0);
+            for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.n_dp_flag[_line[k]] = TRACKED_FLAG; }
+            ln[node_i] = max_node;
+            last_n = ln[0];
+            for (int k = mini_len - 1; k >= 0; --k) {
+                if (nx(r, last_n) - nx(r, ln[node_i - k]) > 2) HP_TRIG_PUSH(ln[node_i - k], last_n);
+                last_n = ln[node_i - k];
+            }
+        }
+        right = max_node;
+        while (right >= 0) {                                          // gaps between anchors
+            ln[node_i++] = right;
+            left = r.n_from[right];
+            if (nx(r, left) < r.n_seed[right] - 1) {
+                mini_len = mini_line(r, left, right, r.n_seed[right], _line, &line_score, &line_NM, 1, 1);
+                for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.n_dp_flag[_line[k]] = TRACKED_FLAG; }
+                ln[node_i] = left;
+                last_n = right;
+                for (int k = mini_len; k >= 0; --k) {
+                    if (nx(r, last_n) - nx(r, ln[node_i - k]) > 2) {
+                        if (ln[node_i - k] < 0) continue;
+                        HP_TRIG_PUSH(ln[node_i - k], last_n);
+                    }
+                    last_n = ln[node_i - k];
+                }
+            }
+            right = left;
+        }
+        for (int k = 0; k < node_i / 2; ++k) { int t = ln[k]; ln[k] = ln[node_i - k - 1]; ln[node_i - k - 1] = t; }
+        L.start[l_i] = next_start; L.len[l_i] = node_i; L.ls[l_i] = L.bs[l_i] = line_score; L.nm[l_i] = line_NM;
+        L.mf[l_i] = 0; L.mh[l_i] = 0; L.lb[l_i] = L.rb[l_i] = 0;
+        ++l_i; next_start += node_i + 1;
+        if (r.cx.status & ST_REFEXIT) return false;
+    }
+#undef HP_TRIG_PUSH
+    L.n = l_i;
+    const int line_n = set_bound(r, L, 0, l_i, &T);                   // :1435
+    return build_flines(r, L, line_n, F);
+}
+
+// ---------------------------------------------------------------- uncovered regions of the read (aln_reg / get_remain_reg)
+struct RegB { int32_t is_rev, chr; int64_t pos; };
+struct Regs {                     // sorted covered intervals + the remain regions derived from them
+    int n;                        // covered intervals (one per result record), in stable beg order
+    int32_t *beg, *end; RegB *rb, *re;           // ref_beg / ref_end of each interval
+    int m;                        // remain regions
+    int32_t *r_beg, *r_end, *r_bs, *r_bn, *r_es, *r_en;   // read interval + (start,count) into re[] / rb[] lists
+};
+
+// ---------------------------------------------------------------- round 2: frag_mini_dp_multi_line, :923-1017
+HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int reg_i, LSet &L)
+{
+    if (left_b + 1 >= right_b) return 0;
+    const lamsa_hp_para *P = r.cx.P;
+    const int start = left_b + 1, end = right_b - 1, dp_flag = WHOLE_FLAG;
+    for (int k = hoff(r, start), e = hoff(r, end + 1); k < e; ++k)
+        if (r.n_dp_flag[k] != TRACKED_FLAG) node_per_init(r, k, -1, dp_flag);
+    wv::sync();
+    for (int k = start + 1 <= end ? hoff(r, start + 1) : hoff(r, end + 1), e = hoff(r, end + 1); k < e; ++k)
+        if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, start, dp_flag);
+    const size_t mark = arena_mark(r.cx.tmp);
+    NScore ns;
+    if (!ns_alloc(r.cx, ns, hoff(r, end + 1) - hoff(r, start) + 1, 0)) return 0;
+    ns.min_score_thd = 0;
+    for (int i = end; i >= start; --i)
+        for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
+            if (r.n_dp_flag[k] == dp_flag && r.n_in_de[k] == 0) branch_track(r, k, ns);
+    int l_i = 0, next_start = 0, score = 0, NM = 0;
+    for (;;) {
+        int rr = ns_pop(ns, &score, &NM);
+        if (rr < 0) break;
+        int node_i = r.n_node_n[rr] - 1;
+        if (l_i >= L.cap || next_start + node_i + 1 > L.pool_cap) { r.cx.status |= ST_OVERFLOW; break; }
+        L.start[l_i] = next_start; L.len[l_i] = node_i + 1; L.mf[l_i] = 0; L.mh[l_i] = 0; L.lb[l_i] = L.rb[l_i] = 0;
+        next_start += node_i + 1;
+        int hit = 0;                                                    // proximity bonus, :979-996
+        const int64_t expect = (int64_t)((r.n_seed[rr] - left_b) * P->seed_step);
+        for (int i = 0; i < G.r_bn[reg_i] && !hit; ++i) {
+            const RegB &b = G.re[G.r_bs[reg_i] + i];
+            int64_t d = (r.h_pos[rr] - b.pos) - expect; if (d < 0) d = -d;
+            if (r.h_chr[rr] == b.chr && d < P->SV_len_thd) hit = 1;
+        }
+        for (int i = 0; i < G.r_en[reg_i] && !hit; ++i) {
+            const RegB &b = G.rb[G.r_es[reg_i] + i];
+            int64_t d = (r.h_pos[rr] - b.pos) - expect; if (d < 0) d = -d;
+            if (r.h_chr[rr] == b.chr && d < P->SV_len_thd) hit = 1;
+        }
+        if (hit) { if (score > 1) score += score / 2; else score++; }
+        L.ls[l_i] = L.bs[l_i] = score; L.nm[l_i] = NM;
+        int32_t *node = L.pool + L.start[l_i];
+        while (rr >= 0) {
+            if (node_i < 0) { r.cx.status |= ST_REFEXIT; arena_release(r.cx.tmp, mark); return 0; }
+            node[node_i--] = rr;
+            rr = r.n_from[rr];
+        }
+        if (node_i >= 0) { r.cx.status |= ST_REFEXIT; arena_release(r.cx.tmp, mark); return 0; }
+        ++l_i;
+    }
+    arena_release(r.cx.tmp, mark);
+    return l_i;
+}
+
+// frag_line_remain, :1252-1302
+HP_NOINL bool chain_remain(ReadCtx &r, const Regs &G, FLines &F)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    const int seed_out = r.seed_out, H = r.H;
+    F.n = 0; F.nfrag = 0;
+    LSet L, T;
+    if (!lset_alloc(r.cx, L, H + 16, H + 1) || !lset_alloc(r.cx, T, H + 16, H + 1)) return false;
+    int l_n = 0, next_start = 0;
+    for (int i = 0; i < G.m; ++i) {
+        const int left_id = (G.r_beg[i] + P->seed_inv - 1) / P->seed_step + 1;
+        int right_id = (G.r_end[i] - 1) / P->seed_step + 1;
+        if (right_id > r.seed_all) right_id -= 1;
+        int left = -2, right = -2;
+        for (int j = 0; j < seed_out; ++j) if (r.seed_id[j] >= left_id) { left = j - 1; break; }
+        if (left == -2) continue;
+        for (int j = seed_out - 1; j >= 0; --j) if (r.seed_id[j] <= right_id) { right = j + 1; break; }
+        if (right == -2) continue;
+        int l = multi_line(r, left, right, G, i, T);                   // trg_dp_line, :1019
+        if (r.cx.status & ST_REFEXIT) return false;
+        T.n = l;
+        l = set_bound(r, T, 0, l, nullptr);
+        for (int _j = 0; _j < l; ++_j) {                               // :1288-1295
+            const int j = T.rank[_j], d = l_n + _j;
+            if (d >= L.cap || next_start + T.len[j] > L.pool_cap) { r.cx.status |= ST_OVERFLOW; return false; }
+            L.start[d] = next_start; L.len[d] = T.len[j]; L.lb[d] = T.lb[j]; L.rb[d] = T.rb[j]; L.mf[d] = T.mf[j]; L.mh[d] = T.mh[j];
+            L.ls[d] = T.ls[j]; L.bs[d] = T.bs[j]; L.nm[d] = T.nm[j];
+            for (int k = 0; k < T.len[j]; ++k) L.pool[next_start + k] = T.pool[T.start[j] + k];
+            next_start += T.len[j];
+            L.rank[d] = d;
+        }
+        l_n += l;
+    }
+    L.n = l_n;
+    return build_flines(r, L, l_n, F);
+}
+
+}  // namespace hp

@@ -1,0 +1,486 @@
+// hp_fill.h -- lines of fragments -> base-level alignment records on one wavefront
+// (reference src/frag_check.c, src/bntseq.c:465).
+//
+//   ref_fetch      <- pac2fa_core      bntseq.c:465  2-bit window unpacked by the 64 lanes
+//   merge_cigar    <- merge_cigar      frag_check.c:251
+//   frag_extend    <- frag_extend      :332
+//   split_mapping  <- split_mapping    :416
+//   head_fix/tail_fix <- frag_head_bound_fix / frag_tail_bound_fix  :576,:656
+//   res_split      <- lamsa_res_split  :712
+//   res_aux        <- lamsa_res_aux    :793  mismatch counting spread over the lanes
+//   fill_lines     <- frag_check       :856
+// Control flow is wave-uniform; sequences are never copied or reversed, DP routines read
+// them through strided views.  Where the reference exit(1)s the read is flagged
+// ST_REFEXIT and abandoned.
+#pragma once
+#include "hp_split.h"
+
+namespace hp {
+
+#define HP_REC_MAX 64            // records per line (split alignments); more flags ST_OVERFLOW
+
+struct Rec {                     // res_t, frag_check.h:46-59
+    int64_t offset, refend; int32_t chr, nstrand, readend, score, NM; CigV cig;
+};
+struct LineRes {                 // line_aln_res, frag_check.h:61-73
+    int line_score, tol_score, tol_NM, cur_res_n;
+    Rec rec[HP_REC_MAX];
+};
+
+// ---------------------------------------------------------------- pac2fa_core, bntseq.c:465-477
+HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t *dst)
+{
+    const int32_t clen = r.ref.seq_len[chr - 1];
+    if (start0 > clen || start0 < 0) { r.cx.status |= ST_REFEXIT; return false; }      // exit(1), :469-472
+    if (start0 + *len > clen) *len = (int32_t)(clen - start0);                          // :474
+    const int64_t k0 = r.ref.seq_off[chr - 1] + start0;
+    const int32_t n = *len;
+    const uint8_t *pac = r.ref.pac;
+    for (int32_t b = 0; b < n; b += 64) {
+        WAVE_FOR(l) {
+            const int32_t i = b + l;
+            if (i < n) { const int64_t k = k0 + i; dst[i] = pac[k >> 2] >> ((~k & 3) << 1) & 3; }   // _get_pac, :242
+        }
+    }
+    wv::sync();
+    return true;
+}
+
+// ---------------------------------------------------------------- merge_cigar, frag_check.c:251-328
+HP_NOINL bool merge_cigar(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_readend, int chr,
+                          const cig_t *_c2, int c2_n, int c2_reflen, int c2_readlen)
+{
+    if (c2_n == 0) return true;
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    bool repair = false;
+    if (c1.n > 1) {
+        const cig_t t = c1.c[c1.n - 1], h = _c2[0];
+        const int top = t & 0xf, hop = h & 0xf;
+        if ((((top == C_I || top == C_D) && (t >> 4) <= 3) && hop != C_S && hop != C_H) ||
+            (((hop == C_I || hop == C_D) && (h >> 4) <= 3) && top != C_S && top != C_H)) repair = true;
+    }
+    if (!repair) cig_pushv(cx, c1, _c2, c2_n);
+    else {
+        const size_t mark = arena_mark(cx.tmp);
+        int len1, len11 = 0, len2, len21 = 0, len22 = 0, len_dif1 = 0, len_dif2 = 0;
+        int b = 0, min_b, ci = 0, left = 1, right = 1;
+        const int md = 5;
+        int64_t ref_start = 0; int read_start = 0;
+        cig_t *c2 = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(c2_n + 1));
+        CigV bd; bd.c = nullptr; bd.n = 0; bd.cap = 0;
+        if (!c2) { arena_release(cx.tmp, mark); return false; }
+        for (int i = 0; i < c2_n; ++i) c2[i] = _c2[i];
+        bool ok = true;
+        for (;;) {
+            if (left) {
+                while (c1.n >= 1) {
+                    const cig_t w = c1.c[c1.n - 1]; const int op = w & 0xf, l = w >> 4;
+                    if (op == C_M && l > md) { c1.c[c1.n - 1] -= md << 4; len21 += md; break; }
+                    else if (op == C_M) { len21 += l; --c1.n; }
+                    else if (op == C_I) { len21 += l; len_dif1 -= l; b += l; --c1.n; }
+                    else if (op == C_D) { len_dif1 += l; b += l; --c1.n; }
+                    else { left = -1; break; }
+                }
+                len11 = len21 + len_dif1;
+                read_start = *c1_readend - len21 + 1;
+                ref_start = *c1_refend - len11 + 1;
+            }
+            if (right) {
+                while (ci < c2_n) {
+                    const int op = c2[ci] & 0xf, l = c2[ci] >> 4;
+                    if (op == C_M && l > md) { c2[ci] -= md << 4; len22 += md; break; }
+                    else if (op == C_M) { len22 += l; ci++; }
+                    else if (op == C_I) { len22 += l; len_dif2 -= l; b += l; ++ci; }
+                    else if (op == C_D) { len_dif2 += l; b += l; ++ci; }
+                    else { right = -1; break; }
+                }
+            }
+            len2 = len21 + len22; len1 = len2 + len_dif1 + len_dif2;
+            min_b = iabs(len_dif1 + len_dif2) + md; b = b > min_b ? b : min_b;
+            const size_t m2 = arena_mark(cx.tmp);
+            uint8_t *seq1 = (uint8_t *)arena_alloc(cx, (size_t)(len1 > 0 ? len1 : 0) + 16);
+            int32_t l1 = len1;
+            if (!seq1 || len2 < 0 || read_start < 1 || read_start - 1 + len2 > r.L || !ref_fetch(r, chr, ref_start - 1, &l1, seq1)) { cx.status |= seq1 ? ST_REFEXIT : ST_OVERFLOW; ok = false; break; }
+            len1 = l1;
+            if (!cig_alloc(cx, bd, len1 + len2 + 8)) { ok = false; break; }
+            ksw_global(cx, len2, seq_fwd(r.cur_read + read_start - 1), len1, seq_fwd(seq1), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, b, &bd);
+            if (bd.n == 0) { cx.status |= ST_REFEXIT; ok = false; break; }    // the reference dereferences an empty CIGAR here
+            bool stop = false;
+            if ((bd.c[0] & 0xf) == C_M) left = 0;
+            else if (c1.n == 0 || left < 0) stop = true;
+            if (!stop) {
+                if ((bd.c[bd.n - 1] & 0xf) == C_M) right = 0;
+                else if (ci == c2_n || right < 0) stop = true;
+            }
+            if (stop || left + right == 0) break;
+            arena_release(cx.tmp, m2);           // drop this round's window + CIGAR, try a longer flank
+        }
+        if (ok) { cig_pushv(cx, c1, bd.c, bd.n); cig_pushv(cx, c1, c2 + ci, c2_n - ci); }
+        arena_release(cx.tmp, mark);
+        if (!ok) return false;
+    }
+    *c1_refend += c2_reflen;
+    *c1_readend += c2_readlen;
+    return true;
+}
+
+// read interval between two chained seeds (get_read_intv, :116): pointer into the strand-appropriate read
+HP_INL int read_gap(const ReadCtx &r, int s1, int s2, const uint8_t **p)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    int i, e;
+    if (r.h_strand[s1] == 1) { i = sid(r, r.n_seed[s1]) * P->seed_step - P->seed_inv; e = (sid(r, r.n_seed[s2]) - 1) * P->seed_step; }
+    else { i = r.last_len + sid(r, r.n_seed[s1]) * P->seed_step - P->seed_inv; e = r.last_len + (sid(r, r.n_seed[s2]) - 1) * P->seed_step; }
+    *p = r.cur_read + i;
+    return e > i ? e - i : 0;
+}
+
+// ---------------------------------------------------------------- frag_extend, :332-410
+HP_NOINL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int32_t *seed = F.fr_seed + F.fr_seed_off[frag];
+    const int seed_n = F.fr_seed_off[frag + 1] - F.fr_seed_off[frag];
+    const int strand = r.h_strand[seed[0]], chr = r.h_chr[seed[0]];
+    const size_t mark = arena_mark(cx.tmp);
+    CigV fc;
+    int cap = 0;                                          // seed CIGARs + gap CIGARs (gap = seed_step - seed_len bases + indels)
+    for (int i = 0; i < seed_n; ++i) cap += r.h_cig_n[seed[i]] + 2 * iabs(P->seed_step) + 64;
+    if (!cig_alloc(cx, fc, cap + 16)) return false;
+    int i, rs, re, last;
+    if (strand == 1) { i = seed_n - 1; last = seed[i]; rs = (sid(r, r.n_seed[last]) - 1) * P->seed_step + 1; }
+    else { i = 0; last = seed[0]; rs = r.last_len + (sid(r, r.n_seed[last]) - 1) * P->seed_step + 1; }
+    re = rs - 1 + P->seed_len;
+    cig_pushv(cx, fc, r.cig + r.h_cig_off[last], r.h_cig_n[last]);
+    const int64_t ref_start = r.h_pos[last];
+    int64_t ref_end = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
+    const int step = strand == 1 ? -1 : 1;
+    bool ok = true;
+    for (i += step; i >= 0 && i < seed_n && ok; i += step) {
+        const int s = seed[i];
+        const size_t m2 = arena_mark(cx.tmp);
+        // get_ref_intv, :98
+        const int64_t start = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
+        int32_t len2 = (int32_t)(r.h_pos[s] - 1 - start);
+        uint8_t *tb = nullptr;
+        if (len2 <= 0) len2 = 0;
+        else {
+            tb = (uint8_t *)arena_alloc(cx, (size_t)len2 + 16);
+            if (!tb || !ref_fetch(r, r.h_chr[last], start, &len2, tb)) { ok = false; break; }
+        }
+        const uint8_t *qp; const int len1 = read_gap(r, last, s, &qp);
+        CigV g;
+        if (!cig_alloc(cx, g, len1 + len2 + 8)) { ok = false; break; }
+        ksw_global(cx, len1, seq_fwd(qp), len2, seq_fwd(tb ? tb : qp), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &g);
+        ok = merge_cigar(r, fc, &ref_end, &re, chr, g.c, g.n, len2, len1) &&
+             merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len);
+        last = s;
+        arena_release(cx.tmp, m2);
+    }
+    if (ok) ok = merge_cigar(r, res.cig, &res.refend, &res.readend, chr, fc.c, fc.n, (int)(ref_end - ref_start + 1), re - rs + 1);
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+// ---------------------------------------------------------------- split_mapping, :416-564
+HP_NOINL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int32_t *sd1 = F.fr_seed + F.fr_seed_off[f1], *sd2 = F.fr_seed + F.fr_seed_off[f2];
+    const int n1 = F.fr_seed_off[f1 + 1] - F.fr_seed_off[f1], n2 = F.fr_seed_off[f2 + 1] - F.fr_seed_off[f2];
+    int s1, s2;
+    if (r.h_strand[sd1[0]] == 1) { s1 = sd1[0]; s2 = sd2[n2 - 1]; }
+    else { s1 = sd1[n1 - 1]; s2 = sd2[0]; }
+    const int64_t at1_off = r.h_pos[s1], at2_off = r.h_pos[s2];
+    const int at1_ld = r.h_len_dif[s1], at1_chr = r.h_chr[s1], at2_chr = r.h_chr[s2];
+    const int hash_len = P->hash_len, did = sid(r, r.n_seed[s2]) - sid(r, r.n_seed[s1]);
+    const int s_qlen = did * P->seed_step - P->seed_len;
+    if (s_qlen < 0) { cx.status |= ST_REFEXIT; return false; }
+    const uint8_t *qp; read_gap(r, s1, s2, &qp);
+    const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
+    const int dis = (int)(at2_off - exp);
+    const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
+    const int gh0 = hash_len * P->match;
+    const size_t mark = arena_mark(cx.tmp);
+    int s_tlen = 0;
+    int32_t tl;
+    CigV sc;
+    bool ok = true;
+    if (dis > match_dis) {                                        // DEL, :475-489
+        s_tlen = s_qlen + dis; tl = s_tlen;
+        uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)(s_tlen > 0 ? s_tlen : 0) + 16);
+        ok = tb && cig_alloc(cx, sc, s_qlen + s_tlen + 64) && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld - 1, &tl, tb);
+        if (ok) {
+            s_tlen = tl;
+            if (s_qlen < hash_len) ksw_bi_extend(cx, s_qlen, seq_fwd(qp), s_tlen, seq_fwd(tb), gh0, gh0, sc);
+            else split_indel_map(cx, sc, qp, s_qlen, tb, s_tlen, 0);
+        }
+    } else if (dis < -match_dis) {                                // INS, :490-546
+        s_tlen = s_qlen + dis;
+        if (s_tlen < 2 * P->hash_step) {                          // overlapped insertion: extend from both sides
+            int32_t _s_tlen = s_qlen + hash_len;
+            int lqe, lte, rqe, rte;
+            uint8_t *tb1 = (uint8_t *)arena_alloc(cx, (size_t)_s_tlen + 16), *tb2 = (uint8_t *)arena_alloc(cx, (size_t)_s_tlen + 16);
+            CigV lc, rcg;
+            ok = tb1 && tb2 && cig_alloc(cx, sc, 2 * (s_qlen + _s_tlen) + 64) && cig_alloc(cx, lc, s_qlen + _s_tlen + 8) && cig_alloc(cx, rcg, s_qlen + _s_tlen + 8);
+            ok = ok && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld - 1, &_s_tlen, tb1);
+            if (ok) {
+                ksw_extend(cx, s_qlen, seq_fwd(qp), _s_tlen, seq_fwd(tb1), P->band_w, gh0, &lqe, &lte, &lc);
+                ok = ref_fetch(r, at2_chr, at2_off - _s_tlen - 1, &_s_tlen, tb2);
+            }
+            if (ok) {
+                const Seq rq = seq_rev(qp, s_qlen), rt = seq_rev(tb2, _s_tlen);
+                ksw_extend(cx, s_qlen, rq, _s_tlen, rt, P->band_w, gh0, &rqe, &rte, &rcg);
+                cig_invert(rcg.c, rcg.n);
+                // the reference hands the still-reversed buffers to sw_mid_fix (:527)
+                sw_mid_fix(cx, sc, lc.c, lc.n, rcg.c, rcg.n, s_qlen, rq, lqe, rqe, s_qlen + dis, rt, lte, rte);
+            }
+        } else {                                                  // DUP, :529-545
+            s_tlen += 2 * (hash_len - dis); tl = s_tlen;
+            uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)s_tlen + 16);
+            ok = tb && cig_alloc(cx, sc, s_qlen + s_tlen + 64) && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld + dis - hash_len - 1, &tl, tb);
+            if (ok) {
+                s_tlen = tl;
+                const int off_dis = (s_tlen != s_qlen - dis + 2 * hash_len) ? 0 : -dis;
+                s_tlen = s_qlen + dis;
+                if (s_tlen < hash_len) ksw_bi_extend(cx, s_qlen, seq_fwd(qp), s_tlen, seq_fwd(tb + hash_len - dis), gh0, gh0, sc);
+                else split_indel_map(cx, sc, qp, s_qlen, tb + hash_len - dis, s_tlen, off_dis);
+            }
+        }
+    } else {                                                      // mismatch class, :547-559
+        s_tlen = s_qlen + dis; tl = s_tlen;
+        if (s_tlen < 0) { cx.status |= ST_REFEXIT; ok = false; }  // ksw_extend_core exit(-1), ksw.c:672
+        else {
+            uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)s_tlen + 16);
+            ok = tb && cig_alloc(cx, sc, s_qlen + s_tlen + 64) && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld - 1, &tl, tb);
+            if (ok) { s_tlen = tl; ksw_bi_extend(cx, s_qlen, seq_fwd(qp), s_tlen, seq_fwd(tb), 100, 100, sc); }
+        }
+    }
+    if (ok) ok = merge_cigar(r, res.cig, &res.refend, &res.readend, at1_chr, sc.c, sc.n, s_tlen, s_qlen);
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+// ---------------------------------------------------------------- frag_head_bound_fix, :576-654
+HP_NOINL bool head_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int left_bound = F.left_bound[line];
+    const int f0 = F.frag_off[line], fl = F.frag_off[line + 1] - 1;
+    int s, read_len, read_start;
+    if (r.h_strand[F.fr_seed[F.fr_seed_off[f0]]] == 1) {
+        s = F.fr_seed[F.fr_seed_off[fl + 1] - 1];                       // last seed of the last fragment
+        if (sid(r, r.n_seed[s]) != 1) {
+            read_len = (left_bound == 0 ? 0 : P->seed_inv) + (sid(r, r.n_seed[s]) - left_bound - 1) * P->seed_step;
+            if (read_len < 0) { cx.status |= ST_REFEXIT; return false; }
+            read_start = left_bound == 0 ? 0 : left_bound * P->seed_step - P->seed_inv;
+        } else { res.offset = r.h_pos[s]; res.refend = res.offset - 1; res.cig.n = 0; return true; }
+    } else {
+        s = F.fr_seed[F.fr_seed_off[f0]];
+        read_len = (left_bound == 0 ? r.last_len : P->seed_inv) + (sid(r, r.n_seed[s]) - 1 - left_bound) * P->seed_step;
+        if (read_len == 0) { res.offset = r.h_pos[s]; res.refend = res.offset - 1; res.cig.n = 0; return true; }
+        if (read_len < 0) { cx.status |= ST_REFEXIT; return false; }
+        read_start = left_bound == 0 ? 0 : r.last_len + left_bound * P->seed_step - P->seed_inv;
+    }
+    res.offset = r.h_pos[s];
+    int32_t ref_len = read_len + P->hash_step * 2;
+    int64_t ref_start = r.h_pos[s] - ref_len;
+    if (ref_start < 1) { ref_start = 1; ref_len = (int32_t)(r.h_pos[s] - 1); }
+    const size_t mark = arena_mark(cx.tmp);
+    uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)(ref_len > 0 ? ref_len : 0) + 16);
+    CigV c;
+    bool ok = tb && cig_alloc(cx, c, read_len + ref_len + 16) && ref_fetch(r, r.h_chr[s], ref_start - 1, &ref_len, tb);
+    if (ok) {
+        int qre, tre;
+        const int rr = ksw_extend_r(cx, read_len, seq_fwd(r.cur_read + read_start), ref_len, seq_fwd(tb), P->band_w, P->seed_len * P->match, &qre, &tre, &c);
+        if (rr != 0) cig_push1(cx, c, ((read_len - qre) << 4) | C_S);
+        cig_invert(c.c, c.n);
+        res.offset -= cig_reflen(c.c, c.n);
+        res.refend = res.offset - 1;
+        cig_pushv(cx, res.cig, c.c, c.n);                              // _push_cigar_e, frag_check.h:193
+        res.refend += cig_reflen(c.c, c.n);
+        res.readend += cig_readlen(c.c, c.n);
+    }
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+// ---------------------------------------------------------------- frag_tail_bound_fix, :656-707
+HP_NOINL bool tail_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int right_bound = F.right_bound[line];
+    const int f0 = F.frag_off[line], fl = F.frag_off[line + 1] - 1;
+    int s, read_len, read_start;
+    if (r.h_strand[F.fr_seed[F.fr_seed_off[f0]]] == 1) {
+        s = F.fr_seed[F.fr_seed_off[f0]];
+        read_start = sid(r, r.n_seed[s]) * P->seed_step - P->seed_inv;
+        read_len = (right_bound == r.seed_all + 1 ? r.last_len : P->seed_inv) + (right_bound - 1 - sid(r, r.n_seed[s])) * P->seed_step;
+        if (read_len == 0) return true;
+        if (read_len < 0) { cx.status |= ST_REFEXIT; return false; }
+    } else {
+        s = F.fr_seed[F.fr_seed_off[fl + 1] - 1];
+        if (sid(r, r.n_seed[s]) == r.seed_all) return true;
+        read_start = sid(r, r.n_seed[s]) * P->seed_step - P->seed_inv + r.last_len;
+        read_len = (right_bound == r.seed_all + 1 ? 0 : P->seed_inv) + (right_bound - 1 - sid(r, r.n_seed[s])) * P->seed_step;
+        if (read_len < 0) { cx.status |= ST_REFEXIT; return false; }
+    }
+    int32_t ref_len = read_len + P->hash_step * 2;
+    const int64_t ref_start = r.h_pos[s] + P->seed_len + r.h_len_dif[s];
+    const size_t mark = arena_mark(cx.tmp);
+    uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)ref_len + 16);
+    CigV c;
+    bool ok = tb && cig_alloc(cx, c, read_len + ref_len + 16) && ref_fetch(r, r.h_chr[s], ref_start - 1, &ref_len, tb);
+    if (ok) {
+        int qle, tle;
+        const int rr = ksw_extend_c(cx, read_len, seq_fwd(r.cur_read + read_start), ref_len, seq_fwd(tb), P->band_w, P->seed_len * P->match, &qle, &tle, &c);
+        if (rr != 0) cig_push1(cx, c, ((read_len - qle) << 4) | C_S);
+        ok = merge_cigar(r, res.cig, &res.refend, &res.readend, r.h_chr[s], c.c, c.n, cig_reflen(c.c, c.n), cig_readlen(c.c, c.n));
+    }
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+// ---------------------------------------------------------------- lamsa_res_split, :712-776
+// The whole-line CIGAR in rec[0] is cut into records whose CIGARs live back to back in `buf`.
+HP_NOINL bool res_split(ReadCtx &r, LineRes &la, cig_t *buf, int buf_cap)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int read_len = r.L;
+    const int n = la.rec[0].cig.n;
+    const size_t mark = arena_mark(cx.tmp);
+    cig_t *cg = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(n + 1));
+    if (!cg) return false;
+    for (int j = 0; j < n; ++j) cg[j] = la.rec[0].cig.c[j];
+    int res_n = 0, used = 0;
+    cig_bind(la.rec[0].cig, buf, buf_cap);
+#define CUR (la.rec[res_n].cig)
+#define NEW_REC(extra_ref) do { \
+        used += CUR.n; CUR.cap = CUR.n; \
+        if (res_n + 1 >= HP_REC_MAX) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return false; } \
+        ++res_n; ++la.cur_res_n; \
+        la.rec[res_n].chr = la.rec[res_n - 1].chr; la.rec[res_n].nstrand = la.rec[res_n - 1].nstrand;        /* push_res, :228 */ \
+        la.rec[res_n].offset = la.rec[res_n - 1].offset + cig_reflen(la.rec[res_n - 1].cig.c, la.rec[res_n - 1].cig.n) + (extra_ref); \
+        cig_bind(la.rec[res_n].cig, buf + used, buf_cap - used); } while (0)
+    for (int j = 0; j < n; ++j) {
+        const int op = cg[j] & 0xf, len = cg[j] >> 4;
+        int len1;
+        if (op == C_M) cig_push1(cx, CUR, cg[j]);
+        else if (op == C_I && len >= P->split_len) {
+            len1 = cig_readlen(CUR.c, CUR.n);
+            cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
+            NEW_REC(0);
+            cig_push1(cx, CUR, ((len + len1) << 4) | C_S);
+        } else if (op == C_D && len >= P->split_len) {
+            len1 = cig_readlen(CUR.c, CUR.n);
+            cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
+            NEW_REC(len);
+            cig_push1(cx, CUR, (len1 << 4) | C_S);
+        } else if (op == C_I || op == C_D) cig_push1(cx, CUR, cg[j]);
+        else if (op == C_S) {
+            if (j > 0 && j < n - 1 && (cg[j + 1] & 0xf) == C_H) {
+                const int Sn = cg[j] >> 4, Hn = cg[j + 1] >> 4;
+                len1 = cig_readlen(CUR.c, CUR.n);
+                cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
+                NEW_REC(Hn);
+                cig_push1(cx, CUR, ((len1 + Sn) << 4) | C_S);
+                j += 1;
+            } else cig_push1(cx, CUR, cg[j]);
+        } else if (op != C_H) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); return false; }
+    }
+#undef CUR
+#undef NEW_REC
+    arena_release(cx.tmp, mark);
+    return !(cx.status & ST_OVERFLOW);
+}
+
+// ---------------------------------------------------------------- lamsa_res_aux, :793-853
+HP_NOINL bool res_aux(ReadCtx &r, LineRes &la)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    for (int m = 0; m <= la.cur_res_n; ++m) {
+        Rec &rec = la.rec[m];
+        const size_t mark = arena_mark(cx.tmp);
+        int32_t ref_len = cig_reflen(rec.cig.c, rec.cig.n);
+        uint8_t *ref = (uint8_t *)arena_alloc(cx, (size_t)(ref_len > 0 ? ref_len : 0) + 16);
+        if (!ref || !ref_fetch(r, rec.chr, rec.offset - 1, &ref_len, ref)) { arena_release(cx.tmp, mark); return false; }
+        int ref_i = 0, read_i = 0, n_mm = 0, n_m = 0, n_io = 0, n_ie = 0, n_do = 0, n_de = 0;
+        bool bad = false;
+        for (int i = 0; i < rec.cig.n && !bad; ++i) {
+            const int op = rec.cig.c[i] & 0xf, len = rec.cig.c[i] >> 4;
+            if (op == C_M) {
+                if (read_i + len > r.L || ref_i + len > ref_len) { bad = true; break; }     // lengths cannot match any more: exit(1) at :834
+                int mm = 0;
+                for (int b = 0; b < len; b += 64) {
+                    wv::Lane<int> d;
+                    WAVE_FOR(l) { const int j = b + l; d[l] = (j < len && r.cur_read[read_i + j] != ref[ref_i + j]) ? 1 : 0; }
+                    mm += wv::reduce_sum(d);
+                }
+                read_i += len; ref_i += len; n_m += len - mm; n_mm += mm;
+            } else if (op == C_I) { read_i += len; n_ie += len; ++n_io; }
+            else if (op == C_D) { ref_i += len; n_de += len; ++n_do; }
+            else if (op == C_S) read_i += len;
+            else bad = true;
+        }
+        arena_release(cx.tmp, mark);
+        if (bad || read_i != r.L || ref_i != ref_len) { cx.status |= ST_REFEXIT; return false; }
+        rec.NM = n_mm + n_ie + n_de;
+        rec.score = n_m * P->match - n_mm * P->mis - n_io * P->ins_gapo - n_ie * P->ins_gape - n_do * P->del_gapo - n_de * P->del_gape;
+        if (rec.score < 0) {                                          // record deleted, :839-844 (CIGARs are views: no copy needed)
+            for (int i = m + 1; i <= la.cur_res_n; ++i) la.rec[i - 1] = la.rec[i];
+            --m; --la.cur_res_n;
+        } else { la.tol_score += rec.score; la.tol_NM += rec.NM; }
+    }
+    if (la.cur_res_n < 0) la.tol_score = -1;
+    else la.tol_score -= la.cur_res_n * P->split_pen;
+    return true;
+}
+
+// ---------------------------------------------------------------- one line of frag_check, :886-955
+HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur_buf, int cur_cap, cig_t *rec_buf, int rec_cap)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int f0 = F.frag_off[line], nfr = F.frag_off[line + 1] - f0;
+    const int first_seed = F.fr_seed[F.fr_seed_off[f0]];
+    const int strand = r.h_strand[first_seed];
+    la.line_score = F.line_score[line]; la.cur_res_n = 0; la.tol_score = la.tol_NM = 0;
+    Rec &r0 = la.rec[0];
+    cig_bind(r0.cig, cur_buf, cur_cap);
+    r0.nstrand = strand == 1 ? 1 : 0; r0.chr = r.h_chr[first_seed]; r0.readend = 0; r0.refend = 0; r0.offset = 0;
+    bool ok = true;
+    if (strand == 1) {
+        r.cur_read = r.read; r.flip = false;
+        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        ok = head_fix(r, F, line, r0);
+        for (int i = nfr - 1; i > 0 && ok; --i) ok = frag_extend(r, F, f0 + i, r0) && split_mapping(r, F, f0 + i, f0 + i - 1, r0);
+        ok = ok && frag_extend(r, F, f0, r0) && tail_fix(r, F, line, r0);
+        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = ((r.L - (F.right_bound[line] - 1) * P->seed_step) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+    } else {
+        if (!r.rc_ready) {                                            // :922-925 (buffer reserved when the read was set up)
+            for (int b = 0; b < r.L; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < r.L) { const int c = r.read[r.L - 1 - i]; r.rc_read[i] = c < 4 ? 3 - c : 4; } } }
+            wv::sync();
+            r.rc_ready = true;
+        }
+        r.cur_read = r.rc_read; r.flip = true;                        // :926
+        const int tmp = F.left_bound[line];
+        F.left_bound[line] = r.seed_all + 1 - F.right_bound[line]; F.right_bound[line] = r.seed_all + 1 - tmp;
+        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv + r.last_len) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        ok = head_fix(r, F, line, r0);
+        for (int i = 0; i < nfr - 1 && ok; ++i) ok = frag_extend(r, F, f0 + i, r0) && split_mapping(r, F, f0 + i, f0 + i + 1, r0);
+        ok = ok && frag_extend(r, F, f0 + nfr - 1, r0) && tail_fix(r, F, line, r0);
+        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = (((r.seed_all - F.right_bound[line] + 1) * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+    }
+    ok = ok && res_split(r, la, rec_buf, rec_cap) && res_aux(r, la);
+    r.flip = false;                                                   // :953
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+}  // namespace hp

@@ -41,8 +41,22 @@ class HpDpOut(C.Structure):
                 ("status", C.POINTER(C.c_int32)), ("cig_off", C.POINTER(C.c_int64)), ("cigar", C.POINTER(C.c_int32))]
 
 
+class HpBatch(C.Structure):
+    """struct lamsa_hp_batch"""
+    _fields_ = [("n_reads", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
+        "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig")] + [("n_cig", C.c_int64)]
+
+
+class HpResult(C.Structure):
+    """struct lamsa_hp_result"""
+    _fields_ = [("stream", C.POINTER(C.c_int32)), ("stream_words", C.c_int64), ("read_off", C.POINTER(C.c_int64)),
+                ("read_len", C.POINTER(C.c_int32)), ("read_status", C.POINTER(C.c_int32))]
+
+
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
-           "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms")
+           "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms",
+           "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded")
 
 _lib = None
 
@@ -63,6 +77,12 @@ def load_library(path=LIB_PATH):
         L.lamsa_hp_last_error.restype = C.c_char_p
         L.lamsa_hp_dp_batch.argtypes = [C.c_void_p, C.POINTER(HpDpJobs), C.POINTER(HpDpOut)]
         L.lamsa_hp_dp_batch.restype = C.c_int
+        L.lamsa_hp_align_batch.argtypes = [C.c_void_p, C.POINTER(HpBatch), C.POINTER(HpResult)]
+        L.lamsa_hp_align_batch.restype = C.c_int
+        L.lamsa_hp_upload_batch.argtypes = [C.c_void_p, C.POINTER(HpBatch)]
+        L.lamsa_hp_upload_batch.restype = C.c_int
+        L.lamsa_hp_run_uploaded.argtypes = [C.c_void_p, C.POINTER(HpResult)]
+        L.lamsa_hp_run_uploaded.restype = C.c_int
         L.lamsa_hp_last_kernel_ms.argtypes = [C.c_void_p, C.c_int]
         L.lamsa_hp_last_kernel_ms.restype = C.c_float
         _lib = L
@@ -151,3 +171,44 @@ class LamsaHp:
         cg = np.ctypeslib.as_array(O.cigar, (max(tot, 1),)).copy()
         cigars = [cg[off[i]:off[i + 1]].tolist() for i in range(n)]
         return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)
+
+    # ---- the hot path proper
+    def _batch_struct(self, batch):
+        b = HpBatch()
+        b.n_reads = batch.n_reads
+        self._keep_batch = []
+        for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
+                     "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+            a = np.ascontiguousarray(getattr(batch, name)); self._keep_batch.append(a); setattr(b, name, a.ctypes.data)
+        b.n_cig = len(batch.cig)
+        return b
+
+    def _result(self, R, n):
+        off = np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n].copy()
+        ln = np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n].copy()
+        st = np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n].copy()
+        stream = np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)).copy()
+        return [stream[int(off[i]):int(off[i]) + int(ln[i])].tolist() for i in range(n)], st
+
+    def align_batch(self, batch):
+        """batch: object with the numpy arrays of lamsa_hp_batch. Returns (per-read result streams, status array)."""
+        b = self._batch_struct(batch)
+        R = HpResult()
+        rc = self.L.lamsa_hp_align_batch(self._h, C.byref(b), C.byref(R))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_align_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        return self._result(R, batch.n_reads)
+
+    def upload_batch(self, batch):
+        b = self._batch_struct(batch)
+        rc = self.L.lamsa_hp_upload_batch(self._h, C.byref(b))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_upload_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        self._n_up = batch.n_reads
+
+    def run_uploaded(self, fetch=True):
+        R = HpResult()
+        rc = self.L.lamsa_hp_run_uploaded(self._h, C.byref(R) if fetch else None)
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_run_uploaded: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        return self._result(R, self._n_up) if fetch else None

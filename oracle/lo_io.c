@@ -363,3 +363,150 @@ int lo_run_aln(const char *ref_prefix, const char *reads, lo_para *P, FILE *out,
     if (n_bases_out) *n_bases_out = n_bases;
     return 0;
 }
+
+/* ================================================================ SoA batches (parity-test plumbing) */
+int lo_batch_load(const lo_index *ix, const char *reads, const lo_para *P, long max_reads, lo_batch *B)
+{
+    memset(B, 0, sizeof(*B));
+    char fn[2048];
+    snprintf(fn, sizeof fn, "%s.seed.gem.map", reads);
+    FILE *mapf = fopen(fn, "r");
+    if (!mapf) { fprintf(stderr, "[lo_io] cannot open %s\n", fn); return -1; }
+    rdr_t rr; memset(&rr, 0, sizeof rr);
+    rr.f = gzopen(reads, "r");
+    if (!rr.f) { fclose(mapf); return -1; }
+    rec_t rd; memset(&rd, 0, sizeof rd);
+    char *line = (char*)malloc(LINE_SIZE);
+    const uint8_t *t4 = nt4();
+    size_t m_reads = 0, m_bases = 0, m_slots = 0;
+    lo_hit *hits = NULL; int hit_n = 0; lo_cig *cig = NULL; int cig_n = 0, cig_m = 0;
+    int64_t n_bases = 0, n_slots = 0;
+    B->read_off = (int64_t*)calloc(1, sizeof(int64_t)); B->seed_off = (int64_t*)calloc(1, sizeof(int64_t)); B->hit_off = (int64_t*)calloc(1, sizeof(int64_t));
+    while ((max_reads <= 0 || B->n_reads < max_reads) && read_record(&rr, &rd)) {
+        const int L = rd.l, r = B->n_reads;
+        if ((size_t)r + 2 > m_reads) {
+            m_reads = m_reads ? m_reads * 2 : 256;
+            B->read_off = (int64_t*)realloc(B->read_off, sizeof(int64_t) * (m_reads + 1)); B->seed_off = (int64_t*)realloc(B->seed_off, sizeof(int64_t) * (m_reads + 1));
+            B->seed_all = (int32_t*)realloc(B->seed_all, sizeof(int32_t) * m_reads); B->last_len = (int32_t*)realloc(B->last_len, sizeof(int32_t) * m_reads);
+        }
+        if ((size_t)(n_bases + L) + 16 > m_bases) { m_bases = (size_t)(n_bases + L) * 2 + 1024; B->read_seq = (uint8_t*)realloc(B->read_seq, m_bases); }
+        for (int i = 0; i < L; ++i) B->read_seq[n_bases + i] = t4[(unsigned char)rd.seq[i]];
+        n_bases += L; B->read_off[r + 1] = n_bases;
+        const int seed_all = L < P->seed_len ? 0 : 1 + (L - P->seed_len) / P->seed_step;
+        B->seed_all[r] = seed_all; B->last_len[r] = L - P->seed_len - (seed_all - 1) * P->seed_step;
+        for (int sd = 0; sd < seed_all; ++sd) {
+            if (!fgets(line, LINE_SIZE, mapf)) { fprintf(stderr, "[lo_io] GEM map result does not match the reads\n"); return -1; }
+            size_t ll = strlen(line); if (ll && line[ll - 1] == '\n') line[ll - 1] = 0;
+            int ct = 0; size_t k;
+            for (k = 0; line[k]; ++k) if (line[k] == '\t') { if (ct == 3) break; ct++; }
+            if (line[k + 1] == '-') continue;
+            if ((size_t)n_slots + 2 > m_slots) { m_slots = m_slots ? m_slots * 2 : 1024; B->seed_id = (int32_t*)realloc(B->seed_id, sizeof(int32_t) * m_slots); B->hit_off = (int64_t*)realloc(B->hit_off, sizeof(int64_t) * (m_slots + 1)); }
+            B->seed_id[n_slots] = sd + 1;
+            lo_parse_hits(line + k + 1, ix, P->per_aln_m, &hits, &hit_n, &cig, &cig_n, &cig_m);
+            ++n_slots; B->hit_off[n_slots] = hit_n;
+        }
+        B->seed_off[r + 1] = n_slots;
+        B->n_reads++;
+    }
+    B->n_slots = n_slots; B->n_hits = hit_n; B->n_cig = cig_n;
+    B->h_pos = (int64_t*)malloc(sizeof(int64_t) * (size_t)(hit_n + 1)); B->h_chr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(hit_n + 1));
+    B->h_strand = (int8_t*)malloc((size_t)hit_n + 1); B->h_nm = (int16_t*)malloc(2 * (size_t)(hit_n + 1)); B->h_len_dif = (int16_t*)malloc(2 * (size_t)(hit_n + 1));
+    B->h_cig_off = (int32_t*)malloc(sizeof(int32_t) * (size_t)(hit_n + 1)); B->h_cig_n = (uint8_t*)malloc((size_t)hit_n + 1);
+    for (int k = 0; k < hit_n; ++k) {
+        B->h_pos[k] = hits[k].offset; B->h_chr[k] = hits[k].chr; B->h_strand[k] = (int8_t)hits[k].strand; B->h_nm[k] = (int16_t)hits[k].NM;
+        B->h_len_dif[k] = (int16_t)hits[k].len_dif; B->h_cig_off[k] = hits[k].cig_off; B->h_cig_n[k] = (uint8_t)hits[k].cig_n;
+    }
+    B->cig = cig ? cig : (lo_cig*)calloc(4, sizeof(lo_cig));
+    if (!B->read_seq) B->read_seq = (uint8_t*)calloc(16, 1);
+    if (!B->seed_id) B->seed_id = (int32_t*)calloc(4, sizeof(int32_t));
+    if (!B->seed_all) { B->seed_all = (int32_t*)calloc(4, sizeof(int32_t)); B->last_len = (int32_t*)calloc(4, sizeof(int32_t)); }
+    free(hits); free(line); free(rd.name); free(rd.seq); free(rd.qual); free(rr.buf); gzclose(rr.f); fclose(mapf);
+    return 0;
+}
+
+void lo_batch_free(lo_batch *B)
+{
+    free(B->read_off); free(B->read_seq); free(B->seed_all); free(B->last_len); free(B->seed_off); free(B->seed_id); free(B->hit_off);
+    free(B->h_pos); free(B->h_chr); free(B->h_strand); free(B->h_nm); free(B->h_len_dif); free(B->h_cig_off); free(B->h_cig_n); free(B->cig);
+    memset(B, 0, sizeof(*B));
+}
+
+typedef struct { int32_t *w; int n, m; } wbuf;
+static void wput(wbuf *b, int32_t v) { if (b->n == b->m) { b->m = b->m ? b->m * 2 : 256; b->w = (int32_t*)realloc(b->w, sizeof(int32_t) * (size_t)b->m); } b->w[b->n++] = v; }
+
+typedef struct { const lo_batch *B; const lo_ref *R; const lo_para *P; wbuf *out; int32_t *status; volatile int next; pthread_mutex_t mu; } bwork_t;
+
+static void batch_one(bwork_t *w, int r)
+{
+    const lo_batch *B = w->B;
+    lo_seeds S; memset(&S, 0, sizeof S);
+    const int64_t s0 = B->seed_off[r], s1 = B->seed_off[r + 1], hb = B->hit_off[s0];
+    S.seed_all = B->seed_all[r]; S.last_len = B->last_len[r]; S.seed_out = (int)(s1 - s0); S.read_len = (int)(B->read_off[r + 1] - B->read_off[r]);
+    S.seed_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(S.seed_out + 1)); S.hit_off = (int32_t*)malloc(sizeof(int32_t) * (size_t)(S.seed_out + 2));
+    for (int i = 0; i < S.seed_out; ++i) S.seed_id[i] = B->seed_id[s0 + i];
+    for (int i = 0; i <= S.seed_out; ++i) S.hit_off[i] = (int32_t)(B->hit_off[s0 + i] - hb);
+    const int H = S.hit_off[S.seed_out];
+    S.hit = (lo_hit*)calloc((size_t)H + 1, sizeof(lo_hit));
+    for (int k = 0; k < H; ++k) {
+        lo_hit *h = &S.hit[k];
+        h->offset = B->h_pos[hb + k]; h->chr = B->h_chr[hb + k]; h->strand = B->h_strand[hb + k]; h->NM = B->h_nm[hb + k]; h->len_dif = B->h_len_dif[hb + k];
+        h->cig_off = B->h_cig_off[hb + k]; h->cig_n = B->h_cig_n[hb + k];
+    }
+    S.cig = B->cig;
+    lo_ares res3[3];
+    for (int i = 0; i < 3; ++i) lo_ares_init(&res3[i], w->P->res_mul_max);
+    lo_areg *a_reg = lo_areg_new(S.read_len);
+    int rc = lo_align_read(&S, B->read_seq + B->read_off[r], w->R, w->P, res3, a_reg);
+    wbuf *o = &w->out[r];
+    w->status[r] = rc < 0 ? 2 : 0;
+    wput(o, w->status[r]);
+    if (rc < 0) { wput(o, 0); wput(o, 0); }
+    else {
+        wput(o, res3[0].l_n); wput(o, res3[1].l_n);
+        for (int st = 0; st < 2; ++st)
+            for (int i = 0; i < res3[st].l_n; ++i) {
+                lo_lres *la = &res3[st].la[i];
+                wput(o, la->line_score); wput(o, la->tol_score); wput(o, la->tol_NM); wput(o, la->cur_res_n + 1);
+                for (int j = 0; j <= la->cur_res_n; ++j) {
+                    lo_res *x = &la->res[j];
+                    wput(o, (int32_t)(x->offset & 0xffffffffll)); wput(o, (int32_t)(x->offset >> 32)); wput(o, x->chr); wput(o, x->nstrand); wput(o, x->score); wput(o, x->NM); wput(o, x->cig.n);
+                    for (int k = 0; k < x->cig.n; ++k) wput(o, x->cig.c[k]);
+                }
+            }
+    }
+    lo_areg_free(a_reg);
+    for (int i = 0; i < 3; ++i) lo_ares_free(&res3[i]);
+    free(S.seed_id); free(S.hit_off); free(S.hit);
+}
+static void *batch_worker(void *arg)
+{
+    bwork_t *w = (bwork_t*)arg;
+    for (;;) {
+        pthread_mutex_lock(&w->mu); int i = w->next++; pthread_mutex_unlock(&w->mu);
+        if (i >= w->B->n_reads) break;
+        batch_one(w, i);
+    }
+    return NULL;
+}
+
+int lo_batch_align_stream(const lo_batch *B, const lo_ref *R, const lo_para *P, int n_threads,
+                          int32_t **stream, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status)
+{
+    const int n = B->n_reads;
+    wbuf *out = (wbuf*)calloc((size_t)n + 1, sizeof(wbuf));
+    bwork_t w; w.B = B; w.R = R; w.P = P; w.out = out; w.status = status; w.next = 0; pthread_mutex_init(&w.mu, NULL);
+    if (n_threads <= 1) batch_worker(&w);
+    else {
+        pthread_t *th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+        for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, batch_worker, &w);
+        for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+        free(th);
+    }
+    int64_t tot = 0;
+    for (int r = 0; r < n; ++r) { read_off[r] = tot; read_len[r] = out[r].n; tot += out[r].n; }
+    *stream = (int32_t*)malloc(sizeof(int32_t) * (size_t)(tot + 4));
+    for (int r = 0; r < n; ++r) { memcpy(*stream + read_off[r], out[r].w, sizeof(int32_t) * (size_t)out[r].n); free(out[r].w); }
+    free(out);
+    *n_words = tot;
+    return 0;
+}

@@ -25,3 +25,24 @@ int lo_run_aln(const char *ref_prefix, const char *reads, lo_para *P, FILE *out,
 }
 #endif
 #endif
+
+/* ---- struct-of-arrays batches (the layout of include/lamsa_hp.h's lamsa_hp_batch), for the parity tests ---- */
+typedef struct {
+    int32_t n_reads; int64_t n_slots, n_hits, n_cig;
+    int64_t *read_off; uint8_t *read_seq; int32_t *seed_all, *last_len;
+    int64_t *seed_off; int32_t *seed_id; int64_t *hit_off;
+    int64_t *h_pos; int32_t *h_chr; int8_t *h_strand; int16_t *h_nm, *h_len_dif; int32_t *h_cig_off; uint8_t *h_cig_n; int32_t *cig;
+} lo_batch;
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* parse <reads> + <reads>.seed.gem.map against the index `ix` into a batch (max_reads <= 0: all) */
+int  lo_batch_load(const lo_index *ix, const char *reads, const lo_para *P, long max_reads, lo_batch *B);
+void lo_batch_free(lo_batch *B);
+/* run the oracle's per-read path over a batch and serialise every read in the result-stream format of
+ * include/lamsa_hp.h.  *stream is malloc'ed; read_off/read_len/status have n_reads entries. */
+int  lo_batch_align_stream(const lo_batch *B, const lo_ref *R, const lo_para *P, int n_threads,
+                           int32_t **stream, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status);
+#ifdef __cplusplus
+}
+#endif

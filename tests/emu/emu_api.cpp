@@ -23,3 +23,25 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
     for (int j = 0; j < n; ++j) dp_run_job(a, j, 0);
     return 0;
 }
+
+// ---------------------------------------------------------------- whole per-read path, emulated
+#include "hp_align.h"
+
+extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
+                               int32_t *stream, int64_t stream_cap, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status)
+{
+    AlignArgs a;
+    a.P = *P;
+    a.ref.pac = ref->pac; a.ref.l_pac = ref->l_pac; a.ref.n_seqs = ref->n_seqs; a.ref.seq_off = ref->seq_offset; a.ref.seq_len = ref->seq_len;
+    a.in.n_reads = B->n_reads; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
+    a.in.seed_off = B->seed_off; a.in.seed_id = B->seed_id; a.in.hit_off = B->hit_off; a.in.h_pos = B->h_pos; a.in.h_chr = B->h_chr;
+    a.in.h_cig_off = B->h_cig_off; a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig;
+    unsigned long long cursor = 0;
+    a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
+    a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status;
+    std::vector<char> slab(slab_bytes);
+    a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale;
+    for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0);
+    *n_words = (int64_t)cursor;
+    return 0;
+}

@@ -46,3 +46,8 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
 }
 
 }  // namespace wv
+
+// single-threaded stand-ins for the two device atomics the kernels use
+static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+

@@ -62,3 +62,18 @@ def stage_scenario(name, tmpdir):
 
 def strip_pg(text):
     return "".join(l + "\n" for l in text.split("\n") if l and not l.startswith("@PG"))
+
+
+def para_from_args(args):
+    """(read_type, overrides) for the fixture's command-line options."""
+    rt, over, i = "default", {}, 0
+    while i < len(args):
+        if args[i] == "-T":
+            rt = args[i + 1]; i += 2
+        elif args[i] == "-w":
+            over["band_w"] = int(args[i + 1]); i += 2
+        elif args[i] == "-V":
+            over["SV_len_thd"] = int(args[i + 1]); i += 2
+        else:
+            i += 1
+    return rt, over

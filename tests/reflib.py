@@ -207,3 +207,137 @@ def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
                    p(score), p(qle), p(tle), p(st), p(cn), p(cap), p(cig), slab_bytes)
     cigars = [cig[cap[i]:cap[i] + cn[i]].tolist() for i in range(n)]
     return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)
+
+
+# ---------------------------------------------------------------- whole-path batches (SoA) + result streams
+class LoRef(C.Structure):
+    _fields_ = [("pac", C.c_void_p), ("l_pac", C.c_int64), ("n_seqs", C.c_int), ("seq_offset", C.c_void_p), ("seq_len", C.c_void_p)]
+
+
+class LoIndex(C.Structure):
+    _fields_ = [("ref", LoRef), ("name", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p), ("pac", C.c_void_p)]
+
+
+class LoBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_slots", C.c_int64), ("n_hits", C.c_int64), ("n_cig", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off",
+                                           "h_pos", "h_chr", "h_strand", "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig")]
+
+
+def _np(ptr, n, dt):
+    n = int(n)
+    if n <= 0 or not ptr:
+        return np.zeros(max(n, 0), dt)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), (n,)).copy()
+
+
+class Batch:
+    """A batch of reads + seed hits as numpy arrays in the layout of lamsa_hp_batch, plus the packed reference."""
+
+    def __init__(self, ref_prefix, reads, P, max_reads=0):
+        L = oracle()
+        ix = LoIndex()
+        if L.lo_index_load(C.byref(ix), ref_prefix.encode()) != 0:
+            raise RuntimeError("cannot load index " + ref_prefix)
+        b = LoBatch()
+        L.lo_batch_load.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long, C.c_void_p]
+        if L.lo_batch_load(C.byref(ix), reads.encode(), C.byref(P), max_reads, C.byref(b)) != 0:
+            raise RuntimeError("cannot load batch " + reads)
+        n, ns, nh = b.n_reads, b.n_slots, b.n_hits
+        self.n_reads = n
+        self.read_off = _np(b.read_off, n + 1, np.int64); self.read_seq = _np(b.read_seq, self.read_off[n] if n else 0, np.uint8)
+        self.seed_all = _np(b.seed_all, n, np.int32); self.last_len = _np(b.last_len, n, np.int32)
+        self.seed_off = _np(b.seed_off, n + 1, np.int64); self.seed_id = _np(b.seed_id, ns, np.int32); self.hit_off = _np(b.hit_off, ns + 1, np.int64)
+        self.h_pos = _np(b.h_pos, nh, np.int64); self.h_chr = _np(b.h_chr, nh, np.int32); self.h_strand = _np(b.h_strand, nh, np.int8)
+        self.h_nm = _np(b.h_nm, nh, np.int16); self.h_len_dif = _np(b.h_len_dif, nh, np.int16)
+        self.h_cig_off = _np(b.h_cig_off, nh, np.int32); self.h_cig_n = _np(b.h_cig_n, nh, np.uint8); self.cig = _np(b.cig, b.n_cig, np.int32)
+        ns_ = ix.ref.n_seqs
+        self.l_pac = ix.ref.l_pac
+        self.pac = _np(ix.ref.pac, ix.ref.l_pac // 4 + 1, np.uint8)
+        self.seq_off = _np(ix.ref.seq_offset, ns_, np.int64); self.seq_len = _np(ix.ref.seq_len, ns_, np.int32)
+        L.lo_batch_free(C.byref(b)); L.lo_index_free(C.byref(ix))
+        for name in ("read_seq", "seed_id", "h_pos", "h_chr", "h_strand", "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+            a = getattr(self, name)
+            if len(a) == 0:
+                setattr(self, name, np.zeros(4, a.dtype))      # keep pointers valid
+
+    def take(self, idx):
+        """A new Batch holding the reads idx (list of indices), renumbered."""
+        o = object.__new__(Batch)
+        for k in ("pac", "l_pac", "seq_off", "seq_len", "cig"):
+            setattr(o, k, getattr(self, k))
+        ro, so, ho = [0], [0], [0]
+        seqs, sid, sall, last = [], [], [], []
+        hsel = []
+        for r in idx:
+            seqs.append(self.read_seq[self.read_off[r]:self.read_off[r + 1]]); ro.append(ro[-1] + len(seqs[-1]))
+            sall.append(self.seed_all[r]); last.append(self.last_len[r])
+            for s in range(self.seed_off[r], self.seed_off[r + 1]):
+                sid.append(self.seed_id[s]); a, b = self.hit_off[s], self.hit_off[s + 1]
+                hsel.extend(range(a, b)); ho.append(ho[-1] + (b - a))
+            so.append(len(sid))
+        hsel = np.array(hsel, np.int64)
+        o.n_reads = len(idx)
+        o.read_off = np.array(ro, np.int64); o.read_seq = np.concatenate(seqs + [np.zeros(4, np.uint8)]).astype(np.uint8)
+        o.seed_all = np.array(sall, np.int32); o.last_len = np.array(last, np.int32); o.seed_off = np.array(so, np.int64)
+        o.seed_id = np.array(sid + [0], np.int32); o.hit_off = np.array(ho, np.int64)
+        for k, dt in (("h_pos", np.int64), ("h_chr", np.int32), ("h_strand", np.int8), ("h_nm", np.int16), ("h_len_dif", np.int16), ("h_cig_off", np.int32), ("h_cig_n", np.uint8)):
+            setattr(o, k, np.concatenate([getattr(self, k)[hsel] if len(hsel) else np.zeros(0, dt), np.zeros(4, dt)]).astype(dt))
+        return o
+
+    def c_lo_batch(self):
+        b = LoBatch()
+        b.n_reads = self.n_reads; b.n_slots = int(self.seed_off[-1]); b.n_hits = int(self.hit_off[-1]); b.n_cig = len(self.cig)
+        for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
+                     "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+            a = np.ascontiguousarray(getattr(self, name)); setattr(self, name, a); setattr(b, name, a.ctypes.data)
+        return b
+
+    def c_lo_ref(self):
+        r = LoRef()
+        r.pac = self.pac.ctypes.data; r.l_pac = int(self.l_pac); r.n_seqs = len(self.seq_len)
+        r.seq_offset = self.seq_off.ctypes.data; r.seq_len = self.seq_len.ctypes.data
+        return r
+
+
+def split_streams(stream, off, ln):
+    return [stream[int(off[i]):int(off[i]) + int(ln[i])].tolist() for i in range(len(off))]
+
+
+def oracle_streams(batch, P, n_threads=4):
+    """Per-read result streams (lists of ints) from the oracle."""
+    L = oracle()
+    n = batch.n_reads
+    b, r = batch.c_lo_batch(), batch.c_lo_ref()
+    sp = C.POINTER(C.c_int32)(); nw = C.c_int64(0)
+    off = np.zeros(max(n, 1), np.int64); ln = np.zeros(max(n, 1), np.int32); st = np.zeros(max(n, 1), np.int32)
+    L.lo_batch_align_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.lo_batch_align_stream(C.byref(b), C.byref(r), C.byref(P), n_threads, C.byref(sp), C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
+    stream = np.ctypeslib.as_array(sp, (max(nw.value, 1),)).copy()
+    C.CDLL(None).free(sp)
+    return split_streams(stream, off[:n], ln[:n])
+
+
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20):
+    """Per-read result streams from the device sources compiled with the CPU lane emulation."""
+    from lamsa_amd.hp import HpRef, HpBatch
+    E = emu()
+    n = batch.n_reads
+    hb = batch.c_hp_batch(HpBatch) if hasattr(batch, "c_hp_batch") else hp_batch_struct(batch, HpBatch)
+    hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
+    cap = 4096 + 64 * n + 16 * int(batch.read_off[-1]) * scale
+    stream = np.zeros(cap, np.int32); nw = C.c_int64(0)
+    off = np.zeros(max(n, 1), np.int64); ln = np.zeros(max(n, 1), np.int32); st = np.zeros(max(n, 1), np.int32)
+    E.emu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    E.emu_align_batch(C.byref(hp_para), C.byref(hr), C.byref(hb), scale, slab_bytes, stream.ctypes.data, cap, C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
+    return split_streams(stream, off[:n], ln[:n]), st[:n].copy()
+
+
+def hp_batch_struct(batch, HpBatch):
+    b = HpBatch()
+    b.n_reads = batch.n_reads
+    for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
+                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+        a = np.ascontiguousarray(getattr(batch, name)); setattr(batch, name, a); setattr(b, name, a.ctypes.data)
+    b.n_cig = len(batch.cig)
+    return b
