@@ -182,7 +182,7 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
     const int n = S->n_reads;
     h->kernel_ms[0] = h->kernel_ms[1] = 0;
-    S->r_st.assign((size_t)n, 0); S->r_off.assign((size_t)n, 0); S->r_len.assign((size_t)n, 0);
+    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
     if (n == 0) {
         S->stream.assign(4, 0);
         if (R) { R->stream = S->stream.data(); R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); }

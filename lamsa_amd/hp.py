@@ -184,6 +184,8 @@ class LamsaHp:
         return b
 
     def _result(self, R, n):
+        if n == 0:
+            return [], np.zeros(0, np.int32)
         off = np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n].copy()
         ln = np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n].copy()
         st = np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n].copy()
