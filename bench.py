@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X hot path (chaining + gap-fill / split extension) on
+synthetic long reads against a GRCh37-sized stand-in reference.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (lamsa_hp_run_uploaded: kernels + result download) over one
+batch of reads that is already resident in HBM (reference, reads and seed hits uploaded before the
+timed region).  N > 1: launched by torch.distributed.run, one process per GPU, every rank owns its
+own shard of the read stream (different reads, same reference) -- weak scaling, no collective on
+the data path; only the barrier + MAX-over-ranks of the timing use RCCL.
+
+The JSON line also carries
+  roofline     -- algorithmic HBM bytes per launch (B_read = L + 20 H + 4 Cs + ceil(T/4) + 4 Co + 32 Rn summed
+                  over the batch) / kernel time measured with HIP events on the kernel's stream
+  cpu_baseline -- the oracle (plain-C port of the reference's path) on this box's host cores over a bounded
+                  sample of the same batch; a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # BASELINE.json configs; the metric ("10 kbp reads vs GRCh37") is quoted on the ONT config
+    "ont10k": dict(read_type="ont2d", profile="ont2d", length=10000, over={}, desc="10 kbp ONT-error reads (12%: sub/ins/del 4% each), -T ont2d"),
+    "pb5k": dict(read_type="pacbio", profile="pacbio", length=5000, over={}, desc="5 kbp PacBio-error reads (~15%), -T pacbio"),
+    "pb20k": dict(read_type="pacbio", profile="pb20k", length=20000, over={"band_w": 200}, desc="20 kbp reads at 15% error, -T pacbio -w 200"),
+    "mol5k": dict(read_type="default", profile="default", length=5000, over={}, desc="5 kbp 1%-error reads, default type"),
+}
+
+
+def algorithmic_bytes(B, streams, tbases):
+    """B_read = L + 20*H + 4*Cs + ceil(T/4) + 4*Co + 32*Rn per read, summed."""
+    L = int(B.read_off[-1]); H = int(B.hit_off[-1]); Cs = int(B.h_cig_n[:H].sum())
+    T4 = int(np.ceil(tbases.astype(np.int64) / 4.0).sum())
+    Co = Rn = 0
+    for s in streams:
+        i, n_lines = 3, s[1] + s[2]
+        for _ in range(n_lines):
+            n_res = s[i + 3]; i += 4
+            for _ in range(n_res):
+                cn = s[i + 6]; Co += cn; Rn += 1; i += 7 + cn
+    return L + 20 * H + 4 * Cs + T4 + 4 * Co + 32 * Rn, dict(L=L, H=H, Cs=Cs, T=int(tbases.astype(np.int64).sum()), Co=Co, Rn=Rn)
+
+
+def count_mapped_bases(B, streams):
+    """Sum of the lengths of reads with at least one mapped record (the 'aligned' of aligned Gbase/s)."""
+    tot = 0
+    for r, s in enumerate(streams):
+        i, ok = 3, False
+        for _ in range(s[1] + s[2]):
+            n_res = s[i + 3]; i += 4
+            ok = ok or n_res > 0
+            for _ in range(n_res):
+                i += 7 + s[i + 6]
+        if ok:
+            tot += int(B.read_off[r + 1] - B.read_off[r])
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ont10k", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=8192, help="reads per batch (= per step) and per GPU")
+    ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
+    ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--no-repeats", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = local if world > 1 else 0
+
+    import simbatch
+    import reflib
+    from lamsa_amd import hp
+
+    wl = WORKLOADS[a.workload]
+    threads = max(1, min(a.threads, os.cpu_count() or 1))
+    t0 = time.time()
+    ref = simbatch.SimRef(a.ref_bp, n_contigs=24, seed=5, threads=threads, repeats=not a.no_repeats)
+    t_ref = time.time() - t0
+    t0 = time.time()
+    B = simbatch.SimBatch(ref, a.reads, wl["length"], wl["profile"], seed=1000 + rank, threads=threads)
+    t_gen = time.time() - t0
+
+    P = hp.make_para(wl["read_type"], **wl["over"])
+    h = hp.LamsaHp(P, ref=(ref.pac, ref.l_pac, ref.seq_off, ref.seq_len), device=device)
+    h.upload_batch(B)                                   # inputs resident in HBM before the timed region
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        h.run_uploaded(fetch=True)
+    kernel_ms = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        streams, status = h.run_uploaded(fetch=True)
+        kernel_ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_bases = int(B.read_off[-1])
+    mapped_bases = count_mapped_bases(B, streams)
+    n_fail = int((status != 0).sum())
+    # whole-job totals over ranks
+    tot = np.array([a.reads, mapped_bases, n_bases, n_fail], dtype=np.float64)
+    if world > 1:
+        t = torch.tensor(tot, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot = t.cpu().numpy()
+    reads_per_s = tot[0] * a.steps / dt
+    gbase_per_s = tot[1] * a.steps / dt / 1e9
+
+    if rank == 0:
+        alg_bytes, parts = algorithmic_bytes(B, streams, h.last_tbases)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
+                "kernel": "k_align_batch", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
+        cpu = None
+        if a.cpu_seconds > 0:
+            lp = reflib.lo_para(wl["read_type"], **wl["over"])
+            probe = min(32, a.reads)
+            t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, threads); tp = time.perf_counter() - t0
+            n_s = int(max(probe, min(a.reads, probe * a.cpu_seconds / max(tp, 1e-3))))
+            sample = take_first(B, n_s)
+            t0 = time.perf_counter(); want = reflib.oracle_streams(sample, lp, threads); tc = time.perf_counter() - t0
+            same = sum(1 for i in range(n_s) if want[i] == streams[i])
+            cpu = {"value": round(n_s / tc, 3), "unit": "reads/s", "cores": threads, "kind": "port",
+                   "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path), %d threads, %.1f s" % (n_s, threads, tc),
+                   "gbase_per_s": round(float(sample.read_off[-1]) / tc / 1e9, 6), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s)}
+        hits = np.diff(B.hit_off)
+        out = {
+            "metric": "aligned Gbase/s, %s vs GRCh37-sized stand-in" % wl["desc"], "value": round(gbase_per_s, 6), "unit": "Gbase/s",
+            "reads_per_s": round(reads_per_s, 2),
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%s: %d reads/step/GPU x %d bp; reference stand-in %d bp in 24 contigs, %d repeat copies; seed hits simulated "
+                                   "(GEM thresholds, <=200/seed): %.1f hits/seed, %.0f hits/read" % (a.workload, a.reads, wl["length"], ref.l_pac, ref.n_copies, hits.mean() if len(hits) else 0, B.n_hits / max(1, a.reads)),
+                       "reads_per_step_per_gpu": a.reads, "read_len": wl["length"], "read_type": wl["read_type"], "parallelism": "reads sharded over %d GPU(s), no collectives" % a.gpus},
+            "reads_not_ok": int(tot[3]), "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def take_first(B, n):
+    """First n reads of a batch as a new batch object (numpy slices; offsets stay valid because they start at 0)."""
+    class _S:
+        pass
+    s = _S()
+    ns = int(B.seed_off[n]); nh = int(B.hit_off[ns])
+    s.n_reads = n
+    s.read_off = B.read_off[:n + 1].copy(); s.read_seq = B.read_seq[:max(int(B.read_off[n]), 1) + 4].copy()
+    s.seed_all = B.seed_all[:max(n, 1)].copy(); s.last_len = B.last_len[:max(n, 1)].copy(); s.seed_off = B.seed_off[:n + 1].copy()
+    s.seed_id = B.seed_id[:max(ns, 1)].copy(); s.hit_off = B.hit_off[:ns + 1].copy()
+    for k in ("h_pos", "h_chr", "h_strand", "h_nm", "h_len_dif", "h_cig_off", "h_cig_n"):
+        setattr(s, k, getattr(B, k)[:max(nh, 1)].copy())
+    s.cig = B.cig
+    s.pac, s.l_pac, s.seq_off, s.seq_len = B.pac, B.l_pac, B.seq_off, B.seq_len
+    return s
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,7 @@ typedef struct lamsa_hp_result {
     const int64_t *read_off;      /* [n_reads] start of read r's stream */
     const int32_t *read_len;      /* [n_reads] its length in words      */
     const int32_t *read_status;   /* [n_reads] LAMSA_HP_ST_* bits       */
+    const int32_t *read_tbases;   /* [n_reads] reference bases the read's DP jobs fetched from the packed reference (accounting) */
 } lamsa_hp_result;
 
 int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_hp_result *res);

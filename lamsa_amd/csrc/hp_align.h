@@ -113,7 +113,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     r.H = (int)(r.hit_off[r.seed_out] - r.hb);
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
-    r.flip = false; r.cur_read = r.read; r.rc_ready = false;
+    r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
     Ctx &cx = r.cx;
     const int H = r.H;
     // read-lifetime allocations
@@ -175,6 +175,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
         a.out.read_out_off[rd] = (int64_t)off; a.out.read_out_len[rd] = n_words;
     } else { a.out.read_out_off[rd] = -1; a.out.read_out_len[rd] = 0; }
     a.out.read_status[rd] = st;
+    if (a.out.read_tbases) a.out.read_tbases[rd] = (int32_t)(r.t_bases > 0x7fffffffLL ? 0x7fffffffLL : r.t_bases);
 }
 
 }  // namespace hp

@@ -25,11 +25,12 @@ __global__ __launch_bounds__(64) void k_align_batch(AlignArgs a)
 
 struct OutDev {                   // result arrays of one launch: per-read offset / length / status + the stream arena
     DevBuf buf; int64_t stream_cap = 0;
-    static size_t hdr(int n) { return al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n); }
+    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n); }
     int ensure(int n, int64_t cap) { stream_cap = cap; return buf.ensure(hdr(n) + 4 * (size_t)cap + 256); }
     int64_t *off() const { return (int64_t *)buf.p; }
     int32_t *len(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n)); }
     int32_t *st(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n) + al256(4 * (size_t)n)); }
+    int32_t *tb(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n)); }
     int32_t *stream(int n) const { return (int32_t *)((char *)buf.p + hdr(n)); }
 };
 
@@ -43,7 +44,7 @@ struct AlignState {
     std::vector<int32_t> order, h_len, h_H;
     int32_t max_L = 0, max_H = 0;
     // host copies of the results
-    std::vector<int32_t> stream, r_len, r_st; std::vector<int64_t> r_off;
+    std::vector<int32_t> stream, r_len, r_st, r_tb; std::vector<int64_t> r_off;
 };
 
 static std::map<lamsa_hp_handle *, AlignState *> g_states;     // per-handle state of the align entry points
@@ -159,7 +160,7 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     a.P = h->para;
     a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
     a.in = S->in;
-    a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.stream = O.stream(n);
+    a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)S->misc.p + 64);
     a.slab = (char *)S->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)S->misc.p;
     a.order = d_order; a.n_units = n_units; a.scale = scale;
@@ -182,10 +183,10 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
     const int n = S->n_reads;
     h->kernel_ms[0] = h->kernel_ms[1] = 0;
-    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
+    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
     if (n == 0) {
         S->stream.assign(4, 0);
-        if (R) { R->stream = S->stream.data(); R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); }
+        if (R) { R->stream = S->stream.data(); R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); }
         return LAMSA_HP_OK;
     }
     // ---- main pass: every read, costliest first
@@ -198,6 +199,7 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
     HIPCHK(h, hipMemcpy(S->r_st.data(), S->out1.st(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemcpy(S->r_off.data(), S->out1.off(), 8 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemcpy(S->r_len.data(), S->out1.len(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipMemcpy(S->r_tb.data(), S->out1.tb(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     // ---- retry pass: reads whose work buffers (or the stream arena) were too small -- outliers; 8x capacities
     std::vector<int32_t> again;
     for (int r = 0; r < n; ++r) if ((S->r_st[r] & LAMSA_HP_ST_OVERFLOW) || S->r_off[r] < 0) again.push_back(r);
@@ -211,18 +213,19 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
         if (rc) return rc;
         HIPCHK(h, hipMemcpy(&used2, (char *)S->misc.p + 64, 8, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
         if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
-        std::vector<int64_t> off2((size_t)n); std::vector<int32_t> len2((size_t)n), st2((size_t)n);
+        std::vector<int64_t> off2((size_t)n); std::vector<int32_t> len2((size_t)n), st2((size_t)n), tb2((size_t)n);
         HIPCHK(h, hipMemcpy(st2.data(), S->out2.st(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpy(off2.data(), S->out2.off(), 8 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpy(len2.data(), S->out2.len(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
+        HIPCHK(h, hipMemcpy(tb2.data(), S->out2.tb(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
+        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
     }
     for (int r = 0; r < n; ++r) if (S->r_off[r] < 0) { S->r_off[r] = 0; S->r_len[r] = 0; S->r_st[r] |= LAMSA_HP_ST_OVERFLOW; }
     if (!R) return LAMSA_HP_OK;
     S->stream.resize((size_t)(used1 + used2) + 4);
     if (used1) HIPCHK(h, hipMemcpy(S->stream.data(), S->out1.stream(n), 4 * (size_t)used1, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     if (used2) HIPCHK(h, hipMemcpy(S->stream.data() + used1, S->out2.stream(n), 4 * (size_t)used2, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    R->stream = S->stream.data(); R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data();
+    R->stream = S->stream.data(); R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data();
     return LAMSA_HP_OK;
 }
 

@@ -46,6 +46,7 @@ struct BatchOut {
     int64_t *read_out_off;       // [n_reads] start of each read's stream (-1: arena overflow)
     int32_t *read_out_len;       // [n_reads]
     int32_t *read_status;        // [n_reads]
+    int32_t *read_tbases;        // [n_reads] reference bases fetched (2-bit windows), or nullptr
 };
 
 struct AlignArgs {

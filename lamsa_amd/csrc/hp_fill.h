@@ -35,6 +35,7 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
     if (start0 + *len > clen) *len = (int32_t)(clen - start0);                          // :474
     const int64_t k0 = r.ref.seq_off[chr - 1] + start0;
     const int32_t n = *len;
+    r.t_bases += n > 0 ? n : 0;
     const uint8_t *pac = r.ref.pac;
     for (int32_t b = 0; b < n; b += 64) {
         WAVE_FOR(l) {

@@ -51,7 +51,7 @@ class HpBatch(C.Structure):
 class HpResult(C.Structure):
     """struct lamsa_hp_result"""
     _fields_ = [("stream", C.POINTER(C.c_int32)), ("stream_words", C.c_int64), ("read_off", C.POINTER(C.c_int64)),
-                ("read_len", C.POINTER(C.c_int32)), ("read_status", C.POINTER(C.c_int32))]
+                ("read_len", C.POINTER(C.c_int32)), ("read_status", C.POINTER(C.c_int32)), ("read_tbases", C.POINTER(C.c_int32))]
 
 
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
@@ -190,6 +190,8 @@ class LamsaHp:
         ln = np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n].copy()
         st = np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n].copy()
         stream = np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)).copy()
+        self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n].copy()
+        self.last_stream_words = int(R.stream_words)
         return [stream[int(off[i]):int(off[i]) + int(ln[i])].tolist() for i in range(n)], st
 
     def align_batch(self, batch):

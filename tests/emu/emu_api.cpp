@@ -38,7 +38,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.in.h_cig_off = B->h_cig_off; a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig;
     unsigned long long cursor = 0;
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
-    a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status;
+    a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;
     std::vector<char> slab(slab_bytes);
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale;
     for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0);

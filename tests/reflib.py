@@ -308,7 +308,7 @@ def oracle_streams(batch, P, n_threads=4):
     """Per-read result streams (lists of ints) from the oracle."""
     L = oracle()
     n = batch.n_reads
-    b, r = batch.c_lo_batch(), batch.c_lo_ref()
+    b, r = Batch.c_lo_batch(batch), Batch.c_lo_ref(batch)
     sp = C.POINTER(C.c_int32)(); nw = C.c_int64(0)
     off = np.zeros(max(n, 1), np.int64); ln = np.zeros(max(n, 1), np.int32); st = np.zeros(max(n, 1), np.int32)
     L.lo_batch_align_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
