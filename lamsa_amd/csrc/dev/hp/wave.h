@@ -15,6 +15,10 @@
 #define HP_INL __device__ __forceinline__
 #define HP_NOINL __device__ __noinline__
 
+// pointers that the hot loops dereference are cast to the global address space so that hipcc emits
+// global_load/global_store instead of flat_* (which also wait on the LDS counter)
+#define HP_G __attribute__((address_space(1)))
+
 namespace wv {
 
 constexpr int W = 64;

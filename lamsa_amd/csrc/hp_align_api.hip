@@ -11,7 +11,10 @@
 
 using namespace hp;
 
-__global__ __launch_bounds__(64) void k_align_batch(AlignArgs a)
+#ifndef HP_WAVES_PER_SIMD
+#define HP_WAVES_PER_SIMD 1
+#endif
+__global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs a)
 {
     const int slot = blockIdx.x;
     for (;;) {

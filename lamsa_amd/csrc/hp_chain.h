@@ -34,6 +34,16 @@ HP_INL int score_table(int flag) { return flag <= 3 ? 1 : (flag <= 7 ? -3 : -6);
 #define HP_MAX_SLOTS 16383
 #define HP_MAX_HITS_PER_SEED 16383
 
+// static facts of one seed hit, packed so that the predecessor scan needs two wide loads per hit
+struct NodeS {
+    int64_t pos;                // 1-based leftmost reference coordinate
+    int32_t chr;                // contig id
+    int32_t slot_j;             // seed slot << 14 | hit index within the seed
+    int16_t sid;                // 1-based seed id (unflipped: chaining never runs while a '-' line is being filled)
+    int8_t strand, len_dif8;    // +1/-1; len_dif clamped to int8 (|len_dif| <= 127 always holds for 50-bp seeds)
+    int32_t pad_;
+};
+
 // one read being aligned by this wave
 struct ReadCtx {
     Ctx cx;
@@ -53,6 +63,7 @@ struct ReadCtx {
     int32_t *n_score, *n_NM, *n_from, *n_in_de, *n_son_n, *n_first, *n_last, *n_next;
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
     int8_t *n_dp_flag; uint8_t *n_match_flag, *n_son_flag;
+    NodeS *ns;                  // packed static record per hit
 };
 
 HP_INL int hoff(const ReadCtx &r, int x) { return (int)(r.hit_off[x] - r.hb); }
@@ -112,10 +123,48 @@ HP_INL void add_son(ReadCtx &r, int fa, int son)
     ++r.n_son_n[fa];
 }
 
+HP_INL NodeS node_load(const HP_G NodeS *p)
+{   // member-wise: a struct copy cannot bind to an address-space qualified lvalue; hipcc merges these into wide loads
+    NodeS q; q.pos = p->pos; q.chr = p->chr; q.slot_j = p->slot_j; q.sid = p->sid; q.strand = p->strand; q.len_dif8 = p->len_dif8; q.pad_ = 0;
+    return q;
+}
+
+// edge class from two packed records (same arithmetic as edge_flag; pre != cur, ids unflipped)
+struct EdgeK { int seed_step, seed_len, match_dis, high_err, mis3, sv_len, half_split; };
+HP_INL EdgeK edge_consts(const lamsa_hp_para *P)
+{
+    EdgeK k; k.seed_step = P->seed_step; k.seed_len = P->seed_len; k.match_dis = P->match_dis; k.high_err = P->aln_mode & 2;
+    k.mis3 = 3 * P->mismatch_thd; k.sv_len = P->SV_len_thd; k.half_split = P->split_len / 2;
+    return k;
+}
+HP_INL int edge_flag_packed(const EdgeK &k, const NodeS &pre, const NodeS &cur)
+{
+    if ((pre.slot_j >> 14) == (cur.slot_j >> 14)) return F_UNCONNECT;
+    const int sp = pre.strand;
+    if (cur.chr != pre.chr || cur.strand != sp) return F_CHR_DIF;
+    const int idp = pre.sid, idc = cur.sid, did = iabs(idp - idc);
+    if (did * k.seed_step < k.seed_len) return F_UNCONNECT;
+    const int64_t exp = pre.pos + (int64_t)(sp * (idc - idp) * k.seed_step);
+    const int64_t act = cur.pos;
+    const int dis = (int)((int64_t)sp * ((idp < idc) ? (act - exp) : (exp - act)) - ((sp * (idp - idc) < 0) ? pre.len_dif8 : cur.len_dif8));
+    const int mat_dis = k.match_dis * (k.high_err ? did : 1);
+    if (dis <= mat_dis && dis >= -mat_dis) return did == 1 ? F_MATCH : (did <= k.mis3 ? F_MISMATCH : F_LONG_MISMATCH);
+    if (dis > mat_dis && dis < k.sv_len) return F_DELETE;
+    if ((dis < -mat_dis && dis >= 0 - (did * k.seed_step - k.seed_len)) || (dis < -k.half_split && dis >= -k.sv_len)) return F_INSERT;
+    return F_UNCONNECT;
+}
+
 // ---------------------------------------------------------------- frag_dp_update, :701-764
 HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
 {
-    const int x = r.n_seed[t];
+    // everything the scan touches, as global-address-space pointers held in registers
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+    const HP_G int32_t *g_score = (const HP_G int32_t *)r.n_score, *g_NM = (const HP_G int32_t *)r.n_NM;
+    const HP_G int8_t *g_dp = (const HP_G int8_t *)r.n_dp_flag;
+    const HP_G uint8_t *g_son = (const HP_G uint8_t *)r.n_son_flag;
+    const EdgeK K = edge_consts(r.cx.P);
+    const NodeS T = node_load(ns + t);
+    const int x = T.slot_j >> 14;
     const int lo = hoff(r, start_slot), hi = hoff(r, x);
     const int t_NM = r.n_NM[t];
     int max_from = r.n_from[t], max_score = r.n_score[t], max_NM = t_NM, max_flag = r.n_dp_flag[t];
@@ -128,16 +177,16 @@ HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
         WAVE_FOR(l) {
             const int p = base - l;
             key[l] = -1; negp[l] = -0x7fffffff;
-            if (p >= lo && r.n_dp_flag[p] == dp_flag) {
-                const int sp = r.h_strand[p];
-                if (!(sp == 1 && r.n_son_flag[p] <= F_MATCH_THD)) {            // '+': already has a match son, :718-720
-                    const int flag = edge_flag(r, p, t);
+            if (p >= lo) {
+                const NodeS Q = node_load(ns + p);                       // independent loads, issued back to back
+                const int dflag = g_dp[p], sflag = g_son[p], pscore = g_score[p], pnm = g_NM[p];
+                if (dflag == dp_flag && !(Q.strand == 1 && sflag <= F_MATCH_THD)) {           // '+': already has a match son, :718-720
+                    const int flag = edge_flag_packed(K, Q, T);
                     if (flag != F_UNCONNECT && flag != F_CHR_DIF) {
-                        const int i = r.n_seed[p], j = p - hoff(r, i);
-                        const int pos = ((x - 1 - i) << 14) | j;                  // scan order: seeds descending, hits ascending
-                        const int cand = r.n_score[p] + 1 + score_table(flag);
-                        const int nm = r.n_NM[p] + t_NM;
-                        if (sp == -1 && flag <= F_MATCH_THD) negp[l] = -pos;      // '-': first match precursor wins, :726-733
+                        const int pos = ((x - 1 - (Q.slot_j >> 14)) << 14) | (Q.slot_j & 16383);   // scan order: seeds descending, hits ascending
+                        const int cand = pscore + 1 + score_table(flag);
+                        const int nm = pnm + t_NM;
+                        if (Q.strand == -1 && flag <= F_MATCH_THD) negp[l] = -pos;             // '-': first match precursor wins, :726-733
                         key[l] = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
                     }
                 }
@@ -147,11 +196,12 @@ HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
         const long long bk = wv::reduce_max64(key);
         if (np < neg_pos) neg_pos = np;
         if (bk > best_key) best_key = bk;
-        if (neg_pos != 0x7fffffff && base - 64 >= lo && r.n_seed[base - 64] < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
+        if (neg_pos != 0x7fffffff && base - 64 >= lo && (ns[base - 64].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
     }
     if (neg_pos != 0x7fffffff) {
         const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = hoff(r, i) + j;
-        const int flag = edge_flag(r, p, t);
+        const NodeS Q = node_load(ns + p);
+        const int flag = edge_flag_packed(K, Q, T);
         max_from = p; max_score = r.n_score[p] + 1 + score_table(flag); max_flag = flag; max_NM = r.n_NM[p] + t_NM;
     } else if (best_key >= 0) {
         const int pos = POSMAX - (int)(best_key & POSMAX);
@@ -159,16 +209,16 @@ HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
         const int cand = (int)(best_key >> 47) - 32768;
         if (cand > max_score || (cand == max_score && nm < max_NM)) {
             const int i = x - 1 - (pos >> 14), j = pos & 16383, p = hoff(r, i) + j;
-            max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag(r, p, t);
+            const NodeS Q = node_load(ns + p);
+            max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag_packed(K, Q, T);
         }
     }
-    if (max_from != r.n_from[t]) {
+    if (max_from != r.n_from[t]) {           // wave-uniform stores: every lane writes (and later re-reads) the same words itself
         r.n_son_flag[max_from] = (uint8_t)max_flag;
         r.n_from[t] = max_from; r.n_score[t] = max_score; r.n_NM[t] = max_NM; r.n_match_flag[t] = (uint8_t)max_flag;
         r.n_node_n[t] = r.n_node_n[max_from] + 1;
         add_son(r, max_from, t);
     }
-    wv::sync();
 }
 
 // ---------------------------------------------------------------- frag_min_extend for one MIN hit, :1031-1066
@@ -177,18 +227,26 @@ HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
 // segmented ballot.  The result is a set union, so the order over MIN hits is irrelevant.
 HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
 {
-    const int xm = r.n_seed[m];
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+    HP_G int8_t *g_dp = (HP_G int8_t *)r.n_dp_flag;
+    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+    const int64_t hb = r.hb;
+    const EdgeK K = edge_consts(r.cx.P);
+    const NodeS M = node_load(ns + m);
+    const int xm = M.slot_j >> 14;
     int carry_seed = -1, carry_found = 0;
     for (int base = 0; base < r.H; base += 64) {
-        wv::Lane<int> q, seg;
+        wv::Lane<int> q, seg, sd;
         WAVE_FOR(l) {
             const int k = base + l;
-            q[l] = 0; seg[l] = 0;
+            q[l] = 0; seg[l] = 0; sd[l] = -1;
             if (k < r.H) {
-                const int s = r.n_seed[k];
-                int st = hoff(r, s) - base; seg[l] = st > 0 ? st : 0;
-                if (s != xm && mapn(r, s) > min_n) {
-                    const int f = s < xm ? edge_flag(r, k, m) : edge_flag(r, m, k);
+                const NodeS Q = node_load(ns + k);
+                const int s = Q.slot_j >> 14;
+                const int h0 = (int)(g_hoff[s] - hb), h1 = (int)(g_hoff[s + 1] - hb);
+                int st = h0 - base; seg[l] = st > 0 ? st : 0; sd[l] = s;
+                if (s != xm && h1 - h0 > min_n) {
+                    const int f = s < xm ? edge_flag_packed(K, Q, M) : edge_flag_packed(K, M, Q);
                     q[l] = (f == F_MATCH || f == F_MISMATCH || f == F_LONG_MISMATCH);
                 }
             }
@@ -197,13 +255,12 @@ HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
         WAVE_FOR(l) {
             const int k = base + l;
             if (k < r.H && q[l]) {
-                const int s = r.n_seed[k];
                 unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
-                if (earlier == 0 && !(s == carry_seed && carry_found)) r.n_dp_flag[k] = MIN_FLAG;
+                if (earlier == 0 && !(sd[l] == carry_seed && carry_found)) g_dp[k] = MIN_FLAG;
             }
         }
         const int klast = base + 63 < r.H ? base + 63 : r.H - 1;
-        const int s_last = r.n_seed[klast];
+        const int s_last = ns[klast].slot_j >> 14;
         int st = hoff(r, s_last) - base; st = st > 0 ? st : 0;
         const int found_here = (qb >> st) != 0;
         carry_found = found_here || (carry_seed == s_last && carry_found);

@@ -54,33 +54,39 @@ HP_NOINL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 1));
     uint8_t *z = out ? (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1) : nullptr;
     if (!H || !E || (out && !z)) { arena_release(cx.tmp, mark); return 0; }
-    const lamsa_hp_para *P = cx.P;
+    const int sc_match = cx.P->match, sc_mis = -cx.P->mis;
+    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E;
+    HP_G uint8_t *gz = (HP_G uint8_t *)z;
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
+#define HP_SUB(tb, qb) (((tb) > 3 || (qb) > 3) ? -1 : ((tb) == (qb) ? sc_match : sc_mis))
 
     for (int j0 = 0; j0 <= qlen; j0 += 64) {                               // first row, :569-572
         WAVE_FOR(l) {
             int j = j0 + l;
-            if (j <= qlen) { H[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : HP_NEG_INF); E[j] = HP_NEG_INF; }
+            if (j <= qlen) { gH[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : HP_NEG_INF); gE[j] = HP_NEG_INF; }
         }
     }
     wv::sync();
     for (int i = 0; i < tlen; ++i) {
-        const int ti = seq_at(t, i);
+        const int ti = gt[(long)i * ts];
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
-        int carryH = H[beg];          // H(i-1,beg-1), read before the in-place update below
+        int carryH = gH[beg];          // H(i-1,beg-1), read before the in-place update below
         int Fin = HP_NEG_INF;         // F(i,beg)
-        H[beg] = h1_init;             // eh[beg].h = H(i,beg-1)
+        gH[beg] = h1_init;            // eh[beg].h = H(i,beg-1)
         for (int j0 = beg; j0 < end; j0 += 64) {
             const int nxt = j0 + 64;
-            const int carry_next = nxt <= qlen ? H[nxt] : 0;   // old value, lane 63 is about to overwrite it
+            const int carry_next = nxt <= qlen ? gH[nxt] : 0;   // old value, lane 63 is about to overwrite it
             wv::Lane<int> m, e, key;
             WAVE_FOR(l) {
                 int j = j0 + l;
                 if (j < end) {
-                    int hm = l == 0 ? carryH : H[j];
-                    m[l] = hm + sub_score(P, ti, seq_at(q, j));
-                    e[l] = E[j];
+                    int hm = l == 0 ? carryH : gH[j];
+                    const int qb = gq[(long)j * qs];
+                    m[l] = hm + HP_SUB(ti, qb);
+                    e[l] = gE[j];
                     key[l] = m[l] - oe_ins + j * e_ins;
                 } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
             }
@@ -99,16 +105,16 @@ HP_NOINL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                     if (ee > tt) dir |= 1 << 2; else ee = tt;              // :603-607
                     tt = mm - oe_ins; f -= e_ins;
                     if (f > tt) dir |= 2 << 4; else f = tt;                // :608-611
-                    E[j] = ee;
-                    H[j + 1] = h;                                          // eh[j+1].h = H(i,j)
-                    if (z) z[(long)i * n_col + (j - beg)] = (uint8_t)dir;
+                    gE[j] = ee;
+                    gH[j + 1] = h;                                         // eh[j+1].h = H(i,j)
+                    if (z) gz[(long)i * n_col + (j - beg)] = (uint8_t)dir;
                     fnext[l] = f;
                 }
             }
             Fin = wv::bcast(fnext, 63);
             carryH = carry_next;
         }
-        E[end] = HP_NEG_INF;                                               // :632
+        gE[end] = HP_NEG_INF;                                              // :632
         wv::sync();
     }
     const int score = H[qlen];
@@ -151,6 +157,11 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
     uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
     if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return 0; }
 
+    const int sc_match = P->match, sc_mis = -P->mis;
+    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E, *growb = (HP_G int32_t *)rowb;
+    HP_G uint8_t *gz = (HP_G uint8_t *)z;
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
     // first row, :692-694: h0, h0-oe_ins, then -e_ins per column while the previous cell is > e_ins
     {
         const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
@@ -163,7 +174,7 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
                     if (j == 0) v = h0;
                     else if (j == 1) v = h1v;
                     else if (j <= qlen) { int prev = h1v - (j - 2) * e_ins; if (prev > e_ins) v = prev - e_ins; }
-                    H[j] = v; E[j] = 0;
+                    gH[j] = v; gE[j] = 0;
                 }
             }
         }
@@ -172,7 +183,7 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
     int beg = 0, end = qlen;
     for (int i = 0; i < tlen; ++i) {
-        const int ti = seq_at(t, i);
+        const int ti = gt[(long)i * ts];
         const int d_beg = i > w ? i - w : 0;
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
@@ -180,25 +191,26 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
-        rowb[2 * i] = beg; rowb[2 * i + 1] = end;
-        int carryH = H[beg];
+        growb[2 * i] = beg; growb[2 * i + 1] = end;
+        int carryH = gH[beg];
         int Fin = 0;
         long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
         int h_last = h1_init;           // H(i,end-1), or the first-column value when the row is empty
         // band shrink bookkeeping (:775-778): nz(j) = eh[j].h != 0 || eh[j].e != 0 after this row
         int first_nz = -1, last_nz = -1, prev_h_nz = h1_init != 0;
-        if (beg < end) H[beg] = h1_init; else H[end] = h1_init;            // eh[end].h = h1 when the row is empty (:758)
+        if (beg < end) gH[beg] = h1_init; else gH[end] = h1_init;            // eh[end].h = h1 when the row is empty (:758)
         for (int j0 = beg; j0 < end; j0 += 64) {
             const int nxt = j0 + 64;
-            const int carry_next = nxt <= qlen + 1 ? H[nxt] : 0;
+            const int carry_next = nxt <= qlen + 1 ? gH[nxt] : 0;
             wv::Lane<int> m, e, key;
             WAVE_FOR(l) {
                 int j = j0 + l;
                 if (j < end) {
-                    int hm = l == 0 ? carryH : H[j];
-                    int M = hm ? hm + sub_score(P, ti, seq_at(q, j)) : 0;   // :737
+                    int hm = l == 0 ? carryH : gH[j];
+                    const int qb = gq[(long)j * qs];
+                    int M = hm ? hm + HP_SUB(ti, qb) : 0;                   // :737
                     int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
-                    m[l] = M; e[l] = E[j]; key[l] = tt + j * e_ins;
+                    m[l] = M; e[l] = gE[j]; key[l] = tt + j * e_ins;
                 } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
             }
             wv::scan_max_excl(key, HP_SCAN_IDENT);
@@ -217,9 +229,9 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
                     if (ee > tt) dir |= 1 << 2; else ee = tt;               // :745-750
                     tt = M - oe_ins; tt = tt > 0 ? tt : 0; f -= e_ins;
                     if (f > tt) dir |= 2 << 4; else f = tt;                 // :751-755
-                    E[j] = ee;
-                    H[j + 1] = h;
-                    z[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
+                    gE[j] = ee;
+                    gH[j + 1] = h;
+                    gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
                     fnext[l] = f; hnz[l] = h != 0; enz[l] = ee != 0;
                     rk[l] = ((long long)h << 32) | (unsigned)j;
                 }
@@ -241,8 +253,8 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
         }
         // H(i,end-1): value of the last computed cell (needed for gscore / eh[end].h)
         wv::sync();
-        if (beg < end) h_last = H[end];
-        E[end] = 0;                                                        // :758
+        if (beg < end) h_last = gH[end];
+        gE[end] = 0;                                                       // :758
         const int jj = beg < end ? end : beg;                              // loop variable j after the row
         if (jj == qlen) {                                                  // :759-762
             max_ie = gscore > h_last ? max_ie : i;

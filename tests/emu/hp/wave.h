@@ -10,6 +10,8 @@
 #define HP_INL static inline
 #define HP_NOINL static
 
+#define HP_G
+
 namespace wv {
 
 constexpr int W = 64;
