@@ -19,6 +19,12 @@
 // global_load/global_store instead of flat_* (which also wait on the LDS counter)
 #define HP_G __attribute__((address_space(1)))
 
+typedef int hp_v4i __attribute__((ext_vector_type(4)));
+typedef int hp_v2i __attribute__((ext_vector_type(2)));
+// whole-vector loads: the compiler cannot sink individual members of a record behind later branches
+HP_INL void hp_load16(const HP_G void *p, int *o) { hp_v4i v = *(const HP_G hp_v4i *)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+HP_INL void hp_load8(const HP_G void *p, int *o) { hp_v2i v = *(const HP_G hp_v2i *)p; o[0] = v.x; o[1] = v.y; }
+
 namespace wv {
 
 constexpr int W = 64;

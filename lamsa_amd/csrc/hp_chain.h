@@ -124,8 +124,12 @@ HP_INL void add_son(ReadCtx &r, int fa, int son)
 }
 
 HP_INL NodeS node_load(const HP_G NodeS *p)
-{   // member-wise: a struct copy cannot bind to an address-space qualified lvalue; hipcc merges these into wide loads
-    NodeS q; q.pos = p->pos; q.chr = p->chr; q.slot_j = p->slot_j; q.sid = p->sid; q.strand = p->strand; q.len_dif8 = p->len_dif8; q.pad_ = 0;
+{   // layout: pos[0..8) chr[8..12) slot_j[12..16) sid[16..18) strand[18] len_dif8[19] pad[20..24)
+    int a[4], b[2];                         // two whole-vector loads (16 B + 8 B), see hp_load16
+    hp_load16(p, a); hp_load8((const HP_G char *)p + 16, b);
+    NodeS q;
+    q.pos = (int64_t)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]); q.chr = a[2]; q.slot_j = a[3];
+    q.sid = (int16_t)(b[0] & 0xffff); q.strand = (int8_t)((b[0] >> 16) & 0xff); q.len_dif8 = (int8_t)((b[0] >> 24) & 0xff); q.pad_ = b[1];
     return q;
 }
 
@@ -171,32 +175,43 @@ HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
     long long best_key = -1;          // (cand+32768) << 47 | (524287-NM) << 28 | (POSMAX-pos)
     int neg_pos = 0x7fffffff;         // scan position of the first '-' strand match precursor
     const int POSMAX = (1 << 28) - 1;
+    // Every lane keeps its own running best over the chunks it sees; the two wave reductions happen once per
+    // target, not once per chunk.  The per-lane body is written without short-circuit conditions so that all
+    // five loads of a predecessor are issued back to back (one memory round trip per chunk, not five).
+    wv::Lane<long long> key;
+    wv::Lane<int> negp;
+    WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
     for (int base = hi - 1; base >= lo; base -= 64) {
-        wv::Lane<long long> key;
-        wv::Lane<int> negp;
+        wv::Lane<int> anyneg;
         WAVE_FOR(l) {
             const int p = base - l;
-            key[l] = -1; negp[l] = -0x7fffffff;
-            if (p >= lo) {
-                const NodeS Q = node_load(ns + p);                       // independent loads, issued back to back
-                const int dflag = g_dp[p], sflag = g_son[p], pscore = g_score[p], pnm = g_NM[p];
-                if (dflag == dp_flag && !(Q.strand == 1 && sflag <= F_MATCH_THD)) {           // '+': already has a match son, :718-720
-                    const int flag = edge_flag_packed(K, Q, T);
-                    if (flag != F_UNCONNECT && flag != F_CHR_DIF) {
-                        const int pos = ((x - 1 - (Q.slot_j >> 14)) << 14) | (Q.slot_j & 16383);   // scan order: seeds descending, hits ascending
-                        const int cand = pscore + 1 + score_table(flag);
-                        const int nm = pnm + t_NM;
-                        if (Q.strand == -1 && flag <= F_MATCH_THD) negp[l] = -pos;             // '-': first match precursor wins, :726-733
-                        key[l] = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
-                    }
-                }
-            }
+            const int inr = p >= lo;
+            const int pc = inr ? p : lo;                         // clamped: always a valid node of this read
+            const NodeS Q = node_load(ns + pc);
+            const int dflag = g_dp[pc], sflag = g_son[pc], pscore = g_score[pc], pnm = g_NM[pc];
+            const int flag = edge_flag_packed(K, Q, T);
+            const int ok = inr & (dflag == dp_flag) & !((Q.strand == 1) & (sflag <= F_MATCH_THD)) & (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
+            const int pos = ((x - 1 - (Q.slot_j >> 14)) << 14) | (Q.slot_j & 16383);        // scan order: seeds descending, hits ascending
+            const int cand = pscore + 1 + score_table(flag);
+            const int nm = pnm + t_NM;
+            const int isneg = ok & (Q.strand == -1) & (flag <= F_MATCH_THD);                 // '-': first match precursor wins, :726-733
+            const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+            const long long kk = ok ? k : -1;
+            key[l] = kk > key[l] ? kk : key[l];
+            const int np = isneg ? -pos : -0x7fffffff;
+            negp[l] = np > negp[l] ? np : negp[l];
+            anyneg[l] = isneg;
         }
+        if (wv::ballot(anyneg) != 0) {                           // rare: decide whether the scan may stop early
+            const int np = -wv::reduce_max(negp);
+            if (np < neg_pos) neg_pos = np;
+            if (base - 64 >= lo && (int)(ns[base - 64].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;    // nothing earlier in scan order is left
+        }
+    }
+    {
         const int np = -wv::reduce_max(negp);
-        const long long bk = wv::reduce_max64(key);
         if (np < neg_pos) neg_pos = np;
-        if (bk > best_key) best_key = bk;
-        if (neg_pos != 0x7fffffff && base - 64 >= lo && (ns[base - 64].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
+        best_key = wv::reduce_max64(key);
     }
     if (neg_pos != 0x7fffffff) {
         const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = hoff(r, i) + j;

@@ -12,6 +12,9 @@
 
 #define HP_G
 
+HP_INL void hp_load16(const void *p, int *o) { memcpy(o, p, 16); }
+HP_INL void hp_load8(const void *p, int *o) { memcpy(o, p, 8); }
+
 namespace wv {
 
 constexpr int W = 64;
