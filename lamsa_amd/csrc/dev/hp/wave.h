@@ -47,6 +47,7 @@ HP_INL void sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 HP_INL bool leader() { return lane() == 0; }
+HP_INL long long clock() { return (long long)__builtin_readcyclecounter(); }     // diagnostic builds only (-DHP_PROF)
 HP_INL int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 HP_INL long long uni64(long long v) {
     int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));

@@ -96,8 +96,17 @@ HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap,
 }
 
 // ---- the per-read entry point ----
+#ifdef HP_PROF
+#define HP_STAMP(k) do { const long long now_ = wv::clock(); if (a.prof) a.prof[(size_t)rd * 16 + (k)] += now_ - t_last_; t_last_ = now_; } while (0)
+#else
+#define HP_STAMP(k) do { } while (0)
+#endif
+
 HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
 {
+#ifdef HP_PROF
+    long long t_last_ = wv::clock();
+#endif
     ReadCtx r;
     r.cx.P = &a.P; r.cx.status = 0;
     arena_init(r.cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
@@ -114,6 +123,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
+    r.prof = a.prof ? a.prof + (size_t)rd * 16 : nullptr;
     Ctx &cx = r.cx;
     const int H = r.H;
     // read-lifetime allocations
@@ -154,11 +164,15 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
         }
         wv::sync();
         out_put(cx, o, 0); out_put(cx, o, 0); out_put(cx, o, 0);
+        HP_STAMP(0);
         // round 1: frag_line_BCC + frag_check + get_reg   (lamsa_aln.c:857-865)
         {
             const size_t mark = arena_mark(cx.tmp);
             FLines F;
-            if (chain_first(r, F) && F.n > 0) { o.w[n0_pos] = F.n; fill_round(r, F, o, &G, reg_cap, a.scale); }
+            const bool ok1 = chain_first(r, F);
+            HP_STAMP(1);
+            if (ok1 && F.n > 0) { o.w[n0_pos] = F.n; fill_round(r, F, o, &G, reg_cap, a.scale); }
+            HP_STAMP(2);
             arena_release(cx.tmp, mark);
         }
         // round 2: frag_line_remain + frag_check          (lamsa_aln.c:867-871)
@@ -166,7 +180,10 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
             const size_t mark = arena_mark(cx.tmp);
             regs_remain(r, G, a.P.seed_len, r.L);
             FLines F;
-            if (chain_remain(r, G, F) && F.n > 0) { o.w[n1_pos] = F.n; fill_round(r, F, o, nullptr, 0, a.scale); }
+            const bool ok2 = chain_remain(r, G, F);
+            HP_STAMP(3);
+            if (ok2 && F.n > 0) { o.w[n1_pos] = F.n; fill_round(r, F, o, nullptr, 0, a.scale); }
+            HP_STAMP(4);
             arena_release(cx.tmp, mark);
         }
     }
@@ -187,6 +204,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
         a.out.read_out_off[rd] = (int64_t)off; a.out.read_out_len[rd] = n_words;
     } else { a.out.read_out_off[rd] = -1; a.out.read_out_len[rd] = 0; }
     a.out.read_status[rd] = st;
+    HP_STAMP(5);
     if (a.out.read_tbases) a.out.read_tbases[rd] = (int32_t)(r.t_bases > 0x7fffffffLL ? 0x7fffffffLL : r.t_bases);
 }
 

@@ -166,7 +166,11 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)S->misc.p + 64);
     a.slab = (char *)S->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)S->misc.p;
-    a.order = d_order; a.n_units = n_units; a.scale = scale;
+    a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr;
+#ifdef HP_PROF
+    static DevBuf profbuf;
+    if (profbuf.ensure(sizeof(long long) * 16 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 16 * (size_t)n); a.prof = (long long *)profbuf.p; }
+#endif
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemsetAsync(S->misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(h->ev0, s), LAMSA_HP_EKERNEL);
@@ -175,6 +179,19 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     HIPCHK(h, hipEventRecord(h->ev1, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
     if (ms) hipEventElapsedTime(ms, h->ev0, h->ev1);
+#ifdef HP_PROF
+    if (a.prof) {
+        std::vector<long long> pr((size_t)n * 16);
+        hipMemcpy(pr.data(), a.prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost);
+        std::vector<int> idx((size_t)n); for (int i = 0; i < n; ++i) idx[i] = i;
+        auto tot = [&](int r) { long long t = 0; for (int k = 0; k < 6; ++k) t += pr[(size_t)r * 16 + k]; return t; };
+        std::sort(idx.begin(), idx.end(), [&](int x, int y) { return tot(x) > tot(y); });
+        long long sum[16] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 16; ++k) sum[k] += pr[(size_t)r * 16 + k];
+        fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
+        fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles)\n");
+        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 16 + k] / 1000000); fprintf(stderr, " | %lld %lld\n", pr[(size_t)r * 16 + 14], pr[(size_t)r * 16 + 15]); }
+    }
+#endif
     return LAMSA_HP_OK;
 }
 

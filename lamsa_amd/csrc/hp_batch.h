@@ -58,6 +58,7 @@ struct AlignArgs {
     int32_t *counter;            // dynamic read queue head
     const int32_t *order;        // processing order (costliest first) / retry list, or nullptr
     int32_t n_units;             // number of entries to process (n_reads, or the length of the retry list)
+    long long *prof;             // diagnostic build (-DHP_PROF): per-read phase cycle sums, 16 per read; else nullptr
     int32_t scale;               // multiplier of the per-read output / CIGAR capacities (1; larger in the retry pass)
 };
 

@@ -64,6 +64,7 @@ struct ReadCtx {
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
     int8_t *n_dp_flag; uint8_t *n_match_flag, *n_son_flag;
     NodeS *ns;                  // packed static record per hit
+    long long *prof;            // diagnostic build only
 };
 
 HP_INL int hoff(const ReadCtx &r, int x) { return (int)(r.hit_off[x] - r.hb); }
@@ -156,6 +157,36 @@ HP_INL int edge_flag_packed(const EdgeK &k, const NodeS &pre, const NodeS &cur)
     if (dis > mat_dis && dis < k.sv_len) return F_DELETE;
     if ((dis < -mat_dis && dis >= 0 - (did * k.seed_step - k.seed_len)) || (dis < -k.half_split && dis >= -k.sv_len)) return F_INSERT;
     return F_UNCONNECT;
+}
+
+// frag_dp_per_init over a whole range of nodes, one node per lane.
+// which == 0: nodes whose dp_flag is +-dp_flag (frag_mini_dp_line, :1086-1091); which == 1: every node that is not TRACKED (:946-951)
+HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, int which)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+    const EdgeK K = edge_consts(r.cx.P);
+    NodeS F; F.pos = 0; F.chr = 0; F.slot_j = 0; F.sid = 0; F.strand = 0; F.len_dif8 = 0; F.pad_ = 0;
+    int from_nm = 0;
+    if (from >= 0) { F = node_load(ns + from); from_nm = r.h_nm[from]; }
+    for (int b = k0; b < k1; b += 64) {
+        WAVE_FOR(l) {
+            const int k = b + l;
+            if (k < k1) {
+                const int df = r.n_dp_flag[k];
+                const bool take = which == 0 ? (df == dp_flag || df == 0 - dp_flag) : (df != TRACKED_FLAG);
+                if (take) {
+                    if (from < 0) node_set(r, k, from, 1, r.h_nm[k], F_MATCH, dp_flag);
+                    else {
+                        const NodeS Q = node_load(ns + k);
+                        const int flag = k == from ? F_MATCH : edge_flag_packed(K, F, Q);
+                        if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, k, from, 2 + score_table(flag), r.h_nm[k] + from_nm, flag, dp_flag);
+                        else r.n_dp_flag[k] = (int8_t)(0 - dp_flag);
+                    }
+                }
+            }
+        }
+    }
+    wv::sync();
 }
 
 // ---------------------------------------------------------------- frag_dp_update, :701-764
@@ -443,21 +474,37 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
     else { old_score = 2 + score_table(r.n_match_flag[right]); old_NM = left_NM + r.h_nm[right]; }
     const int dp_flag = MULTI_FLAG;
-    for (int k = hoff(r, left_x + 1), e = hoff(r, right_x); k < e; ++k)
-        if (r.n_dp_flag[k] == dp_flag || r.n_dp_flag[k] == 0 - dp_flag) node_per_init(r, k, head, dp_flag);
-    wv::sync();
+    nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0);
     for (int k = hoff(r, left_x + 2), e = hoff(r, right_x); k < e; ++k)      // callers guarantee left_x + 2 <= right_x
         if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, left_x + 1, dp_flag);
     int max_score, max_NM = 0, max_n = 0, max_node = head;
     if (_tail == 0) {
+        // best end node: score desc, NM asc, then the reference's scan order (seeds descending, hits ascending), :1105-1123
         max_score = old_score;
-        for (int i = right_x - 1; i > left_x; --i)
-            for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k) {
-                if (r.n_dp_flag[k] != dp_flag) continue;
-                if (r.n_score[k] > max_score || (r.n_score[k] == max_score && r.n_NM[k] < max_NM)) {
-                    max_score = r.n_score[k]; max_NM = r.n_NM[k]; max_node = k; max_n = r.n_node_n[k];
+        const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+        const int k0 = hoff(r, left_x + 1), k1 = hoff(r, right_x);
+        wv::Lane<long long> key;
+        WAVE_FOR(l) { key[l] = -1; }
+        for (int b = k0; b < k1; b += 64) {
+            WAVE_FOR(l) {
+                const int k = b + l;
+                if (k < k1 && r.n_dp_flag[k] == dp_flag) {
+                    const int sj = ns[k].slot_j;
+                    const int pos = ((right_x - 1 - (sj >> 14)) << 14) | (sj & 16383);
+                    const long long kk = ((long long)(r.n_score[k] + 32768) << 47) | ((long long)(524287 - r.n_NM[k]) << 28) | (long long)(((1 << 28) - 1) - pos);
+                    key[l] = kk > key[l] ? kk : key[l];
                 }
             }
+        }
+        const long long bk = wv::reduce_max64(key);
+        if (bk >= 0) {
+            const int pos = ((1 << 28) - 1) - (int)(bk & ((1 << 28) - 1));
+            const int nm = 524287 - (int)((bk >> 28) & 524287), sc = (int)(bk >> 47) - 32768;
+            if (sc > max_score || (sc == max_score && nm < max_NM)) {
+                const int k = hoff(r, right_x - 1 - (pos >> 14)) + (pos & 16383);
+                max_score = sc; max_NM = nm; max_node = k; max_n = r.n_node_n[k];
+            }
+        }
     } else {
         r.n_from[right] = head; r.n_score[right] = old_score; r.n_NM[right] = old_NM; r.n_node_n[right] = 1;
         wv::sync();
@@ -734,8 +781,17 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
 }
 
 // ---------------------------------------------------------------- round 1: frag_line_BCC, :1305-1445
+#ifdef HP_PROF
+#define HP_CSTAMP(k) do { const long long now_ = wv::clock(); if (r.prof) r.prof[(k)] += now_ - tc_; tc_ = now_; } while (0)
+#else
+#define HP_CSTAMP(k) do { } while (0)
+#endif
+
 HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
 {
+#ifdef HP_PROF
+    long long tc_ = wv::clock();
+#endif
     const lamsa_hp_para *P = r.cx.P;
     const int seed_out = r.seed_out, H = r.H;
     F.n = 0; F.nfrag = 0;
@@ -756,9 +812,11 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
             for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k) min_extend(r, k, min_n);
         }
     }
+    HP_CSTAMP(6);
     for (int k = seed_out > 1 ? hoff(r, 1) : H; k < H; ++k)                                       // main pass, :1345-1350
         if (r.n_dp_flag[k] == MIN_FLAG) dp_update(r, k, 0, MIN_FLAG);
 
+    HP_CSTAMP(7);
     NScore ns;
     if (!ns_alloc(r.cx, ns, H + 1, 0)) return false;
     ns.min_score_thd = 2;
@@ -766,6 +824,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
         for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
             if (r.n_dp_flag[k] == MIN_FLAG && r.n_in_de[k] == 0) branch_track(r, k, ns);
 
+    HP_CSTAMP(8);
     const int o_l = ns.node_n;
     LSet L;
     Trig T;
@@ -823,8 +882,12 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     }
 #undef HP_TRIG_PUSH
     L.n = l_i;
+    HP_CSTAMP(9);
     const int line_n = set_bound(r, L, 0, l_i, &T);                   // :1435
-    return build_flines(r, L, line_n, F);
+    const bool okf = build_flines(r, L, line_n, F);
+    HP_CSTAMP(10);
+    if (r.prof) { r.prof[14] = o_l; r.prof[15] = H; }
+    return okf;
 }
 
 // ---------------------------------------------------------------- uncovered regions of the read (aln_reg / get_remain_reg)
@@ -842,9 +905,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
     if (left_b + 1 >= right_b) return 0;
     const lamsa_hp_para *P = r.cx.P;
     const int start = left_b + 1, end = right_b - 1, dp_flag = WHOLE_FLAG;
-    for (int k = hoff(r, start), e = hoff(r, end + 1); k < e; ++k)
-        if (r.n_dp_flag[k] != TRACKED_FLAG) node_per_init(r, k, -1, dp_flag);
-    wv::sync();
+    nodes_per_init(r, hoff(r, start), hoff(r, end + 1), -1, dp_flag, 1);
     for (int k = start + 1 <= end ? hoff(r, start + 1) : hoff(r, end + 1), e = hoff(r, end + 1); k < e; ++k)
         if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, start, dp_flag);
     const size_t mark = arena_mark(r.cx.tmp);

@@ -29,6 +29,7 @@ template <class T> struct Lane {
 
 HP_INL void sync() {}
 HP_INL bool leader() { return true; }
+HP_INL long long clock() { return 0; }
 HP_INL int uni(int v) { return v; }
 HP_INL long long uni64(long long v) { return v; }
 HP_INL int bcast(const Lane<int> &x, int src) { return x.v[src]; }
