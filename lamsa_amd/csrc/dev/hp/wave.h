@@ -59,32 +59,50 @@ HP_INL int bcast(const Lane<int> &x, int src) { return __builtin_amdgcn_readlane
 
 HP_INL unsigned long long ballot(const Lane<int> &p) { return __ballot(p.v != 0); }
 
+// Cross-lane reductions and the prefix scan use DPP row operations (no LDS round trip):
+//   quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140,
+//   row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shr:1 = 0x138  (GFX9 DPP controls)
+template <int CTRL, int ROW_MASK = 0xf>
+HP_INL int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+
 HP_INL int reduce_max(const Lane<int> &x) {
-    int v = x.v;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-    return uni(v);
+    int v = x.v, o;
+    o = dpp<0xB1>(v, v); v = o > v ? o : v;
+    o = dpp<0x4E>(v, v); v = o > v ? o : v;
+    o = dpp<0x141>(v, v); v = o > v ? o : v;
+    o = dpp<0x140>(v, v); v = o > v ? o : v;          // every lane of a 16-lane row now holds the row maximum
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 HP_INL int reduce_sum(const Lane<int> &x) {
     int v = x.v;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return uni(v);
+    v += dpp<0xB1>(v, v); v += dpp<0x4E>(v, v); v += dpp<0x141>(v, v); v += dpp<0x140>(v, v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 HP_INL long long reduce_max64(const Lane<long long> &x) {
-    long long v = x.v;
+    int hi = (int)(x.v >> 32); unsigned lo = (unsigned)(x.v & 0xffffffffll);
+#define HP_STEP64(C) { int oh = dpp<C>(hi, hi); unsigned ol = (unsigned)dpp<C>((int)lo, (int)lo); const bool g = oh > hi || (oh == hi && ol > lo); hi = g ? oh : hi; lo = g ? ol : lo; }
+    HP_STEP64(0xB1) HP_STEP64(0x4E) HP_STEP64(0x141) HP_STEP64(0x140)
+#undef HP_STEP64
+    long long best = ((long long)__builtin_amdgcn_readlane(hi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 0);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-    return uni64(v);
+    for (int r = 16; r < 64; r += 16) {
+        const long long c = ((long long)__builtin_amdgcn_readlane(hi, r) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, r);
+        best = c > best ? c : best;
+    }
+    return best;
 }
-// exclusive prefix max over lanes; lane 0 receives `ident`
+// exclusive prefix max over lanes; lane 0 receives `ident` (which must be <= every input)
 HP_INL void scan_max_excl(Lane<int> &x, int ident) {
-    int v = x.v;
-    const int l = lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d, 64); if (l >= d) v = o > v ? o : v; }
-    int e = __shfl_up(v, 1, 64);
-    x.v = l == 0 ? ident : e;
+    int v = x.v, o;
+    o = dpp<0x111>(ident, v); v = o > v ? o : v;      // Hillis-Steele inside each 16-lane row
+    o = dpp<0x112>(ident, v); v = o > v ? o : v;
+    o = dpp<0x114>(ident, v); v = o > v ? o : v;
+    o = dpp<0x118>(ident, v); v = o > v ? o : v;
+    o = dpp<0x142, 0xA>(ident, v); v = o > v ? o : v; // row 0 -> row 1, row 2 -> row 3
+    o = dpp<0x143, 0xC>(ident, v); v = o > v ? o : v; // rows 0-1 -> rows 2,3
+    x.v = dpp<0x138>(ident, v);                        // shift the inclusive scan right by one lane
 }
 
 }  // namespace wv

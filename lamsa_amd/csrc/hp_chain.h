@@ -189,83 +189,113 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
     wv::sync();
 }
 
-// ---------------------------------------------------------------- frag_dp_update, :701-764
-HP_NOINL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag)
+// ---------------------------------------------------------------- frag_dp_update, :701-764, over a range of targets
+// Targets k0..k1-1 are updated strictly in order (the son_flag side effect of a chosen predecessor is visible to
+// the next target).  `force`: update node k0 whatever its dp_flag (the right anchor of a mini-DP, :1129); otherwise
+// only nodes whose dp_flag equals `dp_flag`.  Per target: one load trip for its own record, the predecessor scan
+// (256 predecessors per trip, per-lane running best), two DPP reductions, one trip for the winner, the stores.
+HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force)
 {
-    // everything the scan touches, as global-address-space pointers held in registers
     const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
-    const HP_G int32_t *g_score = (const HP_G int32_t *)r.n_score, *g_NM = (const HP_G int32_t *)r.n_NM;
-    const HP_G int8_t *g_dp = (const HP_G int8_t *)r.n_dp_flag;
-    const HP_G uint8_t *g_son = (const HP_G uint8_t *)r.n_son_flag;
+    HP_G int32_t *g_score = (HP_G int32_t *)r.n_score, *g_NM = (HP_G int32_t *)r.n_NM, *g_from = (HP_G int32_t *)r.n_from;
+    HP_G int32_t *g_node_n = (HP_G int32_t *)r.n_node_n, *g_in_de = (HP_G int32_t *)r.n_in_de, *g_son_n = (HP_G int32_t *)r.n_son_n;
+    HP_G int32_t *g_first = (HP_G int32_t *)r.n_first, *g_last = (HP_G int32_t *)r.n_last, *g_next = (HP_G int32_t *)r.n_next;
+    HP_G int8_t *g_dp = (HP_G int8_t *)r.n_dp_flag;
+    HP_G uint8_t *g_son = (HP_G uint8_t *)r.n_son_flag, *g_mf = (HP_G uint8_t *)r.n_match_flag;
+    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+    const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
-    const NodeS T = node_load(ns + t);
-    const int x = T.slot_j >> 14;
-    const int lo = hoff(r, start_slot), hi = hoff(r, x);
-    const int t_NM = r.n_NM[t];
-    int max_from = r.n_from[t], max_score = r.n_score[t], max_NM = t_NM, max_flag = r.n_dp_flag[t];
-    long long best_key = -1;          // (cand+32768) << 47 | (524287-NM) << 28 | (POSMAX-pos)
-    int neg_pos = 0x7fffffff;         // scan position of the first '-' strand match precursor
+    const int lo = (int)(g_hoff[start_slot] - hb);
     const int POSMAX = (1 << 28) - 1;
-    // Every lane keeps its own running best over the chunks it sees; the two wave reductions happen once per
-    // target, not once per chunk.  The per-lane body is written without short-circuit conditions so that all
-    // five loads of a predecessor are issued back to back (one memory round trip per chunk, not five).
-    wv::Lane<long long> key;
-    wv::Lane<int> negp;
-    WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
-    for (int base = hi - 1; base >= lo; base -= 64) {
-        wv::Lane<int> anyneg;
-        WAVE_FOR(l) {
-            const int p = base - l;
-            const int inr = p >= lo;
-            const int pc = inr ? p : lo;                         // clamped: always a valid node of this read
-            const NodeS Q = node_load(ns + pc);
-            const int dflag = g_dp[pc], sflag = g_son[pc], pscore = g_score[pc], pnm = g_NM[pc];
-            const int flag = edge_flag_packed(K, Q, T);
-            const int ok = inr & (dflag == dp_flag) & !((Q.strand == 1) & (sflag <= F_MATCH_THD)) & (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
-            const int pos = ((x - 1 - (Q.slot_j >> 14)) << 14) | (Q.slot_j & 16383);        // scan order: seeds descending, hits ascending
-            const int cand = pscore + 1 + score_table(flag);
-            const int nm = pnm + t_NM;
-            const int isneg = ok & (Q.strand == -1) & (flag <= F_MATCH_THD);                 // '-': first match precursor wins, :726-733
-            const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
-            const long long kk = ok ? k : -1;
-            key[l] = kk > key[l] ? kk : key[l];
-            const int np = isneg ? -pos : -0x7fffffff;
-            negp[l] = np > negp[l] ? np : negp[l];
-            anyneg[l] = isneg;
+    for (int tb = k0; tb < k1; tb += 64) {
+        unsigned long long todo;
+        if (force) todo = 1ull;
+        else { wv::Lane<int> c; WAVE_FOR(l) { const int k = tb + l; c[l] = (k < k1 && g_dp[k] == dp_flag); } todo = wv::ballot(c); }
+        while (todo) {
+            const int t = tb + __builtin_ctzll(todo); todo &= todo - 1;
+            const NodeS T = node_load(ns + t);
+            const int x = T.slot_j >> 14;
+            const int hi = (int)(g_hoff[x] - hb);
+            const int t_NM = g_NM[t], t_from = g_from[t], t_score = g_score[t];
+            wv::Lane<long long> key;
+            wv::Lane<int> negp;
+            WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
+            int neg_pos = 0x7fffffff;                    // scan position of the first '-' strand match precursor
+            for (int base = hi - 1; base >= lo; base -= 256) {
+                wv::Lane<int> anyneg;
+                WAVE_FOR(l) {
+                    NodeS Q[4]; int dflag[4], sflag[4], pscore[4], pnm[4], inr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = base - u * 64 - l;
+                        inr[u] = p >= lo;
+                        const int pc = inr[u] ? p : lo;          // clamped: always a valid node of this read
+                        Q[u] = node_load(ns + pc);
+                        dflag[u] = g_dp[pc]; sflag[u] = g_son[pc]; pscore[u] = g_score[pc]; pnm[u] = g_NM[pc];
+                    }
+                    int an = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int flag = edge_flag_packed(K, Q[u], T);
+                        const int ok = inr[u] & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) & (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
+                        const int pos = ((x - 1 - (Q[u].slot_j >> 14)) << 14) | (Q[u].slot_j & 16383);      // scan order: seeds descending, hits ascending
+                        const int cand = pscore[u] + 1 + score_table(flag);
+                        const int nm = pnm[u] + t_NM;
+                        const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);                   // '-': first match precursor wins, :726-733
+                        const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+                        const long long kk = ok ? k : -1;
+                        key[l] = kk > key[l] ? kk : key[l];
+                        const int np = isneg ? -pos : -0x7fffffff;
+                        negp[l] = np > negp[l] ? np : negp[l];
+                        an |= isneg;
+                    }
+                    anyneg[l] = an;
+                }
+                if (wv::ballot(anyneg) != 0) {                   // rare: may the scan stop early?
+                    const int np = -wv::reduce_max(negp);
+                    if (np < neg_pos) neg_pos = np;
+                    if (base - 256 >= lo && (int)(ns[base - 256].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
+                }
+            }
+            int max_from = t_from, max_score = t_score, max_NM = t_NM, max_flag = 0;
+            bool changed = false;
+            if (hi > lo) {
+                const int np = -wv::reduce_max(negp);
+                if (np < neg_pos) neg_pos = np;
+                const long long best_key = wv::reduce_max64(key);
+                if (neg_pos != 0x7fffffff) {
+                    const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = (int)(g_hoff[i] - hb) + j;
+                    const NodeS Q = node_load(ns + p);
+                    const int flag = edge_flag_packed(K, Q, T);
+                    max_from = p; max_score = g_score[p] + 1 + score_table(flag); max_flag = flag; max_NM = g_NM[p] + t_NM;
+                    changed = max_from != t_from;
+                } else if (best_key >= 0) {
+                    const int pos = POSMAX - (int)(best_key & POSMAX);
+                    const int nm = 524287 - (int)((best_key >> 28) & 524287);
+                    const int cand = (int)(best_key >> 47) - 32768;
+                    if (cand > max_score || (cand == max_score && nm < max_NM)) {
+                        const int i = x - 1 - (pos >> 14), j = pos & 16383, p = (int)(g_hoff[i] - hb) + j;
+                        const NodeS Q = node_load(ns + p);
+                        max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag_packed(K, Q, T);
+                        changed = max_from != t_from;
+                    }
+                }
+            }
+            if (changed) {                               // wave-uniform stores (:753-761); every lane re-reads only what it wrote itself
+                g_son[max_from] = (uint8_t)max_flag;
+                g_from[t] = max_from; g_score[t] = max_score; g_NM[t] = max_NM; g_mf[t] = (uint8_t)max_flag;
+                g_node_n[t] = g_node_n[max_from] + 1;
+                const int sn = g_son_n[max_from], la = g_last[max_from];      // fnode_add_son, :683
+                g_in_de[max_from] = g_in_de[max_from] + 1;
+                g_next[t] = -1;
+                if (sn == 0) g_first[max_from] = t; else g_next[la] = t;
+                g_last[max_from] = t;
+                g_son_n[max_from] = sn + 1;
+            }
         }
-        if (wv::ballot(anyneg) != 0) {                           // rare: decide whether the scan may stop early
-            const int np = -wv::reduce_max(negp);
-            if (np < neg_pos) neg_pos = np;
-            if (base - 64 >= lo && (int)(ns[base - 64].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;    // nothing earlier in scan order is left
-        }
-    }
-    {
-        const int np = -wv::reduce_max(negp);
-        if (np < neg_pos) neg_pos = np;
-        best_key = wv::reduce_max64(key);
-    }
-    if (neg_pos != 0x7fffffff) {
-        const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = hoff(r, i) + j;
-        const NodeS Q = node_load(ns + p);
-        const int flag = edge_flag_packed(K, Q, T);
-        max_from = p; max_score = r.n_score[p] + 1 + score_table(flag); max_flag = flag; max_NM = r.n_NM[p] + t_NM;
-    } else if (best_key >= 0) {
-        const int pos = POSMAX - (int)(best_key & POSMAX);
-        const int nm = 524287 - (int)((best_key >> 28) & 524287);
-        const int cand = (int)(best_key >> 47) - 32768;
-        if (cand > max_score || (cand == max_score && nm < max_NM)) {
-            const int i = x - 1 - (pos >> 14), j = pos & 16383, p = hoff(r, i) + j;
-            const NodeS Q = node_load(ns + p);
-            max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag_packed(K, Q, T);
-        }
-    }
-    if (max_from != r.n_from[t]) {           // wave-uniform stores: every lane writes (and later re-reads) the same words itself
-        r.n_son_flag[max_from] = (uint8_t)max_flag;
-        r.n_from[t] = max_from; r.n_score[t] = max_score; r.n_NM[t] = max_NM; r.n_match_flag[t] = (uint8_t)max_flag;
-        r.n_node_n[t] = r.n_node_n[max_from] + 1;
-        add_son(r, max_from, t);
     }
 }
+HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true); }
 
 // ---------------------------------------------------------------- frag_min_extend for one MIN hit, :1031-1066
 // For every seed with more than min_n hits, the first hit (ascending) that is match-class
@@ -475,8 +505,7 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     else { old_score = 2 + score_table(r.n_match_flag[right]); old_NM = left_NM + r.h_nm[right]; }
     const int dp_flag = MULTI_FLAG;
     nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0);
-    for (int k = hoff(r, left_x + 2), e = hoff(r, right_x); k < e; ++k)      // callers guarantee left_x + 2 <= right_x
-        if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, left_x + 1, dp_flag);
+    dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false);      // callers guarantee left_x + 2 <= right_x
     int max_score, max_NM = 0, max_n = 0, max_node = head;
     if (_tail == 0) {
         // best end node: score desc, NM asc, then the reference's scan order (seeds descending, hits ascending), :1105-1123
@@ -813,8 +842,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
         }
     }
     HP_CSTAMP(6);
-    for (int k = seed_out > 1 ? hoff(r, 1) : H; k < H; ++k)                                       // main pass, :1345-1350
-        if (r.n_dp_flag[k] == MIN_FLAG) dp_update(r, k, 0, MIN_FLAG);
+    if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false);                      // main pass, :1345-1350
 
     HP_CSTAMP(7);
     NScore ns;
@@ -906,8 +934,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
     const lamsa_hp_para *P = r.cx.P;
     const int start = left_b + 1, end = right_b - 1, dp_flag = WHOLE_FLAG;
     nodes_per_init(r, hoff(r, start), hoff(r, end + 1), -1, dp_flag, 1);
-    for (int k = start + 1 <= end ? hoff(r, start + 1) : hoff(r, end + 1), e = hoff(r, end + 1); k < e; ++k)
-        if (r.n_dp_flag[k] == dp_flag) dp_update(r, k, start, dp_flag);
+    if (start + 1 <= end) dp_update_range(r, hoff(r, start + 1), hoff(r, end + 1), start, dp_flag, false);
     const size_t mark = arena_mark(r.cx.tmp);
     NScore ns;
     if (!ns_alloc(r.cx, ns, hoff(r, end + 1) - hoff(r, start) + 1, 0)) return 0;
