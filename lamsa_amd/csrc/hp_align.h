@@ -121,6 +121,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     r.hb = r.hit_off[0];
     r.H = (int)(r.hit_off[r.seed_out] - r.hb);
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
+    r.srt = in.h_sort + r.hb; r.rnk = in.h_rank + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
     r.prof = a.prof ? a.prof + (size_t)rd * 16 : nullptr;

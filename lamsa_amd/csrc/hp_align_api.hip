@@ -8,6 +8,7 @@
 #include <map>
 #include "hp_align.h"
 #include "hp_handle.h"
+#include "hp_hostprep.h"
 
 using namespace hp;
 
@@ -119,7 +120,10 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     const size_t o_roff = place(8 * ((size_t)n + 1)), o_rseq = place((size_t)n_bases), o_sall = place(4 * (size_t)n), o_last = place(4 * (size_t)n),
                  o_soff = place(8 * ((size_t)n + 1)), o_sid = place(4 * (size_t)n_slots), o_hoff = place(8 * ((size_t)n_slots + 1)),
                  o_pos = place(8 * (size_t)n_hits), o_chr = place(4 * (size_t)n_hits), o_coff = place(4 * (size_t)n_hits), o_nm = place(2 * (size_t)n_hits),
-                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n);
+                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n),
+                 o_srt = place(4 * (size_t)n_hits), o_rnk = place(4 * (size_t)n_hits);
+    std::vector<int32_t> srt, rnk;
+    hp_build_sort_index(n, B->seed_off, B->hit_off, B->h_pos, B->h_chr, B->h_strand, srt, rnk);
     if (S->bin.ensure(off)) { h->err = "hipMalloc(batch)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)S->bin.p;
     hipStream_t s = h->stream;
@@ -133,6 +137,7 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     UP(o_pos, B->h_pos, 8 * (size_t)n_hits); UP(o_chr, B->h_chr, 4 * (size_t)n_hits); UP(o_coff, B->h_cig_off, 4 * (size_t)n_hits);
     UP(o_nm, B->h_nm, 2 * (size_t)n_hits); UP(o_ld, B->h_len_dif, 2 * (size_t)n_hits); UP(o_st, B->h_strand, (size_t)n_hits); UP(o_cn, B->h_cig_n, (size_t)n_hits);
     UP(o_cig, B->cig, 4 * (size_t)B->n_cig); UP(o_ord, S->order.data(), 4 * (size_t)n);
+    UP(o_srt, srt.data(), 4 * (size_t)n_hits); UP(o_rnk, rnk.data(), 4 * (size_t)n_hits);
 #undef UP
     HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
     BatchIn &in = S->in;
@@ -142,6 +147,7 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     in.h_chr = (const int32_t *)(d + o_chr); in.h_cig_off = (const int32_t *)(d + o_coff); in.h_nm = (const int16_t *)(d + o_nm);
     in.h_len_dif = (const int16_t *)(d + o_ld); in.h_strand = (const int8_t *)(d + o_st); in.h_cig_n = (const uint8_t *)(d + o_cn);
     in.cig = (const int32_t *)(d + o_cig);
+    in.h_sort = (const int32_t *)(d + o_srt); in.h_rank = (const int32_t *)(d + o_rnk);
     S->d_order = (const int32_t *)(d + o_ord);
     S->n_reads = n; S->n_bases = n_bases; S->n_cig = B->n_cig;
     S->valid = true;
@@ -188,8 +194,8 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
         std::sort(idx.begin(), idx.end(), [&](int x, int y) { return tot(x) > tot(y); });
         long long sum[16] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 16; ++k) sum[k] += pr[(size_t)r * 16 + k];
         fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
-        fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles)\n");
-        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 16 + k] / 1000000); fprintf(stderr, " | %lld %lld\n", pr[(size_t)r * 16 + 14], pr[(size_t)r * 16 + 15]); }
+        fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles) targets %lld trips %lld init_Mcyc %lld\n", sum[11], sum[12], sum[13] / 1000000);
+        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 16 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 16 + 14], pr[(size_t)r * 16 + 15], pr[(size_t)r * 16 + 11], pr[(size_t)r * 16 + 12], pr[(size_t)r * 16 + 13] / 1000000); }
     }
 #endif
     return LAMSA_HP_OK;

@@ -33,6 +33,8 @@ struct BatchIn {
     const int8_t  *h_strand;     // +1 / -1
     const uint8_t *h_cig_n;
     const int32_t *cig;          // seed CIGAR words
+    const int32_t *h_sort;       // [n_hits] per read: local hit indices sorted by (contig, strand, position)  (hp_hostprep.h)
+    const int32_t *h_rank;       // [n_hits] inverse permutation
 };
 
 // Result stream of one read (int32 words), serialised by the wave that aligned it:

@@ -64,6 +64,7 @@ struct ReadCtx {
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
     int8_t *n_dp_flag; uint8_t *n_match_flag, *n_son_flag;
     NodeS *ns;                  // packed static record per hit
+    const int32_t *srt, *rnk;   // hits sorted by (contig, strand, position) and the inverse permutation (local indices)
     long long *prof;            // diagnostic build only
 };
 
@@ -163,6 +164,9 @@ HP_INL int edge_flag_packed(const EdgeK &k, const NodeS &pre, const NodeS &cur)
 // which == 0: nodes whose dp_flag is +-dp_flag (frag_mini_dp_line, :1086-1091); which == 1: every node that is not TRACKED (:946-951)
 HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, int which)
 {
+#ifdef HP_PROF
+    const long long t0_ = wv::clock();
+#endif
     const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
     const EdgeK K = edge_consts(r.cx.P);
     NodeS F; F.pos = 0; F.chr = 0; F.slot_j = 0; F.sid = 0; F.strand = 0; F.len_dif8 = 0; F.pad_ = 0;
@@ -187,6 +191,9 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
         }
     }
     wv::sync();
+#ifdef HP_PROF
+    if (r.prof) r.prof[13] += wv::clock() - t0_;
+#endif
 }
 
 // ---------------------------------------------------------------- frag_dp_update, :701-764, over a range of targets
@@ -207,12 +214,17 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     const EdgeK K = edge_consts(r.cx.P);
     const int lo = (int)(g_hoff[start_slot] - hb);
     const int POSMAX = (1 << 28) - 1;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
+    const int sid_lo = start_slot < r.seed_out ? r.seed_id[start_slot] : 0;
     for (int tb = k0; tb < k1; tb += 64) {
         unsigned long long todo;
         if (force) todo = 1ull;
         else { wv::Lane<int> c; WAVE_FOR(l) { const int k = tb + l; c[l] = (k < k1 && g_dp[k] == dp_flag); } todo = wv::ballot(c); }
         while (todo) {
             const int t = tb + __builtin_ctzll(todo); todo &= todo - 1;
+#ifdef HP_PROF
+            if (r.prof) r.prof[11] += 1;
+#endif
             const NodeS T = node_load(ns + t);
             const int x = T.slot_j >> 14;
             const int hi = (int)(g_hoff[x] - hb);
@@ -221,40 +233,62 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             wv::Lane<int> negp;
             WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
             int neg_pos = 0x7fffffff;                    // scan position of the first '-' strand match precursor
-            for (int base = hi - 1; base >= lo; base -= 256) {
-                wv::Lane<int> anyneg;
-                WAVE_FOR(l) {
-                    NodeS Q[4]; int dflag[4], sflag[4], pscore[4], pnm[4], inr[4];
+            // Predecessors that get_fseed_dis can connect at all lie on the same contig and strand within R bases of
+            // the target (|dis| < max(SV_len_thd, did*step, mat_dis) and |act-exp| <= |dis|+|len_dif|, exp within
+            // did*step of the predecessor).  In the (contig, strand, position) order they are the neighbours of the
+            // target itself, so the scan walks outwards from the target's rank, 128 hits per trip and direction,
+            // and stops at the first hit outside the window.  Everything else is F_CHR_DIF / F_UNCONNECT for the
+            // reference too, hence the result is unchanged.
+            const int did_max = T.sid - sid_lo;
+            const int mdm = K.match_dis * (K.high_err ? did_max : 1);
+            long long Rw = K.sv_len > did_max * K.seed_step ? K.sv_len : did_max * K.seed_step;
+            if (mdm + 1 > Rw) Rw = mdm + 1;
+            Rw += 128 + (long long)did_max * K.seed_step;
+            const int rT = g_rnk[t];
+            const int tkey = T.chr * 2 + (T.strand > 0 ? 1 : 0);
+            for (int dir = -1; dir <= 1 && hi > lo; dir += 2) {
+                for (int c = 0;; ++c) {
+#ifdef HP_PROF
+                    if (r.prof) r.prof[12] += 1;
+#endif
+                    wv::Lane<int> outw;
+                    WAVE_FOR(l) {
+                        int idx[2], inb[2], pn[2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int p = base - u * 64 - l;
-                        inr[u] = p >= lo;
-                        const int pc = inr[u] ? p : lo;          // clamped: always a valid node of this read
-                        Q[u] = node_load(ns + pc);
-                        dflag[u] = g_dp[pc]; sflag[u] = g_son[pc]; pscore[u] = g_score[pc]; pnm[u] = g_NM[pc];
-                    }
-                    int an = 0;
+                        for (int u = 0; u < 2; ++u) {
+                            idx[u] = rT + dir * (1 + c * 128 + u * 64 + l);
+                            inb[u] = idx[u] >= 0 && idx[u] < r.H;
+                            pn[u] = g_srt[inb[u] ? idx[u] : rT];
+                        }
+                        NodeS Q[2]; int dflag[2], sflag[2], pscore[2], pnm[2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int flag = edge_flag_packed(K, Q[u], T);
-                        const int ok = inr[u] & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) & (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
-                        const int pos = ((x - 1 - (Q[u].slot_j >> 14)) << 14) | (Q[u].slot_j & 16383);      // scan order: seeds descending, hits ascending
-                        const int cand = pscore[u] + 1 + score_table(flag);
-                        const int nm = pnm[u] + t_NM;
-                        const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);                   // '-': first match precursor wins, :726-733
-                        const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
-                        const long long kk = ok ? k : -1;
-                        key[l] = kk > key[l] ? kk : key[l];
-                        const int np = isneg ? -pos : -0x7fffffff;
-                        negp[l] = np > negp[l] ? np : negp[l];
-                        an |= isneg;
+                        for (int u = 0; u < 2; ++u) {
+                            Q[u] = node_load(ns + pn[u]);
+                            dflag[u] = g_dp[pn[u]]; sflag[u] = g_son[pn[u]]; pscore[u] = g_score[pn[u]]; pnm[u] = g_NM[pn[u]];
+                        }
+                        int ow = 0;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            long long dp = Q[u].pos - T.pos; if (dp < 0) dp = -dp;
+                            const int inwin = inb[u] & ((Q[u].chr * 2 + (Q[u].strand > 0 ? 1 : 0)) == tkey) & (dp <= Rw);
+                            ow |= !inwin;
+                            const int qslot = Q[u].slot_j >> 14;
+                            const int flag = edge_flag_packed(K, Q[u], T);
+                            const int ok = inwin & (qslot >= start_slot) & (qslot < x) & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) &
+                                           (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
+                            const int pos = ((x - 1 - qslot) << 14) | (Q[u].slot_j & 16383);            // scan order: seeds descending, hits ascending
+                            const int cand = pscore[u] + 1 + score_table(flag);
+                            const int nm = pnm[u] + t_NM;
+                            const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733
+                            const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+                            const long long kk = ok ? k : -1;
+                            key[l] = kk > key[l] ? kk : key[l];
+                            const int np = isneg ? -pos : -0x7fffffff;
+                            negp[l] = np > negp[l] ? np : negp[l];
+                        }
+                        outw[l] = ow;
                     }
-                    anyneg[l] = an;
-                }
-                if (wv::ballot(anyneg) != 0) {                   // rare: may the scan stop early?
-                    const int np = -wv::reduce_max(negp);
-                    if (np < neg_pos) neg_pos = np;
-                    if (base - 256 >= lo && (int)(ns[base - 256].slot_j >> 14) < x - 1 - (neg_pos >> 14)) break;   // nothing earlier in scan order is left
+                    if (wv::ballot(outw) != 0) break;            // sorted order: once a hit is outside the window, all farther ones are
                 }
             }
             int max_from = t_from, max_score = t_score, max_NM = t_NM, max_flag = 0;

@@ -26,6 +26,7 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
 
 // ---------------------------------------------------------------- whole per-read path, emulated
 #include "hp_align.h"
+#include "hp_hostprep.h"
 
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
                                int32_t *stream, int64_t stream_cap, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status)
@@ -36,6 +37,9 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.in.n_reads = B->n_reads; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
     a.in.seed_off = B->seed_off; a.in.seed_id = B->seed_id; a.in.hit_off = B->hit_off; a.in.h_pos = B->h_pos; a.in.h_chr = B->h_chr;
     a.in.h_cig_off = B->h_cig_off; a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig;
+    std::vector<int32_t> srt, rnk;
+    hp_build_sort_index(B->n_reads, B->seed_off, B->hit_off, B->h_pos, B->h_chr, B->h_strand, srt, rnk);
+    a.in.h_sort = srt.data(); a.in.h_rank = rnk.data();
     unsigned long long cursor = 0;
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;
