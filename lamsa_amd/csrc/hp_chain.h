@@ -219,7 +219,35 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     for (int tb = k0; tb < k1; tb += 64) {
         unsigned long long todo;
         if (force) todo = 1ull;
-        else { wv::Lane<int> c; WAVE_FOR(l) { const int k = tb + l; c[l] = (k < k1 && g_dp[k] == dp_flag); } todo = wv::ballot(c); }
+        else {
+            // one target per lane: is it due in this pass, and does it have any neighbour (in sorted order) inside its
+            // window?  A target without one has no connectable predecessor at all and keeps its state (exact skip).
+            wv::Lane<int> c;
+            WAVE_FOR(l) {
+                const int k = tb + l;
+                int due = 0;
+                if (k < k1 && g_dp[k] == dp_flag) {
+                    const NodeS Tk = node_load(ns + k);
+                    const int dm = Tk.sid - sid_lo;
+                    const int mdm_ = K.match_dis * (K.high_err ? dm : 1);
+                    long long Rk = K.sv_len > dm * K.seed_step ? K.sv_len : dm * K.seed_step;
+                    if (mdm_ + 1 > Rk) Rk = mdm_ + 1;
+                    Rk += 128 + (long long)dm * K.seed_step;
+                    const int rk = g_rnk[k], tk_ = Tk.chr * 2 + (Tk.strand > 0 ? 1 : 0);
+#pragma unroll
+                    for (int d = -1; d <= 1; d += 2) {
+                        const int i2 = rk + d;
+                        if (i2 >= 0 && i2 < r.H) {
+                            const NodeS Nb = node_load(ns + g_srt[i2]);
+                            long long dp_ = Nb.pos - Tk.pos; if (dp_ < 0) dp_ = -dp_;
+                            due |= ((Nb.chr * 2 + (Nb.strand > 0 ? 1 : 0)) == tk_) & (dp_ <= Rk);
+                        }
+                    }
+                }
+                c[l] = due;
+            }
+            todo = wv::ballot(c);
+        }
         while (todo) {
             const int t = tb + __builtin_ctzll(todo); todo &= todo - 1;
 #ifdef HP_PROF
@@ -246,51 +274,57 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             Rw += 128 + (long long)did_max * K.seed_step;
             const int rT = g_rnk[t];
             const int tkey = T.chr * 2 + (T.strand > 0 ? 1 : 0);
-            for (int dir = -1; dir <= 1 && hi > lo; dir += 2) {
-                for (int c = 0;; ++c) {
+            // u = 0 walks down the sorted order, u = 1 up; trip c covers the c-th 64 hits on either side
+            bool live0 = hi > lo, live1 = hi > lo;
+            int any_ok = 0;
+            for (int c = 0; live0 || live1; ++c) {
 #ifdef HP_PROF
-                    if (r.prof) r.prof[12] += 1;
+                if (r.prof) r.prof[12] += 1;
 #endif
-                    wv::Lane<int> outw;
-                    WAVE_FOR(l) {
-                        int idx[2], inb[2], pn[2];
+                wv::Lane<int> out0, out1, okl;
+                WAVE_FOR(l) {
+                    int idx[2], inb[2], pn[2];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            idx[u] = rT + dir * (1 + c * 128 + u * 64 + l);
-                            inb[u] = idx[u] >= 0 && idx[u] < r.H;
-                            pn[u] = g_srt[inb[u] ? idx[u] : rT];
-                        }
-                        NodeS Q[2]; int dflag[2], sflag[2], pscore[2], pnm[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            Q[u] = node_load(ns + pn[u]);
-                            dflag[u] = g_dp[pn[u]]; sflag[u] = g_son[pn[u]]; pscore[u] = g_score[pn[u]]; pnm[u] = g_NM[pn[u]];
-                        }
-                        int ow = 0;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            long long dp = Q[u].pos - T.pos; if (dp < 0) dp = -dp;
-                            const int inwin = inb[u] & ((Q[u].chr * 2 + (Q[u].strand > 0 ? 1 : 0)) == tkey) & (dp <= Rw);
-                            ow |= !inwin;
-                            const int qslot = Q[u].slot_j >> 14;
-                            const int flag = edge_flag_packed(K, Q[u], T);
-                            const int ok = inwin & (qslot >= start_slot) & (qslot < x) & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) &
-                                           (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
-                            const int pos = ((x - 1 - qslot) << 14) | (Q[u].slot_j & 16383);            // scan order: seeds descending, hits ascending
-                            const int cand = pscore[u] + 1 + score_table(flag);
-                            const int nm = pnm[u] + t_NM;
-                            const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733
-                            const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
-                            const long long kk = ok ? k : -1;
-                            key[l] = kk > key[l] ? kk : key[l];
-                            const int np = isneg ? -pos : -0x7fffffff;
-                            negp[l] = np > negp[l] ? np : negp[l];
-                        }
-                        outw[l] = ow;
+                    for (int u = 0; u < 2; ++u) {
+                        idx[u] = rT + (u ? 1 : -1) * (1 + c * 64 + l);
+                        inb[u] = (u ? live1 : live0) && idx[u] >= 0 && idx[u] < r.H;
+                        pn[u] = g_srt[inb[u] ? idx[u] : rT];
                     }
-                    if (wv::ballot(outw) != 0) break;            // sorted order: once a hit is outside the window, all farther ones are
+                    NodeS Q[2]; int dflag[2], sflag[2], pscore[2], pnm[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        Q[u] = node_load(ns + pn[u]);
+                        dflag[u] = g_dp[pn[u]]; sflag[u] = g_son[pn[u]]; pscore[u] = g_score[pn[u]]; pnm[u] = g_NM[pn[u]];
+                    }
+                    int ow[2], oka = 0;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        long long dp = Q[u].pos - T.pos; if (dp < 0) dp = -dp;
+                        const int inwin = inb[u] & ((Q[u].chr * 2 + (Q[u].strand > 0 ? 1 : 0)) == tkey) & (dp <= Rw);
+                        ow[u] = !inwin;
+                        const int qslot = Q[u].slot_j >> 14;
+                        const int flag = edge_flag_packed(K, Q[u], T);
+                        const int ok = inwin & (qslot >= start_slot) & (qslot < x) & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) &
+                                       (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
+                        const int pos = ((x - 1 - qslot) << 14) | (Q[u].slot_j & 16383);            // scan order: seeds descending, hits ascending
+                        const int cand = pscore[u] + 1 + score_table(flag);
+                        const int nm = pnm[u] + t_NM;
+                        const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733
+                        const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+                        const long long kk = ok ? k : -1;
+                        key[l] = kk > key[l] ? kk : key[l];
+                        const int np = isneg ? -pos : -0x7fffffff;
+                        negp[l] = np > negp[l] ? np : negp[l];
+                        oka |= ok;
+                    }
+                    out0[l] = ow[0]; out1[l] = ow[1]; okl[l] = oka;
                 }
+                // sorted order: once a hit is outside the window, all farther ones on that side are
+                if (live0 && wv::ballot(out0) != 0) live0 = false;
+                if (live1 && wv::ballot(out1) != 0) live1 = false;
+                any_ok |= wv::ballot(okl) != 0;
             }
+            if (!any_ok) continue;                        // no connectable predecessor: the node keeps its state
             int max_from = t_from, max_score = t_score, max_NM = t_NM, max_flag = 0;
             bool changed = false;
             if (hi > lo) {
