@@ -210,9 +210,19 @@ class LamsaHp:
             raise RuntimeError("lamsa_hp_upload_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
         self._n_up = batch.n_reads
 
-    def run_uploaded(self, fetch=True):
+    def run_uploaded(self, fetch=True, raw=False):
+        """Align the resident batch.  fetch=False leaves the results on the device; raw=True returns the numpy
+        views (stream, read_off, read_len, status) without splitting them into per-read lists."""
         R = HpResult()
         rc = self.L.lamsa_hp_run_uploaded(self._h, C.byref(R) if fetch else None)
         if rc != 0:
             raise RuntimeError("lamsa_hp_run_uploaded: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
-        return self._result(R, self._n_up) if fetch else None
+        if not fetch:
+            return None
+        if raw:
+            n = self._n_up
+            self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
+            self.last_stream_words = int(R.stream_words)
+            return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
+                    np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
+        return self._result(R, self._n_up)
