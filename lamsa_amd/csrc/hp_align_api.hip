@@ -13,7 +13,7 @@
 using namespace hp;
 
 #ifndef HP_WAVES_PER_SIMD
-#define HP_WAVES_PER_SIMD 1
+#define HP_WAVES_PER_SIMD 2
 #endif
 __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs a)
 {
