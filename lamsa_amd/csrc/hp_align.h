@@ -132,9 +132,8 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     OutBuf o; o.n = 0; o.cap = out_cap;
     o.w = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)out_cap);
     r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
-    int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 13 * (size_t)(H + 1));
-    int8_t *nb = (int8_t *)arena_alloc(cx, 3 * (size_t)(H + 1));
-    r.ns = (NodeS *)arena_alloc(cx, sizeof(NodeS) * (size_t)(H + 1));
+    int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 11 * (size_t)(H + 1));
+    r.nd = (NodeS *)arena_alloc(cx, sizeof(NodeS) * (size_t)(H + 1));
     const int reg_cap = 256 * a.scale;
     Regs G; G.n = 0; G.m = 0;
     G.beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)reg_cap); G.end = G.beg + reg_cap;
@@ -142,12 +141,11 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     G.r_beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 6 * (size_t)(reg_cap + 2));
     G.r_end = G.r_beg + (reg_cap + 2); G.r_bs = G.r_end + (reg_cap + 2); G.r_bn = G.r_bs + (reg_cap + 2); G.r_es = G.r_bn + (reg_cap + 2); G.r_en = G.r_es + (reg_cap + 2);
     int n0_pos = 1, n1_pos = 2;
-    if (o.w && r.rc_read && nm && nb && r.ns && G.beg && G.rb && G.r_beg) {
+    if (o.w && r.rc_read && nm && r.nd && G.beg && G.rb && G.r_beg) {
         const int c = H + 1;
-        r.n_score = nm; r.n_NM = nm + c; r.n_from = nm + 2 * c; r.n_in_de = nm + 3 * c; r.n_son_n = nm + 4 * c; r.n_first = nm + 5 * c;
-        r.n_last = nm + 6 * c; r.n_next = nm + 7 * c; r.n_max_score = nm + 8 * c; r.n_max_NM = nm + 9 * c; r.n_max_node = nm + 10 * c;
-        r.n_node_n = nm + 11 * c; r.n_seed = nm + 12 * c;
-        r.n_dp_flag = nb; r.n_match_flag = (uint8_t *)(nb + c); r.n_son_flag = (uint8_t *)(nb + 2 * c);
+        r.n_from = nm; r.n_in_de = nm + c; r.n_son_n = nm + 2 * c; r.n_first = nm + 3 * c;
+        r.n_last = nm + 4 * c; r.n_next = nm + 5 * c; r.n_max_score = nm + 6 * c; r.n_max_NM = nm + 7 * c; r.n_max_node = nm + 8 * c;
+        r.n_node_n = nm + 9 * c; r.n_seed = nm + 10 * c;
         for (int s = 0; s < r.seed_out; ++s) {                  // slot of every hit
             const int b = hoff(r, s), e = hoff(r, s + 1);
             const int sidv = r.seed_id[s];
@@ -158,7 +156,8 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
                         r.n_seed[k] = s;
                         NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)sidv;
                         q.strand = r.h_strand[k]; q.len_dif8 = (int8_t)r.h_len_dif[k]; q.pad_ = 0;
-                        r.ns[k] = q;
+                        q.dp_flag = 0; q.son_flag = F_INIT; q.match_flag = 0; q.score = 0; q.NM = 0;
+                        r.nd[k] = q;
                     }
                 }
             }

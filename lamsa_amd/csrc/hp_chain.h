@@ -34,14 +34,19 @@ HP_INL int score_table(int flag) { return flag <= 3 ? 1 : (flag <= 7 ? -3 : -6);
 #define HP_MAX_SLOTS 16383
 #define HP_MAX_HITS_PER_SEED 16383
 
-// static facts of one seed hit, packed so that the predecessor scan needs two wide loads per hit
+// Everything the predecessor scan needs about one seed hit, static and dynamic, in ONE 32-byte record: a candidate
+// costs a single 32-B sector of HBM/L2 traffic and two 16-B loads instead of six scattered cache lines.
 struct NodeS {
     int64_t pos;                // 1-based leftmost reference coordinate
     int32_t chr;                // contig id
     int32_t slot_j;             // seed slot << 14 | hit index within the seed
     int16_t sid;                // 1-based seed id (unflipped: chaining never runs while a '-' line is being filled)
-    int8_t strand, len_dif8;    // +1/-1; len_dif clamped to int8 (|len_dif| <= 127 always holds for 50-bp seeds)
-    int32_t pad_;
+    int8_t strand, len_dif8;    // +1/-1; len_dif (|len_dif| <= 127 always holds for 50-bp seeds)
+    int8_t dp_flag;             // pass flag (MIN / MULTI / WHOLE / TRACKED, negative: unreachable)   -- dynamic
+    uint8_t son_flag;           // edge class of the last chosen son (F_INIT: none)                   -- dynamic
+    uint8_t match_flag;         // edge class to `from`                                                -- dynamic
+    uint8_t pad_;
+    int32_t score, NM;          // chain score / total NM up to this node                             -- dynamic
 };
 
 // one read being aligned by this wave
@@ -60,10 +65,9 @@ struct ReadCtx {
     const int64_t *h_pos; const int32_t *h_chr, *h_cig_off; const int16_t *h_nm, *h_len_dif;
     const int8_t *h_strand; const uint8_t *h_cig_n; const int32_t *cig;
     // chaining DP cells (frag_dp_node, lamsa_aln.h:352-373), indexed by local hit index
-    int32_t *n_score, *n_NM, *n_from, *n_in_de, *n_son_n, *n_first, *n_last, *n_next;
+    int32_t *n_from, *n_in_de, *n_son_n, *n_first, *n_last, *n_next;
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
-    int8_t *n_dp_flag; uint8_t *n_match_flag, *n_son_flag;
-    NodeS *ns;                  // packed static record per hit
+    NodeS *nd;                  // 32-byte hot record per hit (static facts + score/NM/flags)
     const int32_t *srt, *rnk;   // hits sorted by (contig, strand, position) and the inverse permutation (local indices)
     long long *prof;            // diagnostic build only
 };
@@ -104,8 +108,8 @@ HP_INL int edge_flag(const ReadCtx &r, int pre, int cur)
 // ---------------------------------------------------------------- node helpers
 HP_INL void node_set(ReadCtx &r, int n, int from, int score, int NM, int match_flag, int dp_flag)
 {   // fnode_set, :636
-    r.n_son_flag[n] = F_INIT; r.n_from[n] = from; r.n_score[n] = score; r.n_NM[n] = NM;
-    r.n_match_flag[n] = (uint8_t)match_flag; r.n_dp_flag[n] = (int8_t)dp_flag;
+    r.nd[n].son_flag = F_INIT; r.n_from[n] = from; r.nd[n].score = score; r.nd[n].NM = NM;
+    r.nd[n].match_flag = (uint8_t)match_flag; r.nd[n].dp_flag = (int8_t)dp_flag;
     r.n_node_n[n] = 1; r.n_in_de[n] = 0; r.n_son_n[n] = 0; r.n_first[n] = -1; r.n_last[n] = -1;
     r.n_max_score[n] = score; r.n_max_NM[n] = NM; r.n_max_node[n] = n;
 }
@@ -114,7 +118,7 @@ HP_FN void node_per_init(ReadCtx &r, int n, int from, int dp_flag)
     if (from < 0) { node_set(r, n, from, 1, r.h_nm[n], F_MATCH, dp_flag); return; }
     int flag = edge_flag(r, from, n);
     if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, n, from, 2 + score_table(flag), r.h_nm[n] + r.h_nm[from], flag, dp_flag);
-    else r.n_dp_flag[n] = (int8_t)(0 - dp_flag);
+    else r.nd[n].dp_flag = (int8_t)(0 - dp_flag);
 }
 HP_INL void add_son(ReadCtx &r, int fa, int son)
 {   // fnode_add_son, :683 (append keeps insertion order, which get_max_son depends on)
@@ -126,12 +130,14 @@ HP_INL void add_son(ReadCtx &r, int fa, int son)
 }
 
 HP_INL NodeS node_load(const HP_G NodeS *p)
-{   // layout: pos[0..8) chr[8..12) slot_j[12..16) sid[16..18) strand[18] len_dif8[19] pad[20..24)
-    int a[4], b[2];                         // two whole-vector loads (16 B + 8 B), see hp_load16
-    hp_load16(p, a); hp_load8((const HP_G char *)p + 16, b);
+{   // layout: pos[0..8) chr[8..12) slot_j[12..16) | sid[16..18) strand[18] len_dif8[19] dp_flag[20] son_flag[21] match_flag[22] pad[23] score[24..28) NM[28..32)
+    int a[4], b[4];                         // two whole-vector loads of one 32-byte sector, see hp_load16
+    hp_load16(p, a); hp_load16((const HP_G char *)p + 16, b);
     NodeS q;
     q.pos = (int64_t)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]); q.chr = a[2]; q.slot_j = a[3];
-    q.sid = (int16_t)(b[0] & 0xffff); q.strand = (int8_t)((b[0] >> 16) & 0xff); q.len_dif8 = (int8_t)((b[0] >> 24) & 0xff); q.pad_ = b[1];
+    q.sid = (int16_t)(b[0] & 0xffff); q.strand = (int8_t)((b[0] >> 16) & 0xff); q.len_dif8 = (int8_t)((b[0] >> 24) & 0xff);
+    q.dp_flag = (int8_t)(b[1] & 0xff); q.son_flag = (uint8_t)((b[1] >> 8) & 0xff); q.match_flag = (uint8_t)((b[1] >> 16) & 0xff); q.pad_ = 0;
+    q.score = b[2]; q.NM = b[3];
     return q;
 }
 
@@ -167,16 +173,16 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 #ifdef HP_PROF
     const long long t0_ = wv::clock();
 #endif
-    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     const EdgeK K = edge_consts(r.cx.P);
-    NodeS F; F.pos = 0; F.chr = 0; F.slot_j = 0; F.sid = 0; F.strand = 0; F.len_dif8 = 0; F.pad_ = 0;
+    NodeS F; F.pos = 0; F.chr = 0; F.slot_j = 0; F.sid = 0; F.strand = 0; F.len_dif8 = 0; F.pad_ = 0; F.dp_flag = 0; F.son_flag = 0; F.match_flag = 0; F.score = 0; F.NM = 0;
     int from_nm = 0;
     if (from >= 0) { F = node_load(ns + from); from_nm = r.h_nm[from]; }
     for (int b = k0; b < k1; b += 64) {
         WAVE_FOR(l) {
             const int k = b + l;
             if (k < k1) {
-                const int df = r.n_dp_flag[k];
+                const int df = r.nd[k].dp_flag;
                 const bool take = which == 0 ? (df == dp_flag || df == 0 - dp_flag) : (df != TRACKED_FLAG);
                 if (take) {
                     if (from < 0) node_set(r, k, from, 1, r.h_nm[k], F_MATCH, dp_flag);
@@ -184,7 +190,7 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
                         const NodeS Q = node_load(ns + k);
                         const int flag = k == from ? F_MATCH : edge_flag_packed(K, F, Q);
                         if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, k, from, 2 + score_table(flag), r.h_nm[k] + from_nm, flag, dp_flag);
-                        else r.n_dp_flag[k] = (int8_t)(0 - dp_flag);
+                        else r.nd[k].dp_flag = (int8_t)(0 - dp_flag);
                     }
                 }
             }
@@ -203,12 +209,11 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 // (256 predecessors per trip, per-lane running best), two DPP reductions, one trip for the winner, the stores.
 HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force)
 {
-    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
-    HP_G int32_t *g_score = (HP_G int32_t *)r.n_score, *g_NM = (HP_G int32_t *)r.n_NM, *g_from = (HP_G int32_t *)r.n_from;
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from;
     HP_G int32_t *g_node_n = (HP_G int32_t *)r.n_node_n, *g_in_de = (HP_G int32_t *)r.n_in_de, *g_son_n = (HP_G int32_t *)r.n_son_n;
     HP_G int32_t *g_first = (HP_G int32_t *)r.n_first, *g_last = (HP_G int32_t *)r.n_last, *g_next = (HP_G int32_t *)r.n_next;
-    HP_G int8_t *g_dp = (HP_G int8_t *)r.n_dp_flag;
-    HP_G uint8_t *g_son = (HP_G uint8_t *)r.n_son_flag, *g_mf = (HP_G uint8_t *)r.n_match_flag;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
@@ -226,8 +231,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             WAVE_FOR(l) {
                 const int k = tb + l;
                 int due = 0;
-                if (k < k1 && g_dp[k] == dp_flag) {
-                    const NodeS Tk = node_load(ns + k);
+                const NodeS Tk = node_load(ns + (k < k1 ? k : k0));
+                if (k < k1 && Tk.dp_flag == dp_flag) {
                     const int dm = Tk.sid - sid_lo;
                     const int mdm_ = K.match_dis * (K.high_err ? dm : 1);
                     long long Rk = K.sv_len > dm * K.seed_step ? K.sv_len : dm * K.seed_step;
@@ -256,7 +261,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             const NodeS T = node_load(ns + t);
             const int x = T.slot_j >> 14;
             const int hi = (int)(g_hoff[x] - hb);
-            const int t_NM = g_NM[t], t_from = g_from[t], t_score = g_score[t];
+            const int t_NM = T.NM, t_from = g_from[t], t_score = T.score;
             wv::Lane<long long> key;
             wv::Lane<int> negp;
             WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
@@ -294,7 +299,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         Q[u] = node_load(ns + pn[u]);
-                        dflag[u] = g_dp[pn[u]]; sflag[u] = g_son[pn[u]]; pscore[u] = g_score[pn[u]]; pnm[u] = g_NM[pn[u]];
+                        dflag[u] = Q[u].dp_flag; sflag[u] = Q[u].son_flag; pscore[u] = Q[u].score; pnm[u] = Q[u].NM;
                     }
                     int ow[2], oka = 0;
 #pragma unroll
@@ -335,7 +340,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
                     const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = (int)(g_hoff[i] - hb) + j;
                     const NodeS Q = node_load(ns + p);
                     const int flag = edge_flag_packed(K, Q, T);
-                    max_from = p; max_score = g_score[p] + 1 + score_table(flag); max_flag = flag; max_NM = g_NM[p] + t_NM;
+                    max_from = p; max_score = Q.score + 1 + score_table(flag); max_flag = flag; max_NM = Q.NM + t_NM;
                     changed = max_from != t_from;
                 } else if (best_key >= 0) {
                     const int pos = POSMAX - (int)(best_key & POSMAX);
@@ -350,8 +355,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
                 }
             }
             if (changed) {                               // wave-uniform stores (:753-761); every lane re-reads only what it wrote itself
-                g_son[max_from] = (uint8_t)max_flag;
-                g_from[t] = max_from; g_score[t] = max_score; g_NM[t] = max_NM; g_mf[t] = (uint8_t)max_flag;
+                gd[max_from].son_flag = (uint8_t)max_flag;
+                g_from[t] = max_from; gd[t].score = max_score; gd[t].NM = max_NM; gd[t].match_flag = (uint8_t)max_flag;
                 g_node_n[t] = g_node_n[max_from] + 1;
                 const int sn = g_son_n[max_from], la = g_last[max_from];      // fnode_add_son, :683
                 g_in_de[max_from] = g_in_de[max_from] + 1;
@@ -371,8 +376,8 @@ HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag) { dp_updat
 // segmented ballot.  The result is a set union, so the order over MIN hits is irrelevant.
 HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
 {
-    const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
-    HP_G int8_t *g_dp = (HP_G int8_t *)r.n_dp_flag;
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
@@ -400,7 +405,7 @@ HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
             const int k = base + l;
             if (k < r.H && q[l]) {
                 unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
-                if (earlier == 0 && !(sd[l] == carry_seed && carry_found)) g_dp[k] = MIN_FLAG;
+                if (earlier == 0 && !(sd[l] == carry_seed && carry_found)) gd[k].dp_flag = MIN_FLAG;
             }
         }
         const int klast = base + 63 < r.H ? base + 63 : r.H - 1;
@@ -487,8 +492,8 @@ HP_FN void ns_add_end(ReadCtx &r, NScore &ns, int score, int NM, int node)
     if (score < ns.min_score_thd) return;
     if (ns.node_n >= ns.cap) { r.cx.status |= ST_OVERFLOW; return; }
     ns.score[ns.node_n] = score; ns.NM[ns.node_n] = NM; ns.node[ns.node_n++] = node;
-    r.n_dp_flag[node] = TRACKED_FLAG;
-    for (int t = r.n_from[node]; t >= 0; t = r.n_from[t]) r.n_dp_flag[t] = TRACKED_FLAG;
+    r.nd[node].dp_flag = TRACKED_FLAG;
+    for (int t = r.n_from[node]; t >= 0; t = r.n_from[t]) r.nd[t].dp_flag = TRACKED_FLAG;
 }
 
 // ---------------------------------------------------------------- forest -> disjoint paths
@@ -497,7 +502,7 @@ HP_FN int best_son(ReadCtx &r, int f)
     int max_score = 0, max_NM = 0, max_dis = 0, flag_thd = F_INIT, max = -1;
     const int x = r.n_seed[f];
     for (int s = r.n_first[f], c = 0; c < r.n_son_n[f] && s >= 0; s = r.n_next[s], ++c) {
-        const int mf = r.n_match_flag[s], sx = r.n_seed[s];
+        const int mf = r.nd[s].match_flag, sx = r.n_seed[s];
         if (mf <= flag_thd && (r.n_max_score[s] > max_score || (r.n_max_score[s] == max_score && (sx - x < max_dis || r.n_max_NM[s] < max_NM)))) {
             max = s; max_score = r.n_max_score[s]; max_NM = r.n_max_NM[s]; max_dis = sx - x;
             if (mf <= F_MATCH_THD) flag_thd = F_MATCH_THD;
@@ -508,8 +513,8 @@ HP_FN int best_son(ReadCtx &r, int f)
 HP_FN void detach(ReadCtx &r, int s, int max_node, NScore &ns)
 {   // :842-847 / :851-857 / :893-899
     r.n_from[s] = -1;
-    r.n_max_score[s] -= (r.n_score[s] - 1);
-    r.n_max_NM[s] -= (r.n_NM[s] - r.h_nm[s]);
+    r.n_max_score[s] -= (r.nd[s].score - 1);
+    r.n_max_NM[s] -= (r.nd[s].NM - r.h_nm[s]);
     r.n_node_n[max_node] -= (r.n_node_n[s] - 1);
     ns_add_end(r, ns, r.n_max_score[s], r.n_max_NM[s], max_node);
 }
@@ -522,11 +527,11 @@ HP_FN void cut_branch(ReadCtx &r, int f, NScore &ns)
         if (s != keep) detach(r, s, r.n_max_node[s], ns);
         s = nxt;
     }
-    if (r.n_score[f] > r.n_max_score[keep]) {        // negative edge
+    if (r.nd[f].score > r.n_max_score[keep]) {        // negative edge
         r.n_in_de[keep] = -1;
         detach(r, keep, r.n_max_node[keep], ns);
         r.n_son_n[f] = 0; r.n_first[f] = r.n_last[f] = -1;
-        r.n_max_node[f] = f; r.n_max_score[f] = r.n_score[f]; r.n_max_NM[f] = r.n_NM[f];
+        r.n_max_node[f] = f; r.n_max_score[f] = r.nd[f].score; r.n_max_NM[f] = r.nd[f].NM;
     } else {
         r.n_son_n[f] = 1; r.n_first[f] = r.n_last[f] = keep; r.n_next[keep] = -1;
         r.n_max_node[f] = r.n_max_node[keep]; r.n_max_score[f] = r.n_max_score[keep]; r.n_max_NM[f] = r.n_max_NM[keep];
@@ -537,17 +542,17 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
 {   // branch_track_new, :873-920
     int max_score, max_NM, max_node;
     r.n_in_de[n] = -1;
-    if (r.n_son_n[n] == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = r.n_score[n]; max_NM = r.n_max_NM[n] = r.n_NM[n]; }
+    if (r.n_son_n[n] == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = r.nd[n].score; max_NM = r.n_max_NM[n] = r.nd[n].NM; }
     else { max_node = r.n_max_node[n]; max_score = r.n_max_score[n]; max_NM = r.n_max_NM[n]; }
     int fa = r.n_from[n];
     while (fa >= 0) {
         if (r.n_son_n[fa] == 1) {
-            if (r.n_score[fa] > max_score) {         // negative edge
+            if (r.nd[fa].score > max_score) {         // negative edge
                 const int s = r.n_first[fa];
                 r.n_in_de[s] = -1;
                 detach(r, s, max_node, ns);
                 r.n_son_n[fa] = 0; r.n_first[fa] = r.n_last[fa] = -1;
-                max_score = r.n_score[fa]; max_NM = r.n_NM[fa]; max_node = fa;
+                max_score = r.nd[fa].score; max_NM = r.nd[fa].NM; max_node = fa;
             }
             r.n_max_score[fa] = max_score; r.n_max_NM[fa] = max_NM; r.n_max_node[fa] = max_node; r.n_in_de[fa] = -1;
             fa = r.n_from[fa];
@@ -570,7 +575,7 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     const int left_NM = left < 0 ? 0 : r.h_nm[left];
     int old_score, old_NM;
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
-    else { old_score = 2 + score_table(r.n_match_flag[right]); old_NM = left_NM + r.h_nm[right]; }
+    else { old_score = 2 + score_table(r.nd[right].match_flag); old_NM = left_NM + r.h_nm[right]; }
     const int dp_flag = MULTI_FLAG;
     nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0);
     dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false);      // callers guarantee left_x + 2 <= right_x
@@ -578,17 +583,17 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     if (_tail == 0) {
         // best end node: score desc, NM asc, then the reference's scan order (seeds descending, hits ascending), :1105-1123
         max_score = old_score;
-        const HP_G NodeS *ns = (const HP_G NodeS *)r.ns;
+        const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
         const int k0 = hoff(r, left_x + 1), k1 = hoff(r, right_x);
         wv::Lane<long long> key;
         WAVE_FOR(l) { key[l] = -1; }
         for (int b = k0; b < k1; b += 64) {
             WAVE_FOR(l) {
                 const int k = b + l;
-                if (k < k1 && r.n_dp_flag[k] == dp_flag) {
+                if (k < k1 && r.nd[k].dp_flag == dp_flag) {
                     const int sj = ns[k].slot_j;
                     const int pos = ((right_x - 1 - (sj >> 14)) << 14) | (sj & 16383);
-                    const long long kk = ((long long)(r.n_score[k] + 32768) << 47) | ((long long)(524287 - r.n_NM[k]) << 28) | (long long)(((1 << 28) - 1) - pos);
+                    const long long kk = ((long long)(r.nd[k].score + 32768) << 47) | ((long long)(524287 - r.nd[k].NM) << 28) | (long long)(((1 << 28) - 1) - pos);
                     key[l] = kk > key[l] ? kk : key[l];
                 }
             }
@@ -603,10 +608,10 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
             }
         }
     } else {
-        r.n_from[right] = head; r.n_score[right] = old_score; r.n_NM[right] = old_NM; r.n_node_n[right] = 1;
+        r.n_from[right] = head; r.nd[right].score = old_score; r.nd[right].NM = old_NM; r.n_node_n[right] = 1;
         wv::sync();
         dp_update(r, right, left_x + 1, dp_flag);
-        max_score = r.n_score[right]; max_NM = r.n_NM[right]; max_node = r.n_from[right]; max_n = r.n_node_n[right] - 1;
+        max_score = r.nd[right].score; max_NM = r.nd[right].NM; max_node = r.n_from[right]; max_n = r.n_node_n[right] - 1;
     }
     int cur = max_node, node_i = max_n - 1;
     while (nx(r, cur) != head_x) {
@@ -773,7 +778,7 @@ HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int p
                     const int l = L.rank[_l];
                     if ((L.mf[l] & 0x3) != 0) break;
                     if (firstx(r, L, l) > r.n_seed[n1] && lastx(r, L, l) < r.n_seed[n2]) {
-                        const int mfl = r.n_match_flag[n2];
+                        const int mfl = r.nd[n2].match_flag;
                         if (mfl == F_MISMATCH || mfl == F_LONG_MISMATCH) {
                             const int s = L.pool[L.start[l]], e = L.pool[L.start[l] + L.len[l] - 1];
                             const int st = r.h_strand[s];
@@ -841,13 +846,13 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
             for (int j = 1; j < ll - 1; ++j) {
                 const int c = ni[j], p = ni[last_i];
                 const int st = r.h_strand[c];
-                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.n_match_flag[c] != F_INSERT) ni[j] = -1;
+                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.nd[c].match_flag != F_INSERT) ni[j] = -1;
                 else last_i = j;
             }
             if (ll - 1 != last_i) {
                 const int c = ni[ll - 1], p = ni[last_i];
                 const int st = r.h_strand[c];
-                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.n_match_flag[c] != F_INSERT) ni[last_i] = -1;
+                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.nd[c].match_flag != F_INSERT) ni[last_i] = -1;
             }
         }
     }
@@ -863,7 +868,7 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
             cur = pre;
             if (ln[i - 1] < 0) continue;
             pre = ln[i - 1];
-            const int mf = r.n_match_flag[cur];
+            const int mf = r.nd[cur].match_flag;
             if (mf == F_INSERT || mf == F_DELETE || mf == F_MISMATCH || mf == F_LONG_MISMATCH) { ++nf; F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre; }
             else if (mf == F_MATCH) F.fr_seed[ns++] = pre;
             else { r.cx.status |= ST_REFEXIT; return false; }          // "[frag dp path] Error: Unknown flag", :1223
@@ -918,7 +923,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     ns.min_score_thd = 2;
     for (int i = seed_out - 1; i >= 0; --i)                                                       // :1356-1361
         for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
-            if (r.n_dp_flag[k] == MIN_FLAG && r.n_in_de[k] == 0) branch_track(r, k, ns);
+            if (r.nd[k].dp_flag == MIN_FLAG && r.n_in_de[k] == 0) branch_track(r, k, ns);
 
     HP_CSTAMP(8);
     const int o_l = ns.node_n;
@@ -943,7 +948,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
         T.off[l_i] = T.used; T.cnt[l_i] = 0;
         if (r.n_seed[max_node] < seed_out - 1) {                      // beyond the chain end
             mini_len = mini_line(r, max_node, -1, seed_out, _line, &line_score, &line_NM, 1, 0);
-            for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.n_dp_flag[_line[k]] = TRACKED_FLAG; }
+            for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.nd[_line[k]].dp_flag = TRACKED_FLAG; }
             ln[node_i] = max_node;
             last_n = ln[0];
             for (int k = mini_len - 1; k >= 0; --k) {
@@ -957,7 +962,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
             left = r.n_from[right];
             if (nx(r, left) < r.n_seed[right] - 1) {
                 mini_len = mini_line(r, left, right, r.n_seed[right], _line, &line_score, &line_NM, 1, 1);
-                for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.n_dp_flag[_line[k]] = TRACKED_FLAG; }
+                for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.nd[_line[k]].dp_flag = TRACKED_FLAG; }
                 ln[node_i] = left;
                 last_n = right;
                 for (int k = mini_len; k >= 0; --k) {
@@ -1009,7 +1014,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
     ns.min_score_thd = 0;
     for (int i = end; i >= start; --i)
         for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
-            if (r.n_dp_flag[k] == dp_flag && r.n_in_de[k] == 0) branch_track(r, k, ns);
+            if (r.nd[k].dp_flag == dp_flag && r.n_in_de[k] == 0) branch_track(r, k, ns);
     int l_i = 0, next_start = 0, score = 0, NM = 0;
     for (;;) {
         int rr = ns_pop(ns, &score, &NM);
