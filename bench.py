@@ -153,7 +153,7 @@ def main():
         cpu = None
         if a.cpu_seconds > 0:
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
-            probe = min(32, a.reads)
+            probe = min(256, a.reads)                      # estimate the rate on a probe, then size the sample for ~cpu_seconds
             t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, threads); tp = time.perf_counter() - t0
             n_s = int(max(probe, min(a.reads, probe * a.cpu_seconds / max(tp, 1e-3))))
             sample = take_first(B, n_s)
