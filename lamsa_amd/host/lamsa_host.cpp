@@ -1,0 +1,434 @@
+// lamsa_host.cpp -- host side of `lamsa aln`: everything around the MI355X hot path.
+//
+// Mirrors the reference's driver for the path (same files, same option letters, same SAM):
+//   load_index      <- bns_restore_core + .pac read            src/bntseq.c:114-166, src/lamsa_aln.c:1237-1239
+//   FastxReader     <- kseq_read with KS_SEP_REF names          src/kseq.h:179-225 (name ends at '\n', ':' or ',')
+//   parse_gem_hits  <- gem_map_read / gem_map_msg / md2cigar    src/gem_parse.c:74-286, map_cal_msg src/lamsa_aln.c:767
+//   cov_fraction    <- get_reg + get_cov_f                      src/lamsa_aln.c:571-651
+//   rank_results    <- rearr_aln_res                            src/lamsa_aln.c:654-724
+//   write_sam       <- aln_res_output / print_sam_header        src/lamsa_aln.c:1001-1100,1215
+//   run_aln         <- lamsa_aln_core chunk loop                src/lamsa_aln.c:1116-1177
+// The per-read stages (2),(3),(2'),(3') are NOT here: they run on the GPU behind lamsa_hp_align_batch()
+// (include/lamsa_hp.h).  Stage (4), the BWT rescue of short uncovered gaps (src/bwt_aln.c), is not built yet:
+// the output equals the reference's with `-R 0`.
+#include "lamsa_host.h"
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <zlib.h>
+
+namespace lamsa {
+
+// ------------------------------------------------------------------ index
+bool load_index(const std::string &prefix, Index &ix, std::string &err)
+{
+    FILE *fp = fopen((prefix + ".ann").c_str(), "r");
+    if (!fp) { err = "cannot open " + prefix + ".ann"; return false; }
+    long long l_pac; int n_seqs; unsigned seed;
+    if (fscanf(fp, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) { fclose(fp); err = "bad .ann header"; return false; }
+    ix.name.resize(n_seqs); ix.off.resize(n_seqs); ix.len.resize(n_seqs);
+    for (int i = 0; i < n_seqs; ++i) {
+        unsigned gi; int c, n_ambs; long long off; std::string line;
+        if (fscanf(fp, "%u", &gi) != 1) { fclose(fp); err = "bad .ann record"; return false; }
+        while ((c = fgetc(fp)) != '\n' && c != EOF) line.push_back((char)c);
+        ix.name[i] = line.size() > 1 ? line.substr(1) : std::string();
+        if (fscanf(fp, "%lld%d%d", &off, &ix.len[i], &n_ambs) != 3) { fclose(fp); err = "bad .ann record"; return false; }
+        ix.off[i] = off;
+    }
+    fclose(fp);
+    fp = fopen((prefix + ".pac").c_str(), "rb");
+    if (!fp) { err = "cannot open " + prefix + ".pac"; return false; }
+    ix.l_pac = l_pac;
+    ix.pac.assign((size_t)(l_pac / 4 + 1) + 16, 0);
+    size_t got = fread(ix.pac.data(), 1, (size_t)(l_pac / 4 + 1), fp);
+    fclose(fp);
+    if (got == 0 && l_pac > 4) { err = "empty .pac"; return false; }
+    for (int i = 0; i < n_seqs; ++i) ix.name_to_id[ix.name[i]] = i + 1;
+    return true;
+}
+
+// ------------------------------------------------------------------ FASTA / FASTQ (+gz)
+struct FastxReader::Impl { gzFile f = nullptr; std::string line; bool have = false; };
+FastxReader::FastxReader() : p(new Impl) {}
+FastxReader::~FastxReader() { if (p->f) gzclose(p->f); delete p; }
+bool FastxReader::open(const std::string &path) { p->f = gzopen(path.c_str(), "r"); return p->f != nullptr; }
+static bool next_line(FastxReader::Impl *p)
+{
+    if (p->have) { p->have = false; return true; }
+    p->line.clear();
+    char buf[1 << 16];
+    bool any = false;
+    while (gzgets(p->f, buf, sizeof buf)) {
+        any = true;
+        size_t n = strlen(buf);
+        p->line.append(buf, n);
+        if (n && buf[n - 1] == '\n') break;
+    }
+    if (!any) return false;
+    while (!p->line.empty() && (p->line.back() == '\n' || p->line.back() == '\r')) p->line.pop_back();
+    return true;
+}
+bool FastxReader::next(Read &r)
+{
+    r.seq.clear(); r.qual.clear(); r.has_qual = false;
+    do { if (!next_line(p)) return false; } while (p->line.empty() || (p->line[0] != '>' && p->line[0] != '@'));
+    const bool fastq = p->line[0] == '@';
+    size_t nl = strcspn(p->line.c_str() + 1, ":,");
+    r.name.assign(p->line, 1, nl);
+    while (next_line(p)) {
+        const char c0 = p->line.empty() ? 0 : p->line[0];
+        if (c0 == '>' || c0 == '+' || c0 == '@') { if (c0 != '+') p->have = true; break; }
+        for (char c : p->line) if (isgraph((unsigned char)c)) r.seq.push_back(c);
+    }
+    if (fastq && !p->have) {
+        while (r.qual.size() < r.seq.size() && next_line(p)) r.qual += p->line;
+        if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());
+        r.has_qual = true;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ GEM map line -> hits
+static inline void cig_push1(std::vector<int32_t> &c, size_t base, int32_t w)
+{   // _push_cigar1, src/frag_check.h:153 (restricted to the CIGAR that starts at `base`)
+    if ((w >> 4) == 0) return;
+    if (c.size() > base && (c.back() & 0xf) == (w & 0xf)) { c.back() += (w >> 4) << 4; return; }
+    c.push_back(w);
+}
+
+// one hit "chr:strand:pos:gigar" appended to the batch; md2cigar, src/gem_parse.c:74-112
+static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
+{
+    const char *e = tok + len, *c1 = (const char *)memchr(tok, ':', len);
+    if (!c1) return;
+    const std::string chr(tok, c1);
+    const char strand = c1 + 1 < e ? c1[1] : '+';
+    const char *c2 = c1 + 2 < e ? (const char *)memchr(c1 + 2, ':', (size_t)(e - c1 - 2)) : nullptr;
+    if (!c2) return;
+    const char *c3 = (const char *)memchr(c2 + 1, ':', (size_t)(e - c2 - 1));
+    if (!c3) c3 = e;
+    const long long pos = atoll(std::string(c2 + 1, c3).c_str());
+    const char *md = c3 < e ? c3 + 1 : e;
+    const char *mdend = (const char *)memchr(md, ':', (size_t)(e - md));
+    if (!mdend) mdend = e;
+    const size_t base = B.cig.size();
+    int nm = 0, bd = 0, bi = 0;
+    for (const char *q = md; q < mdend;) {
+        if (*q == '>') {
+            const int n = atoi(q + 1);
+            const char *s = q + 1; while (s < mdend && *s != '+' && *s != '-') ++s;
+            if (s < mdend && *s == '+') { bd += n; cig_push1(B.cig, base, (n << 4) | 2); } else { bi += n; cig_push1(B.cig, base, (n << 4) | 1); }
+            nm += n;
+            int d = 1; for (int t = n; t >= 10; t /= 10) ++d;
+            q += d + 2;
+        } else {
+            int m = 0, mm = 0, run = 0; bool in_run = false;
+            for (; q < mdend && *q != '>'; ++q) {
+                if (*q >= 'A' && *q <= 'T') { ++mm; if (in_run) { m += run; run = 0; in_run = false; } }
+                else if (isdigit((unsigned char)*q)) { run = in_run ? run * 10 + (*q - '0') : (*q - '0'); in_run = true; }
+                else if (in_run) { m += run; run = 0; in_run = false; }
+            }
+            if (in_run) m += run;
+            cig_push1(B.cig, base, ((m + mm) << 4) | 0);
+            nm += mm;
+        }
+    }
+    if (strand == '-') std::reverse(B.cig.begin() + (long)base, B.cig.end());      // _invert_cigar, src/gem_parse.c:267
+    auto it = ix.name_to_id.find(chr);
+    B.h_pos.push_back(pos); B.h_chr.push_back(it == ix.name_to_id.end() ? -1 : it->second); B.h_strand.push_back(strand == '+' ? 1 : -1);
+    B.h_nm.push_back((int16_t)nm); B.h_len_dif.push_back((int16_t)(bd - bi)); B.h_cig_off.push_back((int32_t)base);
+    B.h_cig_n.push_back((uint8_t)std::min<size_t>(255, B.cig.size() - base));
+}
+
+// all hits of one seed; more than max_n hits: the seed keeps its slot but loses all hits (src/gem_parse.c:243-246)
+static void parse_gem_hits(Batch &B, const Index &ix, const char *s, int max_n)
+{
+    const size_t h0 = B.h_pos.size(), c0 = B.cig.size();
+    int n = 0;
+    for (const char *p = s; *p;) {
+        while (*p == ',') ++p;
+        if (!*p) break;
+        const char *e = p; while (*e && *e != ',') ++e;
+        if (n >= max_n) {
+            B.h_pos.resize(h0); B.h_chr.resize(h0); B.h_strand.resize(h0); B.h_nm.resize(h0); B.h_len_dif.resize(h0); B.h_cig_off.resize(h0); B.h_cig_n.resize(h0); B.cig.resize(c0);
+            return;
+        }
+        add_hit(B, ix, p, (size_t)(e - p));
+        ++n; p = e;
+    }
+}
+
+void Batch::clear()
+{
+    reads.clear(); read_off.assign(1, 0); read_seq.clear(); seed_all.clear(); last_len.clear(); seed_off.assign(1, 0); seed_id.clear(); hit_off.assign(1, 0);
+    h_pos.clear(); h_chr.clear(); h_strand.clear(); h_nm.clear(); h_len_dif.clear(); h_cig_off.clear(); h_cig_n.clear(); cig.clear();
+}
+
+static const uint8_t *nt4_table()
+{   // nst_nt4_table, src/bntseq.c:20 ('-' maps to 5 there; the hot path accepts 0..4, so it is treated as N)
+    static uint8_t t[256]; static bool init = false;
+    if (!init) { memset(t, 4, 256); t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3; init = true; }
+    return t;
+}
+
+// one read + its seed_all GEM map lines -> batch (lamsa_read_seq, src/lamsa_aln.c:927-956; split_seed :252-253,281)
+bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err)
+{
+    const int L = (int)rd.seq.size();
+    const uint8_t *t4 = nt4_table();
+    for (char c : rd.seq) B.read_seq.push_back(t4[(unsigned char)c]);
+    B.read_off.push_back((int64_t)B.read_seq.size());
+    const int seed_all = L < P.seed_len ? 0 : 1 + (L - P.seed_len) / P.seed_step;
+    B.seed_all.push_back(seed_all); B.last_len.push_back(L - P.seed_len - (seed_all - 1) * P.seed_step);
+    static thread_local std::vector<char> line(65536);
+    for (int sd = 0; sd < seed_all; ++sd) {
+        if (!fgets(line.data(), (int)line.size(), mapf)) { err = "seeds' GEM map result does not match the reads"; return false; }
+        size_t ll = strlen(line.data()); if (ll && line[ll - 1] == '\n') line[ll - 1] = 0;
+        int ct = 0; size_t k;
+        for (k = 0; line[k]; ++k) if (line[k] == '\t') { if (ct == 3) break; ct++; }
+        if (!line[k] || line[k + 1] == '-') continue;                   // no map line content: the seed gets no slot
+        B.seed_id.push_back(sd + 1);
+        parse_gem_hits(B, ix, line.data() + k + 1, P.per_aln_m);
+        B.hit_off.push_back((int64_t)B.h_pos.size());
+    }
+    B.seed_off.push_back((int64_t)B.seed_id.size());
+    B.reads.push_back(rd);
+    return true;
+}
+
+// ------------------------------------------------------------------ result stream -> records
+void parse_stream(const int32_t *s, int n_words, int read_len, ReadResult &R)
+{
+    for (int st = 0; st < 3; ++st) R.stage[st].clear();
+    R.status = n_words > 0 ? s[0] : LAMSA_HP_ST_OVERFLOW;
+    if (n_words < 3 || R.status != 0) return;
+    int i = 3;
+    for (int st = 0; st < 2; ++st) {
+        R.stage[st].resize((size_t)s[1 + st]);
+        for (Line &ln : R.stage[st]) {
+            ln.line_score = s[i]; ln.tol_score = s[i + 1]; ln.tol_NM = s[i + 2];
+            const int n_res = s[i + 3]; i += 4;
+            ln.rec.resize((size_t)n_res);
+            for (Rec &r : ln.rec) {
+                r.offset = (int64_t)(((uint64_t)(uint32_t)s[i + 1] << 32) | (uint32_t)s[i]); r.chr = s[i + 2]; r.nstrand = s[i + 3]; r.score = s[i + 4]; r.NM = s[i + 5];
+                const int cn = s[i + 6]; i += 7;
+                r.cigar.assign(s + i, s + i + cn); i += cn;
+                // covered read interval, push_reg_res src/lamsa_aln.c:571-595
+                if (r.cigar.empty()) { r.reg_beg = 1; r.reg_end = read_len; continue; }
+                const int32_t c0 = r.cigar.front(), c1 = r.cigar.back();
+                if (r.nstrand == 1) { r.reg_beg = (c0 & 0xf) == 4 ? (c0 >> 4) + 1 : 1; r.reg_end = (c1 & 0xf) == 4 ? read_len - (c1 >> 4) : read_len; }
+                else { r.reg_beg = (c1 & 0xf) == 4 ? (c1 >> 4) + 1 : 1; r.reg_end = (c0 & 0xf) == 4 ? read_len - (c0 >> 4) : read_len; }
+            }
+        }
+    }
+}
+
+// get_cov_f, src/lamsa_aln.c:639-651
+static float cov_fraction(const ReadResult &R, int read_len)
+{
+    std::vector<std::pair<int, int>> reg;
+    for (int st = 0; st < 3; ++st) for (const Line &ln : R.stage[st]) { if (ln.tol_score < 0) continue; for (const Rec &r : ln.rec) reg.push_back({r.reg_beg, r.reg_end}); }
+    if (reg.empty()) return (float)(0.0 / read_len);
+    std::stable_sort(reg.begin(), reg.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    int cov = 0; size_t cur = 0;
+    for (size_t i = 1; i < reg.size(); ++i) {                              // aln_merg_reg with thd 0, :499
+        if (reg[i].first - reg[cur].second - 1 < 0) { if (reg[i].second > reg[cur].second) reg[cur].second = reg[i].second; }
+        else { ++cur; reg[cur] = reg[i]; }
+    }
+    for (size_t i = 0; i <= cur; ++i) cov += reg[i].second - reg[i].first + 1;
+    return (float)((cov + 0.0) / read_len);
+}
+
+static float cover_rate(int s1, int e1, int s2, int e2)
+{   // src/lamsa_dp_con.c:61-67
+    const int s = s2 > s1 ? s2 : s1, e = e2 < e1 ? e2 : e1;
+    const float rat1 = (float)((e - s + 1 + 0.0) / (e1 - s1 + 1 + 0.0)), rat2 = (float)((e - s + 1 + 0.0) / (e2 - s2 + 1 + 0.0));
+    return rat1 > rat2 ? rat1 : rat2;
+}
+
+// rearr_aln_res, src/lamsa_aln.c:654-724
+void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P)
+{
+    struct Q { int st, li, a, b; };
+    std::vector<Q> qua;
+    for (int st = 0; st < 3; ++st)
+        for (size_t i = 0; i < R.stage[st].size(); ++i) {
+            Line &l = R.stage[st][i];
+            l.xa.clear(); l.mapQ = 0;
+            if (l.tol_score < 0) { l.merg_x = 0; l.merg_y = -1; continue; }
+            qua.push_back({st, (int)i, l.tol_score, l.line_score});
+        }
+    if (qua.empty()) return;
+    std::stable_sort(qua.begin(), qua.end(), [](const Q &x, const Q &y) { return x.a != y.a ? x.a > y.a : x.b > y.b; });   // res_comp :632 on glibc's stable qsort
+    auto L = [&](int i) -> Line & { return R.stage[qua[i].st][qua[i].li]; };
+    std::vector<int> head;
+    std::vector<std::pair<int, int>> reg;                                     // intervals of the accepted heads, in acceptance order
+    for (const Rec &r : L(0).rec) reg.push_back({r.reg_beg, r.reg_end});
+    head.push_back(0);
+    L(0).merg_x = 1; L(0).merg_y = 0;
+    for (size_t i = 0; i < qua.size(); ++i) L((int)i).mapQ = 255;
+    const float cov_f = cov_fraction(R, read_len);
+    const int mapq_max = (int)(254 * cov_f);
+    for (int i = 1; i < (int)qua.size(); ++i) {
+        int cov_qi = -1;
+        for (const Rec &nr : L(i).rec) {                                      // get_cover_res :607-629
+            size_t reg_i = 0;
+            for (int hi : head) {
+                for (size_t j = 0; j < L(hi).rec.size(); ++j, ++reg_i)
+                    if (cover_rate(reg[reg_i].first, reg[reg_i].second, nr.reg_beg, nr.reg_end) >= P.ovlp_rat) { cov_qi = hi; break; }
+                if (cov_qi >= 0) break;
+            }
+            if (cov_qi >= 0) break;
+        }
+        if (cov_qi < 0) {
+            for (const Rec &r : L(i).rec) reg.push_back({r.reg_beg, r.reg_end});
+            head.push_back(i);
+            L(i).merg_x = 1; L(i).merg_y = 0;
+        } else if (qua[i].a > qua[cov_qi].a / 2 && (int)L(cov_qi).xa.size() + (int)L(i).rec.size() - 1 < P.res_mul_max) {
+            for (size_t j = 0; j < L(i).rec.size(); ++j) L(cov_qi).xa.push_back({qua[i].st, qua[i].li, (int)j});
+            L(cov_qi).merg_y = 1;
+            const uint8_t tmpQ = (uint8_t)(mapq_max * (qua[cov_qi].a - qua[i].a) / qua[cov_qi].a);
+            if (tmpQ < L(cov_qi).mapQ) L(cov_qi).mapQ = tmpQ;
+            L(i).merg_x = 2; L(i).merg_y = 0;
+        } else { L(i).merg_x = 0; L(i).merg_y = -1; }
+    }
+    for (size_t i = 0; i < qua.size(); ++i) {
+        Line &l = L((int)i);
+        if (l.merg_x != 1) continue;
+        if (l.mapQ == 255) l.mapQ = (uint8_t)(mapq_max / (int)head.size()); else l.mapQ = (uint8_t)(l.mapQ / (int)head.size());
+    }
+}
+
+// ------------------------------------------------------------------ SAM
+static char comp_char(char c)
+{
+    switch (c) { case 'A': return 'T'; case 'a': return 't'; case 'C': return 'G'; case 'c': return 'g';
+                 case 'G': return 'C'; case 'g': return 'c'; case 'T': return 'A'; case 't': return 'a'; default: return c; }
+}
+static void appendf(std::string &o, const char *fmt, ...)
+{
+    char tmp[256]; va_list ap; va_start(ap, fmt); int n = vsnprintf(tmp, sizeof tmp, fmt, ap); va_end(ap);
+    if (n < (int)sizeof tmp) { o.append(tmp, (size_t)n); return; }
+    std::vector<char> big((size_t)n + 1); va_start(ap, fmt); vsnprintf(big.data(), big.size(), fmt, ap); va_end(ap); o.append(big.data(), (size_t)n);
+}
+
+void sam_header(std::string &o, const Index &ix, const std::string &pg)
+{   // print_sam_header, src/lamsa_aln.c:1215
+    for (size_t i = 0; i < ix.name.size(); ++i) appendf(o, "@SQ\tSN:%s\tLN:%d\n", ix.name[i].c_str(), ix.len[i]);
+    o += pg; o += "\n";
+}
+
+// aln_res_output, src/lamsa_aln.c:1001-1100.  (`-C` with a reverse-strand FASTQ read never terminates in the
+// reference, :1043; here QUAL is printed reversed -- the evident intent, documented divergence.)
+void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt)
+{
+    static const char OPS[] = "MIDNSHP=XB", OPS_HC[] = "MIDNHHP=XB";
+    const int read_len = (int)rd.seq.size();
+    const bool with_qual = rd.has_qual && opt.comm;
+    int all = 0; bool prim = false;
+    for (int st = 0; st < 3; ++st)
+        for (const Line &la : R.stage[st]) {
+            if (la.merg_x != 1) continue;
+            for (size_t j = 0; j < la.rec.size(); ++j) {
+                const Rec &r = la.rec[j];
+                ++all;
+                int flag = r.nstrand ? 0 : 0x10;
+                const bool soft = !prim || opt.supp_soft;
+                if (!soft) flag |= 0x800;
+                appendf(o, "%s\t%d\t%s\t%lld\t%d\t", rd.name.c_str(), flag, ix.name[(size_t)r.chr - 1].c_str(), (long long)r.offset, (int)la.mapQ);
+                for (int32_t w : r.cigar) appendf(o, "%d%c", w >> 4, (soft ? OPS : OPS_HC)[w & 0xf]);
+                o += "\t*\t0\t0\t";
+                const int b = soft ? 0 : r.reg_beg - 1, e = soft ? read_len : r.reg_end;
+                if (r.nstrand == 1) o.append(rd.seq, (size_t)b, (size_t)(e - b)); else for (int si = e - 1; si >= b; --si) o.push_back(comp_char(rd.seq[(size_t)si]));
+                o.push_back('\t');
+                if (with_qual) { if (r.nstrand == 1) o.append(rd.qual, (size_t)b, (size_t)(e - b)); else for (int si = e - 1; si >= b; --si) o.push_back(rd.qual[(size_t)si]); }
+                else o.push_back('*');
+                if (soft) prim = true;
+                appendf(o, "\tNM:i:%d\tAS:i:%d", r.NM, r.score);
+                if (j == 0 && !la.xa.empty()) {
+                    o += "\tXA:Z:";
+                    for (const XaRef &x : la.xa) {
+                        const Rec &xr = R.stage[x.st][(size_t)x.li].rec[(size_t)x.ri];
+                        appendf(o, "%s,%c%lld,", ix.name[(size_t)xr.chr - 1].c_str(), "-+"[xr.nstrand], (long long)xr.offset);
+                        for (int32_t w : xr.cigar) appendf(o, "%d%c", w >> 4, OPS[w & 0xf]);
+                        appendf(o, ",%d;", xr.NM);
+                    }
+                }
+                o.push_back('\n');
+            }
+        }
+    if (all == 0) {
+        appendf(o, "%s\t%d\t*\t%lld\t%d\t*\t*\t0\t0\t", rd.name.c_str(), 4, 0LL, 0);
+        o += rd.seq; o.push_back('\t');
+        if (rd.has_qual) o += rd.qual; else o.push_back('*');
+        o.push_back('\n');
+    }
+}
+
+// ------------------------------------------------------------------ chunk loop
+int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats)
+{
+    Index ix; std::string err;
+    if (!load_index(opt.ref_prefix, ix, err)) { fprintf(stderr, "[lamsa_aln] %s\n", err.c_str()); return 1; }
+    const std::string map_path = opt.seed_result.empty() ? opt.reads + ".seed.gem.map" : opt.seed_result;
+    FILE *mapf = fopen(map_path.c_str(), "r");
+    if (!mapf) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
+    FastxReader fx;
+    if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); fclose(mapf); return 1; }
+    lamsa_hp_ref ref; ref.pac = ix.pac.data(); ref.l_pac = ix.l_pac; ref.n_seqs = (int32_t)ix.name.size(); ref.seq_offset = ix.off.data(); ref.seq_len = ix.len.data();
+    lamsa_hp_handle *h = nullptr;
+    int rc = lamsa_hp_create(&h, &P, &ref, opt.device);
+    if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] no usable MI355X / HIP device (lamsa_hp_create: %d); this build has no CPU path\n", rc); fclose(mapf); return 2; }
+    std::string sam;
+    sam_header(sam, ix, pg_line);
+    fwrite(sam.data(), 1, sam.size(), out);
+    Batch B; B.clear();
+    Read rd; bool eof = false; int ret = 0;
+    long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
+    while (!eof && ret == 0) {
+        B.clear();
+        int64_t chunk_bases = 0;
+        while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
+            if (!fx.next(rd)) { eof = true; break; }
+            if (!append_read(B, ix, P, rd, mapf, err)) { fprintf(stderr, "[lamsa_read_seq] %s\n", err.c_str()); ret = 1; break; }
+            chunk_bases += (int64_t)rd.seq.size();
+        }
+        if (ret || B.reads.empty()) break;
+        for (int32_t c : B.h_chr) if (c < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); ret = 1; break; }
+        if (ret) break;
+        lamsa_hp_batch hb;
+        hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
+        hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
+        hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_off = B.h_cig_off.data(); hb.h_cig_n = B.h_cig_n.data(); hb.cig = B.cig.data(); hb.n_cig = (int64_t)B.cig.size();
+        static const int32_t zero32 = 0; static const uint8_t zero8 = 0; static const int64_t zero64 = 0; static const int16_t zero16 = 0; static const int8_t zeroi8 = 0;
+        if (!hb.seed_id) hb.seed_id = &zero32;
+        if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_off = &zero32; hb.h_cig_n = &zero8; }
+        if (!hb.cig) hb.cig = &zero32;
+        if (!hb.read_seq) hb.read_seq = &zero8;
+        lamsa_hp_result res;
+        rc = lamsa_hp_align_batch(h, &hb, &res);
+        if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_align_batch failed: %d %s\n", rc, lamsa_hp_last_error(h)); ret = 2; break; }
+        kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
+        sam.clear();
+        ReadResult R;
+        for (size_t r = 0; r < B.reads.size(); ++r) {
+            const int L = (int)B.reads[r].seq.size();
+            parse_stream(res.stream + res.read_off[r], res.read_len[r], L, R);
+            if (R.status != 0) { ++n_bad; fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow"); }
+            rank_results(R, L, P);
+            write_sam(sam, R, B.reads[r], ix, opt);
+            n_bases += L;
+        }
+        fwrite(sam.data(), 1, sam.size(), out);
+        n_reads += (long)B.reads.size();
+    }
+    lamsa_hp_destroy(h);
+    fclose(mapf);
+    if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms; }
+    return ret;
+}
+
+}  // namespace lamsa

@@ -1,0 +1,62 @@
+// lamsa_host.h -- host side of `lamsa aln` (see lamsa_host.cpp).  Plain C++17; talks to the GPU only through
+// the C-ABI of include/lamsa_hp.h.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/lamsa_hp.h"
+
+namespace lamsa {
+
+struct Index {                       // .ann contig table + .pac (src/bntseq.h bntseq_t, the parts the path reads)
+    std::vector<std::string> name; std::vector<int64_t> off; std::vector<int32_t> len;
+    std::vector<uint8_t> pac; int64_t l_pac = 0;
+    std::map<std::string, int> name_to_id;
+};
+bool load_index(const std::string &prefix, Index &ix, std::string &err);
+
+struct Read { std::string name, seq, qual; bool has_qual = false; };
+
+class FastxReader {
+  public:
+    struct Impl;
+    FastxReader(); ~FastxReader();
+    bool open(const std::string &path);
+    bool next(Read &r);
+  private:
+    Impl *p;
+};
+
+struct Batch {                       // the arrays of lamsa_hp_batch, host side
+    std::vector<Read> reads;
+    std::vector<int64_t> read_off, seed_off, hit_off, h_pos;
+    std::vector<uint8_t> read_seq, h_cig_n;
+    std::vector<int32_t> seed_all, last_len, seed_id, h_chr, h_cig_off, cig;
+    std::vector<int16_t> h_nm, h_len_dif;
+    std::vector<int8_t> h_strand;
+    void clear();
+};
+bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err);
+
+struct Rec { int64_t offset = 0; int chr = 0, nstrand = 0, score = 0, NM = 0, reg_beg = 0, reg_end = 0; std::vector<int32_t> cigar; };   // res_t
+struct XaRef { int st, li, ri; };
+struct Line { int line_score = 0, tol_score = 0, tol_NM = 0, merg_x = 0, merg_y = 0; uint8_t mapQ = 0; std::vector<Rec> rec; std::vector<XaRef> xa; };   // line_aln_res
+struct ReadResult { int status = 0; std::vector<Line> stage[3]; };   // aln_res[3]: first round, remain round, BWT rescue (empty)
+
+void parse_stream(const int32_t *s, int n_words, int read_len, ReadResult &R);
+void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P);
+
+struct Options {
+    std::string ref_prefix, reads, seed_result;
+    int supp_soft = 0, comm = 0, device = 0, n_thread = 1;
+    int chunk_reads = 16384; int64_t chunk_bases = 256ll << 20;     // reads per GPU batch (the reference's CHUNK_READ_N is 128 per thread pool)
+};
+struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0; };
+
+void sam_header(std::string &o, const Index &ix, const std::string &pg);
+void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);
+int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats);
+
+}  // namespace lamsa

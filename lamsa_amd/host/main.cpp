@@ -1,0 +1,93 @@
+// main.cpp -- `lamsa aln` on the MI355X hot path: same command line, scoring options and SAM output as the
+// reference's `lamsa aln` (src/main.c:29-44, src/lamsa_aln.c:1424-1538), including its quirks: `-g` also sets
+// soft clipping (missing break, :1509-1510); `-C` gates QUAL instead of appending the comment (:1037).
+// Differences, all stated at run time: seeding is never started from here (the GEM map <reads>.seed.gem.map
+// must exist: the reference's -N, and -I, are implied); stage (4) (BWT rescue) is not built, so results equal
+// the reference's with `-R 0`; `lamsa index` is left to the reference.
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <getopt.h>
+#include <string>
+#include "lamsa_host.h"
+
+static int usage()
+{
+    fprintf(stderr, "\nUsage:   lamsa aln [options] <ref.fa> <read.fa/fq>\n\n"
+                    "         options of the reference's `lamsa aln` (-t -l -i -p -V -v -s -R -k -f -m -M -O -E -w -b -e -d -x -T -r -g -S -C -o -N -I);\n"
+                    "         additionally --device INT (GPU ordinal), --seed-result FILE (GEM map, default <read>.seed.gem.map), --batch INT (reads per GPU batch)\n\n");
+    return 1;
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc < 2) return usage();
+    if (strcmp(argv[1], "index") == 0) { fprintf(stderr, "[lamsa] index construction is outside the hot path: run the reference's `lamsa index` (BWT + GEM index); this build reads its .ann/.pac files\n"); return 1; }
+    if (strcmp(argv[1], "aln") != 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]); return 1; }
+    std::string pg = std::string("@PG\tID:lamsa\tPN:lamsa\tVN:1.0.0\tCL:") + argv[0];
+    for (int i = 1; i < argc; ++i) { pg += " "; pg += argv[i]; }
+    lamsa_hp_para P; lamsa_hp_para_init(&P);
+    lamsa::Options opt;
+    FILE *out = stdout; char *p; int c;
+    static const struct option lopt[] = {
+        {"thread",1,0,'t'},{"seed-len",1,0,'l'},{"seed-inv",1,0,'i'},{"max-loci",1,0,'p'},{"SV-len",1,0,'V'},{"ovlp-rat",1,0,'v'},
+        {"max-skel",1,0,'s'},{"max-reg",1,0,'R'},{"bwt-kmer",1,0,'k'},{"fastest",0,0,'f'},{"ed-rate",1,0,'e'},{"diff-rate",1,0,'d'},
+        {"mis-rate",1,0,'x'},{"read-type",1,0,'T'},{"match-sc",1,0,'m'},{"mis-pen",1,0,'M'},{"open-pen",1,0,'O'},{"ext-pen",1,0,'E'},
+        {"band-width",1,0,'w'},{"end-bonus",1,0,'b'},{"max-out",1,0,'r'},{"gap-split",1,0,'g'},{"soft-clip",0,0,'S'},{"comment",0,0,'C'},
+        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"seed-result",1,0,1001},{"batch",1,0,1002},{0,0,0,0}};
+    optind = 2;
+    while ((c = getopt_long(argc, argv, "t:l:i:p:V:v:s:R:k:fm:M:O:E:w:b:e:d:x:T:r:g:SCo:hHNI", lopt, NULL)) >= 0) {
+        switch (c) {
+        case 't': opt.n_thread = atoi(optarg); break;
+        case 'l': P.seed_len = atoi(optarg); break;
+        case 'i': P.seed_step = atoi(optarg); break;
+        case 'p': P.per_aln_m = atoi(optarg); break;
+        case 'V': P.SV_len_thd = atoi(optarg); break;
+        case 'v': P.ovlp_rat = (float)atof(optarg); if (P.ovlp_rat < 0 || P.ovlp_rat > 1) return usage(); break;
+        case 's': P.ske_max = atoi(optarg); break;
+        case 'R': P.bwt_max_len = atoi(optarg); break;
+        case 'k': P.bwt_seed_len = atoi(optarg); break;
+        case 'f': break;
+        case 'm': P.match = atoi(optarg); break;
+        case 'M': P.mis = atoi(optarg); break;
+        case 'O': P.ins_gapo = P.del_gapo = P.ins_ext_o = P.del_ext_o = (int)strtol(optarg, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.del_gapo = (int)strtol(p + 1, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.ins_ext_o = (int)strtol(p + 1, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.del_ext_o = (int)strtol(p + 1, &p, 10);
+                  break;
+        case 'E': P.ins_gape = P.del_gape = P.ins_ext_e = P.del_ext_e = (int)strtol(optarg, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.del_gape = (int)strtol(p + 1, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.ins_ext_e = (int)strtol(p + 1, &p, 10);
+                  if (*p != 0 && ispunct((unsigned char)*p) && isdigit((unsigned char)p[1])) P.del_ext_e = (int)strtol(p + 1, &p, 10);
+                  break;
+        case 'w': P.band_w = atoi(optarg); break;
+        case 'b': P.end_bonus = atoi(optarg); break;
+        case 'e': case 'x': break;                                  // GEM seeding rates: not used on this path
+        case 'd': P.id_rate = (float)atof(optarg); break;
+        case 'T': if (!strcmp(optarg, "pacbio")) P.read_type = 1; else if (!strcmp(optarg, "ont2d")) P.read_type = 2;
+                  else { fprintf(stderr, "[lamsa_aln] Unkown parameter: %s\n", optarg); return usage(); } break;
+        case 'r': P.res_mul_max = atoi(optarg); break;
+        case 'g': P.split_len = atoi(optarg);                        // falls through, as in the reference
+                  /* fall through */
+        case 'S': opt.supp_soft = 1; break;
+        case 'C': opt.comm = 1; break;
+        case 'o': out = fopen(optarg, "w"); if (!out) { fprintf(stderr, "[lamsa_aln] Can not open output file: %s.\n", optarg); return 1; } break;
+        case 'N': case 'I': break;
+        case 1000: opt.device = atoi(optarg); break;
+        case 1001: opt.seed_result = optarg; break;
+        case 1002: opt.chunk_reads = atoi(optarg) > 0 ? atoi(optarg) : opt.chunk_reads; break;
+        default: return usage();
+        }
+    }
+    lamsa_hp_para_finish(&P);
+    if (argc - optind != 2) return usage();
+    opt.ref_prefix = argv[optind]; opt.reads = argv[optind + 1];
+    if (P.bwt_max_len != 0) fprintf(stderr, "[lamsa_aln] note: stage 4 (BWT rescue of uncovered gaps <= -R %d bp) is not part of this build; output equals the reference's with -R 0\n", P.bwt_max_len);
+    lamsa::Stats st;
+    fprintf(stderr, "[lamsa_aln] Mapping reads to genome ...\n");
+    int rc = lamsa::run_aln(opt, P, out, pg, &st);
+    fprintf(stderr, "[lamsa_aln] Mapping done! %ld reads, %ld bases, GPU kernels %.1f ms%s\n", st.n_reads, st.n_bases, st.kernel_ms, st.n_bad ? " (some reads reported unmapped, see above)" : "");
+    if (out != stdout) fclose(out);
+    return rc;
+}

@@ -186,6 +186,22 @@ def emu():
     return _emu
 
 
+def emu_cli():
+    """tests/_build/lamsa_emu: the product's host program (lamsa_amd/host) linked against the emulated C-ABI
+    (tests/emu/emu_capi.cpp) instead of liblamsa_hp.so -- exercises file IO, GEM parsing, ranking and SAM on the CPU."""
+    os.makedirs(EMU_DIR, exist_ok=True)
+    out = os.path.join(EMU_DIR, "lamsa_emu")
+    host = os.path.join(ROOT, "lamsa_amd", "host")
+    srcs = [os.path.join(host, "main.cpp"), os.path.join(host, "lamsa_host.cpp"),
+            os.path.join(ROOT, "tests", "emu", "emu_api.cpp"), os.path.join(ROOT, "tests", "emu", "emu_capi.cpp")]
+    deps = srcs + [os.path.join(host, "lamsa_host.h"), os.path.join(ROOT, "include", "lamsa_hp.h"), os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
+        [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "emu"),
+                        "-I", os.path.join(ROOT, "lamsa_amd", "csrc"), "-o", out] + srcs + ["-lz", "-lpthread"], check=True)
+    return out
+
+
 def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
     """Run DP jobs through the emulated device code (same kernel sources, CPU lanes)."""
     import sys

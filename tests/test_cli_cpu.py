@@ -1,0 +1,52 @@
+"""The `lamsa aln` host program (lamsa_amd/host): FASTA/FASTQ + GEM-map parsing, result ranking / MAPQ / XA and
+the SAM writer, byte-for-byte against the reference's SAM (tests/golden/*/golden_R0.sam, made by the reference
+binary with `-R 0`; tools/make_golden_reads.py).  On the CPU the host program is linked against the emulated
+C-ABI (tests/emu); tests/test_cli_gpu.py runs the product binary on the MI355X."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import goldenlib as G
+import reflib
+
+
+@pytest.fixture(scope="module")
+def cli():
+    return reflib.emu_cli()
+
+
+@pytest.mark.parametrize("name", G.SCENARIOS)
+def test_sam_identical_to_reference(cli, name, tmp_path):
+    ref, reads, args, gold = G.stage_scenario(name, str(tmp_path))
+    p = subprocess.run([cli, "aln", "-R", "0"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "@PG\tID:lamsa" in p.stdout
+    assert G.strip_pg(p.stdout) == G.strip_pg(gold)
+
+
+def test_output_file_small_batches_and_gz_reads(cli, tmp_path):
+    """-o FILE; reads given gzipped; --batch smaller than the file (several chunks) -- same SAM."""
+    ref, reads, args, gold = G.stage_scenario("c5_sv", str(tmp_path))
+    gz = reads + ".gz"
+    with open(reads, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    shutil.move(reads + ".seed.gem.map", gz + ".seed.gem.map")
+    out = str(tmp_path / "out.sam")
+    p = subprocess.run([cli, "aln", "-R", "0", "--batch", "3", "-o", out] + args + [ref, gz], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(open(out).read()) == G.strip_pg(gold)
+
+
+def test_error_paths(cli, tmp_path):
+    ref, reads, args, gold = G.stage_scenario("c1_perfect", str(tmp_path))
+    assert subprocess.run([cli], capture_output=True).returncode == 1                                  # usage
+    assert subprocess.run([cli, "aln", ref], capture_output=True).returncode == 1                       # one positional argument only
+    assert subprocess.run([cli, "aln", "-T", "nanopore", ref, reads], capture_output=True).returncode == 1
+    assert subprocess.run([cli, "aln", "-v", "1.5", ref, reads], capture_output=True).returncode == 1
+    assert subprocess.run([cli, "aln", str(tmp_path / "nope.fa"), reads], capture_output=True).returncode != 0
+    os.remove(reads + ".seed.gem.map")                                                                 # no seeding results: must say so, not run
+    p = subprocess.run([cli, "aln", ref, reads], capture_output=True, text=True)
+    assert p.returncode != 0 and "gem" in p.stderr.lower()
