@@ -67,6 +67,30 @@ def count_mapped_bases(B, streams):
     return tot
 
 
+def shard_seed(rank):
+    """Every rank simulates its own shard of the read stream (same reference, different reads)."""
+    return 1000 + rank
+
+
+def reduce_job(dt, totals, world, device=None):
+    """Whole-job figures from per-rank ones: MAX of the timed region, SUM of the per-rank counters.
+    The only collectives of the bench -- the data path has none (reads are independent)."""
+    if world <= 1:
+        return float(dt), np.asarray(totals, dtype=np.float64)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor(np.asarray(totals, dtype=np.float64), dtype=torch.float64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), c.cpu().numpy()
+
+
+def job_rates(dt, totals, steps):
+    """(reads/s, aligned Gbase/s) of the whole job; totals = [reads, mapped bases, bases, failed reads] per step, summed over ranks."""
+    return totals[0] * steps / dt, totals[1] * steps / dt / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +125,7 @@ def main():
     ref = simbatch.SimRef(a.ref_bp, n_contigs=24, seed=5, threads=threads, repeats=not a.no_repeats)
     t_ref = time.time() - t0
     t0 = time.time()
-    B = simbatch.SimBatch(ref, a.reads, wl["length"], wl["profile"], seed=1000 + rank, threads=threads)
+    B = simbatch.SimBatch(ref, a.reads, wl["length"], wl["profile"], seed=shard_seed(rank), threads=threads)
     t_gen = time.time() - t0
 
     P = hp.make_para(wl["read_type"], **wl["over"])
@@ -126,22 +150,11 @@ def main():
     stream, r_off, r_len, status = raw
     tbases = np.array(h.last_tbases, copy=True); status = np.array(status, copy=True)
     streams = [stream[int(r_off[i]):int(r_off[i]) + int(r_len[i])].tolist() for i in range(a.reads)]   # untimed: parsing for the report
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
     n_bases = int(B.read_off[-1])
     mapped_bases = count_mapped_bases(B, streams)
     n_fail = int((status != 0).sum())
-    # whole-job totals over ranks
-    tot = np.array([a.reads, mapped_bases, n_bases, n_fail], dtype=np.float64)
-    if world > 1:
-        t = torch.tensor(tot, dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        tot = t.cpu().numpy()
-    reads_per_s = tot[0] * a.steps / dt
-    gbase_per_s = tot[1] * a.steps / dt / 1e9
+    dt, tot = reduce_job(dt, [a.reads, mapped_bases, n_bases, n_fail], world, device="cuda" if world > 1 else None)   # whole-job totals over ranks
+    reads_per_s, gbase_per_s = job_rates(dt, tot, a.steps)
 
     if rank == 0:
         alg_bytes, parts = algorithmic_bytes(B, streams, tbases)
@@ -150,6 +163,8 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
                 "kernel": "k_align_batch", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
+        # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
+        t0 = time.perf_counter(); h.upload_batch(B); h.run_uploaded(fetch=True, raw=True); t_pcie = time.perf_counter() - t0
         cpu = None
         if a.cpu_seconds > 0:
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
@@ -171,7 +186,7 @@ def main():
             "config": {"workload": "%s: %d reads/step/GPU x %d bp; reference stand-in %d bp in 24 contigs, %d repeat copies; seed hits simulated "
                                    "(GEM thresholds, <=200/seed): %.1f hits/seed, %.0f hits/read" % (a.workload, a.reads, wl["length"], ref.l_pac, ref.n_copies, hits.mean() if len(hits) else 0, B.n_hits / max(1, a.reads)),
                        "reads_per_step_per_gpu": a.reads, "read_len": wl["length"], "read_type": wl["read_type"], "parallelism": "reads sharded over %d GPU(s), no collectives" % a.gpus},
-            "reads_not_ok": int(tot[3]), "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
+            "reads_not_ok": int(tot[3]), "pcie_inclusive_reads_per_s": round(a.reads / t_pcie, 2), "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
