@@ -205,8 +205,56 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 // ---------------------------------------------------------------- frag_dp_update, :701-764, over a range of targets
 // Targets k0..k1-1 are updated strictly in order (the son_flag side effect of a chosen predecessor is visible to
 // the next target).  `force`: update node k0 whatever its dp_flag (the right anchor of a mini-DP, :1129); otherwise
-// only nodes whose dp_flag equals `dp_flag`.  Per target: one load trip for its own record, the predecessor scan
-// (256 predecessors per trip, per-lane running best), two DPP reductions, one trip for the winner, the stores.
+// only nodes whose dp_flag equals `dp_flag`.
+//
+// Latency structure (this loop is where most of the read's time goes; every dependent HBM/L2 round trip counts):
+//   * the 64 targets of a chunk load their own records once, one per lane; a target's record then comes out of
+//     those registers by readlane (a target's record is never written by an earlier target of the pass);
+//   * candidates are the target's neighbours in the (contig, strand, position) order (see below); the sort-index
+//     entries of the NEXT target are fetched while the current one is evaluated, and the next target's candidate
+//     records are requested right after the current target's own stores, so that they travel together with the
+//     son-list bookkeeping loads of the current target;
+//   * every lane remembers node id and edge class of its running best, so the winner is read out of a lane
+//     instead of being re-fetched.
+// One dependent round trip per target instead of seven.
+struct ScanT { NodeS T; int tkey, x, t_NM; long long Rw; };
+
+HP_INL NodeS node_unpack(const int *a, const int *b)
+{
+    NodeS q;
+    q.pos = (int64_t)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]); q.chr = a[2]; q.slot_j = a[3];
+    q.sid = (int16_t)(b[0] & 0xffff); q.strand = (int8_t)((b[0] >> 16) & 0xff); q.len_dif8 = (int8_t)((b[0] >> 24) & 0xff);
+    q.dp_flag = (int8_t)(b[1] & 0xff); q.son_flag = (uint8_t)((b[1] >> 8) & 0xff); q.match_flag = (uint8_t)((b[1] >> 16) & 0xff); q.pad_ = 0;
+    q.score = b[2]; q.NM = b[3];
+    return q;
+}
+
+// one candidate predecessor Q (node id p) against target T; per-lane running bests are updated in place
+HP_INL void scan_eval(const EdgeK &K, const ScanT &S, const NodeS &Q, int p, int inb, int start_slot, int dp_flag,
+                      long long &key, int &bp, int &bf, int &negp, int &n_p, int &n_f, int &n_c, int &n_n, int &outw, int &oka)
+{
+    const int POSMAX = (1 << 28) - 1;
+    long long dp = Q.pos - S.T.pos; if (dp < 0) dp = -dp;
+    const int inwin = inb & ((Q.chr * 2 + (Q.strand > 0 ? 1 : 0)) == S.tkey) & (dp <= S.Rw);
+    outw = !inwin;
+    const int qslot = Q.slot_j >> 14;
+    const int flag = edge_flag_packed(K, Q, S.T);
+    const int ok = inwin & (qslot >= start_slot) & (qslot < S.x) & (Q.dp_flag == dp_flag) & !((Q.strand == 1) & (Q.son_flag <= F_MATCH_THD)) &
+                   (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
+    const int pos = ((S.x - 1 - qslot) << 14) | (Q.slot_j & 16383);            // scan order: seeds descending, hits ascending
+    const int cand = Q.score + 1 + score_table(flag);
+    const int nm = Q.NM + S.t_NM;
+    const int isneg = ok & (Q.strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733
+    const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
+    const long long kk = ok ? k : -1;
+    const bool better = kk > key;
+    key = better ? kk : key; bp = better ? p : bp; bf = better ? flag : bf;
+    const int np = isneg ? -pos : -0x7fffffff;
+    const bool nb = np > negp;
+    negp = nb ? np : negp; n_p = nb ? p : n_p; n_f = nb ? flag : n_f; n_c = nb ? cand : n_c; n_n = nb ? nm : n_n;
+    oka |= ok;
+}
+
 HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
@@ -214,149 +262,194 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from;
     HP_G int32_t *g_node_n = (HP_G int32_t *)r.n_node_n, *g_in_de = (HP_G int32_t *)r.n_in_de, *g_son_n = (HP_G int32_t *)r.n_son_n;
     HP_G int32_t *g_first = (HP_G int32_t *)r.n_first, *g_last = (HP_G int32_t *)r.n_last, *g_next = (HP_G int32_t *)r.n_next;
-    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
-    const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
-    const int lo = (int)(g_hoff[start_slot] - hb);
-    const int POSMAX = (1 << 28) - 1;
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
     const int sid_lo = start_slot < r.seed_out ? r.seed_id[start_slot] : 0;
+    const int H = r.H;
     for (int tb = k0; tb < k1; tb += 64) {
-        unsigned long long todo;
-        if (force) todo = 1ull;
-        else {
-            // one target per lane: is it due in this pass, and does it have any neighbour (in sorted order) inside its
-            // window?  A target without one has no connectable predecessor at all and keeps its state (exact skip).
-            wv::Lane<int> c;
-            WAVE_FOR(l) {
-                const int k = tb + l;
-                int due = 0;
-                const NodeS Tk = node_load(ns + (k < k1 ? k : k0));
+        // ---- one target per lane: its record, rank and predecessor; is it due in this pass, and does it have any
+        // neighbour (in sorted order) inside its window?  A target without one has no connectable predecessor at all
+        // and keeps its state (exact skip).
+        wv::Lane<int> Ta0, Ta1, Ta2, Ta3, Tb0, Tb1, Tb2, Tb3, Trk, Tfrom, c;
+        WAVE_FOR(l) {
+            const int k = tb + l, kk = k < k1 ? k : k0;
+            int a[4], b[4];
+            hp_load16(ns + kk, a); hp_load16((const HP_G char *)(ns + kk) + 16, b);
+            const int rk = g_rnk[kk];
+            Ta0[l] = a[0]; Ta1[l] = a[1]; Ta2[l] = a[2]; Ta3[l] = a[3]; Tb0[l] = b[0]; Tb1[l] = b[1]; Tb2[l] = b[2]; Tb3[l] = b[3];
+            Trk[l] = rk; Tfrom[l] = g_from[kk];
+            int due = 0;
+            if (!force) {
+                const NodeS Tk = node_unpack(a, b);
                 if (k < k1 && Tk.dp_flag == dp_flag) {
                     const int dm = Tk.sid - sid_lo;
                     const int mdm_ = K.match_dis * (K.high_err ? dm : 1);
                     long long Rk = K.sv_len > dm * K.seed_step ? K.sv_len : dm * K.seed_step;
                     if (mdm_ + 1 > Rk) Rk = mdm_ + 1;
                     Rk += 128 + (long long)dm * K.seed_step;
-                    const int rk = g_rnk[k], tk_ = Tk.chr * 2 + (Tk.strand > 0 ? 1 : 0);
+                    const int tk_ = Tk.chr * 2 + (Tk.strand > 0 ? 1 : 0);
 #pragma unroll
                     for (int d = -1; d <= 1; d += 2) {
                         const int i2 = rk + d;
-                        if (i2 >= 0 && i2 < r.H) {
+                        if (i2 >= 0 && i2 < H) {
                             const NodeS Nb = node_load(ns + g_srt[i2]);
                             long long dp_ = Nb.pos - Tk.pos; if (dp_ < 0) dp_ = -dp_;
                             due |= ((Nb.chr * 2 + (Nb.strand > 0 ? 1 : 0)) == tk_) & (dp_ <= Rk);
                         }
                     }
                 }
-                c[l] = due;
             }
-            todo = wv::ballot(c);
+            c[l] = due;
         }
-        while (todo) {
-            const int t = tb + __builtin_ctzll(todo); todo &= todo - 1;
+        unsigned long long todo = force ? 1ull : wv::ballot(c);
+        if (!todo) continue;
+        // ---- software pipeline over the due targets of the chunk
+        int li = __builtin_ctzll(todo);
+        wv::Lane<int> pn0, pn1;                          // sort-index entries of the current target, first trip
+        wv::Lane<int> Qa[2][4], Qb[2][4];                // and the candidate records they name
+        {
+            const int rT = wv::bcast(Trk, li);
+            WAVE_FOR(l) {
+                const int i0 = rT - 1 - l, i1 = rT + 1 + l;
+                pn0[l] = g_srt[i0 >= 0 ? i0 : rT]; pn1[l] = g_srt[i1 < H ? i1 : rT];
+            }
+            WAVE_FOR(l) {
+                int a[4], b[4];
+                hp_load16(ns + pn0[l], a); hp_load16((const HP_G char *)(ns + pn0[l]) + 16, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { Qa[0][q][l] = a[q]; Qb[0][q][l] = b[q]; }
+                hp_load16(ns + pn1[l], a); hp_load16((const HP_G char *)(ns + pn1[l]) + 16, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { Qa[1][q][l] = a[q]; Qb[1][q][l] = b[q]; }
+            }
+        }
+        for (;;) {
+            const int t = tb + li;
 #ifdef HP_PROF
             if (r.prof) r.prof[11] += 1;
 #endif
-            const NodeS T = node_load(ns + t);
-            const int x = T.slot_j >> 14;
-            const int hi = (int)(g_hoff[x] - hb);
-            const int t_NM = T.NM, t_from = g_from[t], t_score = T.score;
-            wv::Lane<long long> key;
-            wv::Lane<int> negp;
-            WAVE_FOR(l) { key[l] = -1; negp[l] = -0x7fffffff; }
-            int neg_pos = 0x7fffffff;                    // scan position of the first '-' strand match precursor
+            ScanT S;
+            {
+                int a[4] = { wv::bcast(Ta0, li), wv::bcast(Ta1, li), wv::bcast(Ta2, li), wv::bcast(Ta3, li) };
+                int b[4] = { wv::bcast(Tb0, li), wv::bcast(Tb1, li), wv::bcast(Tb2, li), wv::bcast(Tb3, li) };
+                S.T = node_unpack(a, b);
+            }
+            const int rT = wv::bcast(Trk, li), t_from = wv::bcast(Tfrom, li);
+            S.x = S.T.slot_j >> 14; S.t_NM = S.T.NM; S.tkey = S.T.chr * 2 + (S.T.strand > 0 ? 1 : 0);
             // Predecessors that get_fseed_dis can connect at all lie on the same contig and strand within R bases of
             // the target (|dis| < max(SV_len_thd, did*step, mat_dis) and |act-exp| <= |dis|+|len_dif|, exp within
             // did*step of the predecessor).  In the (contig, strand, position) order they are the neighbours of the
-            // target itself, so the scan walks outwards from the target's rank, 128 hits per trip and direction,
+            // target itself, so the scan walks outwards from the target's rank, 64 hits per trip and direction,
             // and stops at the first hit outside the window.  Everything else is F_CHR_DIF / F_UNCONNECT for the
             // reference too, hence the result is unchanged.
-            const int did_max = T.sid - sid_lo;
-            const int mdm = K.match_dis * (K.high_err ? did_max : 1);
-            long long Rw = K.sv_len > did_max * K.seed_step ? K.sv_len : did_max * K.seed_step;
-            if (mdm + 1 > Rw) Rw = mdm + 1;
-            Rw += 128 + (long long)did_max * K.seed_step;
-            const int rT = g_rnk[t];
-            const int tkey = T.chr * 2 + (T.strand > 0 ? 1 : 0);
-            // u = 0 walks down the sorted order, u = 1 up; trip c covers the c-th 64 hits on either side
-            bool live0 = hi > lo, live1 = hi > lo;
-            int any_ok = 0;
-            for (int c = 0; live0 || live1; ++c) {
+            {
+                const int did_max = S.T.sid - sid_lo;
+                const int mdm = K.match_dis * (K.high_err ? did_max : 1);
+                long long Rw = K.sv_len > did_max * K.seed_step ? K.sv_len : did_max * K.seed_step;
+                if (mdm + 1 > Rw) Rw = mdm + 1;
+                S.Rw = Rw + 128 + (long long)did_max * K.seed_step;
+            }
+            todo &= todo - 1;
+            const bool has_next = todo != 0;
+            const int li2 = has_next ? __builtin_ctzll(todo) : li;
+            wv::Lane<int> pm0, pm1;                      // prefetch: the next target's sort-index entries
+            if (has_next) {
+                const int rT2 = wv::bcast(Trk, li2);
+                WAVE_FOR(l) {
+                    const int i0 = rT2 - 1 - l, i1 = rT2 + 1 + l;
+                    pm0[l] = g_srt[i0 >= 0 ? i0 : rT2]; pm1[l] = g_srt[i1 < H ? i1 : rT2];
+                }
+            }
+            wv::Lane<long long> key;
+            wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, out0, out1, okl;
+            WAVE_FOR(l) {                                // first trip: the records are already here
+#ifdef HP_PROF
+                if (l == 0 && r.prof) r.prof[12] += 1;
+#endif
+                key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0;
+                int ow[2], oka = 0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int a[4], b[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[q] = Qa[u][q][l]; b[q] = Qb[u][q][l]; }
+                    const NodeS Q = node_unpack(a, b);
+                    const int idx = u ? rT + 1 + l : rT - 1 - l;
+                    scan_eval(K, S, Q, u ? pn1[l] : pn0[l], idx >= 0 && idx < H, start_slot, dp_flag,
+                              key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow[u], oka);
+                }
+                out0[l] = ow[0]; out1[l] = ow[1]; okl[l] = oka;
+            }
+            // sorted order: once a hit is outside the window, all farther ones on that side are
+            bool live0 = wv::ballot(out0) == 0, live1 = wv::ballot(out1) == 0;
+            int any_ok = wv::ballot(okl) != 0;
+            for (int cc = 1; live0 || live1; ++cc) {     // wide windows (repeat clusters): further trips, fetched directly
 #ifdef HP_PROF
                 if (r.prof) r.prof[12] += 1;
 #endif
-                wv::Lane<int> out0, out1, okl;
                 WAVE_FOR(l) {
                     int idx[2], inb[2], pn[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        idx[u] = rT + (u ? 1 : -1) * (1 + c * 64 + l);
-                        inb[u] = (u ? live1 : live0) && idx[u] >= 0 && idx[u] < r.H;
+                        idx[u] = rT + (u ? 1 : -1) * (1 + cc * 64 + l);
+                        inb[u] = (u ? live1 : live0) && idx[u] >= 0 && idx[u] < H;
                         pn[u] = g_srt[inb[u] ? idx[u] : rT];
                     }
-                    NodeS Q[2]; int dflag[2], sflag[2], pscore[2], pnm[2];
+                    NodeS Q[2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        Q[u] = node_load(ns + pn[u]);
-                        dflag[u] = Q[u].dp_flag; sflag[u] = Q[u].son_flag; pscore[u] = Q[u].score; pnm[u] = Q[u].NM;
-                    }
+                    for (int u = 0; u < 2; ++u) Q[u] = node_load(ns + pn[u]);
                     int ow[2], oka = 0;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        long long dp = Q[u].pos - T.pos; if (dp < 0) dp = -dp;
-                        const int inwin = inb[u] & ((Q[u].chr * 2 + (Q[u].strand > 0 ? 1 : 0)) == tkey) & (dp <= Rw);
-                        ow[u] = !inwin;
-                        const int qslot = Q[u].slot_j >> 14;
-                        const int flag = edge_flag_packed(K, Q[u], T);
-                        const int ok = inwin & (qslot >= start_slot) & (qslot < x) & (dflag[u] == dp_flag) & !((Q[u].strand == 1) & (sflag[u] <= F_MATCH_THD)) &
-                                       (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
-                        const int pos = ((x - 1 - qslot) << 14) | (Q[u].slot_j & 16383);            // scan order: seeds descending, hits ascending
-                        const int cand = pscore[u] + 1 + score_table(flag);
-                        const int nm = pnm[u] + t_NM;
-                        const int isneg = ok & (Q[u].strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733
-                        const long long k = ((long long)(cand + 32768) << 47) | ((long long)(524287 - nm) << 28) | (long long)(POSMAX - pos);
-                        const long long kk = ok ? k : -1;
-                        key[l] = kk > key[l] ? kk : key[l];
-                        const int np = isneg ? -pos : -0x7fffffff;
-                        negp[l] = np > negp[l] ? np : negp[l];
-                        oka |= ok;
-                    }
+                    for (int u = 0; u < 2; ++u)
+                        scan_eval(K, S, Q[u], pn[u], inb[u], start_slot, dp_flag, key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow[u], oka);
                     out0[l] = ow[0]; out1[l] = ow[1]; okl[l] = oka;
                 }
-                // sorted order: once a hit is outside the window, all farther ones on that side are
                 if (live0 && wv::ballot(out0) != 0) live0 = false;
                 if (live1 && wv::ballot(out1) != 0) live1 = false;
                 any_ok |= wv::ballot(okl) != 0;
             }
-            if (!any_ok) continue;                        // no connectable predecessor: the node keeps its state
-            int max_from = t_from, max_score = t_score, max_NM = t_NM, max_flag = 0;
+            int max_from = t_from, max_score = S.T.score, max_NM = S.t_NM, max_flag = 0;
             bool changed = false;
-            if (hi > lo) {
-                const int np = -wv::reduce_max(negp);
-                if (np < neg_pos) neg_pos = np;
-                const long long best_key = wv::reduce_max64(key);
-                if (neg_pos != 0x7fffffff) {
-                    const int i = x - 1 - (neg_pos >> 14), j = neg_pos & 16383, p = (int)(g_hoff[i] - hb) + j;
-                    const NodeS Q = node_load(ns + p);
-                    const int flag = edge_flag_packed(K, Q, T);
-                    max_from = p; max_score = Q.score + 1 + score_table(flag); max_flag = flag; max_NM = Q.NM + t_NM;
+            if (any_ok) {                                 // otherwise no connectable predecessor: the node keeps its state
+                const int npos = wv::reduce_max(negp);
+                if (npos != -0x7fffffff) {                // '-' strand: the first match precursor in scan order
+                    wv::Lane<int> w;
+                    WAVE_FOR(l) w[l] = negp[l] == npos;
+                    const int wl = __builtin_ctzll(wv::ballot(w));
+                    max_from = wv::bcast(n_p, wl); max_flag = wv::bcast(n_f, wl); max_score = wv::bcast(n_c, wl); max_NM = wv::bcast(n_n, wl);
                     changed = max_from != t_from;
-                } else if (best_key >= 0) {
-                    const int pos = POSMAX - (int)(best_key & POSMAX);
-                    const int nm = 524287 - (int)((best_key >> 28) & 524287);
-                    const int cand = (int)(best_key >> 47) - 32768;
-                    if (cand > max_score || (cand == max_score && nm < max_NM)) {
-                        const int i = x - 1 - (pos >> 14), j = pos & 16383, p = (int)(g_hoff[i] - hb) + j;
-                        const NodeS Q = node_load(ns + p);
-                        max_from = p; max_score = cand; max_NM = nm; max_flag = edge_flag_packed(K, Q, T);
-                        changed = max_from != t_from;
+                } else {
+                    const long long best_key = wv::reduce_max64(key);
+                    if (best_key >= 0) {
+                        const int nm = 524287 - (int)((best_key >> 28) & 524287);
+                        const int cand = (int)(best_key >> 47) - 32768;
+                        if (cand > max_score || (cand == max_score && nm < max_NM)) {
+                            wv::Lane<int> w;
+                            WAVE_FOR(l) w[l] = key[l] == best_key;
+                            const int wl = __builtin_ctzll(wv::ballot(w));
+                            max_from = wv::bcast(bp, wl); max_flag = wv::bcast(bf, wl); max_score = cand; max_NM = nm;
+                            changed = max_from != t_from;
+                        }
                     }
                 }
             }
             if (changed) {                               // wave-uniform stores (:753-761); every lane re-reads only what it wrote itself
                 gd[max_from].son_flag = (uint8_t)max_flag;
                 g_from[t] = max_from; gd[t].score = max_score; gd[t].NM = max_NM; gd[t].match_flag = (uint8_t)max_flag;
+            }
+            if (has_next) {                              // the next target's candidates, after the stores they may have to see
+                WAVE_FOR(l) {
+                    int a[4], b[4];
+                    hp_load16(ns + pm0[l], a); hp_load16((const HP_G char *)(ns + pm0[l]) + 16, b);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { Qa[0][q][l] = a[q]; Qb[0][q][l] = b[q]; }
+                    hp_load16(ns + pm1[l], a); hp_load16((const HP_G char *)(ns + pm1[l]) + 16, b);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { Qa[1][q][l] = a[q]; Qb[1][q][l] = b[q]; }
+                    pn0[l] = pm0[l]; pn1[l] = pm1[l];
+                }
+            }
+            if (changed) {
                 g_node_n[t] = g_node_n[max_from] + 1;
                 const int sn = g_son_n[max_from], la = g_last[max_from];      // fnode_add_son, :683
                 g_in_de[max_from] = g_in_de[max_from] + 1;
@@ -365,6 +458,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
                 g_last[max_from] = t;
                 g_son_n[max_from] = sn + 1;
             }
+            if (!has_next) break;
+            li = li2;
         }
     }
 }
