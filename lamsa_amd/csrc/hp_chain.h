@@ -168,7 +168,9 @@ HP_INL int edge_flag_packed(const EdgeK &k, const NodeS &pre, const NodeS &cur)
 
 // frag_dp_per_init over a whole range of nodes, one node per lane.
 // which == 0: nodes whose dp_flag is +-dp_flag (frag_mini_dp_line, :1086-1091); which == 1: every node that is not TRACKED (:946-951)
-HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, int which)
+// rlo..rhi: when from < 0, only nodes whose rank in the (contig, strand, position) order lies in [rlo, rhi] become
+// active; the others are marked unreachable exactly like nodes that cannot be connected to `from` (see mini_line).
+HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, int which, int rlo = 0, int rhi = 0x7fffffff)
 {
 #ifdef HP_PROF
     const long long t0_ = wv::clock();
@@ -185,8 +187,11 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
                 const int df = r.nd[k].dp_flag;
                 const bool take = which == 0 ? (df == dp_flag || df == 0 - dp_flag) : (df != TRACKED_FLAG);
                 if (take) {
-                    if (from < 0) node_set(r, k, from, 1, r.h_nm[k], F_MATCH, dp_flag);
-                    else {
+                    if (from < 0) {
+                        const int rk = rhi == 0x7fffffff ? 0 : r.rnk[k];
+                        if (rk >= rlo && rk <= rhi) node_set(r, k, from, 1, r.h_nm[k], F_MATCH, dp_flag);
+                        else r.nd[k].dp_flag = (int8_t)(0 - dp_flag);
+                    } else {
                         const NodeS Q = node_load(ns + k);
                         const int flag = k == from ? F_MATCH : edge_flag_packed(K, F, Q);
                         if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, k, from, 2 + score_table(flag), r.h_nm[k] + from_nm, flag, dp_flag);
@@ -217,6 +222,11 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 //   * every lane remembers node id and edge class of its running best, so the winner is read out of a lane
 //     instead of being re-fetched.
 // One dependent round trip per target instead of seven.
+#ifdef HP_EMU_STATS
+void hp_emu_stat_call(int range, int lo, int hi, bool force);
+void hp_emu_stat_due(int range, int due, int span);
+static int g_emu_act = 0;
+#endif
 struct ScanT { NodeS T; int tkey, x, t_NM; long long Rw; };
 
 HP_INL NodeS node_unpack(const int *a, const int *b)
@@ -266,7 +276,14 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
     const int sid_lo = start_slot < r.seed_out ? r.seed_id[start_slot] : 0;
     const int H = r.H;
+#ifdef HP_PROF
+    const long long tu0_ = wv::clock();
+    if (r.prof) { r.prof[19] += 1; if (force) r.prof[23] += 1; }
+#endif
     for (int tb = k0; tb < k1; tb += 64) {
+#ifdef HP_PROF
+        const long long tp0_ = wv::clock();
+#endif
         // ---- one target per lane: its record, rank and predecessor; is it due in this pass, and does it have any
         // neighbour (in sorted order) inside its window?  A target without one has no connectable predecessor at all
         // and keeps its state (exact skip).
@@ -302,7 +319,17 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             c[l] = due;
         }
         unsigned long long todo = force ? 1ull : wv::ballot(c);
+#ifdef HP_EMU_STATS
+        if (tb == k0) { int act_ = 0; for (int q_ = hoff(r, start_slot); q_ < k1; ++q_) act_ += r.nd[q_].dp_flag == dp_flag; g_emu_act = act_; hp_emu_stat_call(k1 - k0, hoff(r, start_slot) , k1, force); }
+        hp_emu_stat_due(k1 - k0, __builtin_popcountll(todo), g_emu_act);
+#endif
+#ifdef HP_PROF
+        if (r.prof) { r.prof[17] += wv::clock() - tp0_; r.prof[22] += 1; }
+#endif
         if (!todo) continue;
+#ifdef HP_PROF
+        const long long tq0_ = wv::clock();
+#endif
         // ---- software pipeline over the due targets of the chunk
         int li = __builtin_ctzll(todo);
         wv::Lane<int> pn0, pn1;                          // sort-index entries of the current target, first trip
@@ -323,6 +350,9 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
                 for (int q = 0; q < 4; ++q) { Qa[1][q][l] = a[q]; Qb[1][q][l] = b[q]; }
             }
         }
+#ifdef HP_PROF
+        if (r.prof) r.prof[18] += wv::clock() - tq0_;
+#endif
         for (;;) {
             const int t = tb + li;
 #ifdef HP_PROF
@@ -462,6 +492,9 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             li = li2;
         }
     }
+#ifdef HP_PROF
+    if (r.prof) r.prof[16] += wv::clock() - tu0_;
+#endif
 }
 HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true); }
 
@@ -660,6 +693,44 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
     ns_add_end(r, ns, max_score, max_NM, max_node);
 }
 
+// ---------------------------------------------------------------- which hits can matter for the chain into `node`
+// A predecessor that get_fseed_dis connects to a target lies on the target's contig and strand within R(target) bases
+// of it, and R(target) <= Rcap for every target of a pass (Rcap = R of the pass's right anchor, which has the largest
+// seed distance).  In the (contig, strand, position) order, the hits that can reach `node` through any number of such
+// edges therefore lie in the run around `node` in which consecutive hits are at most Rcap apart: two hits within Rcap
+// of each other have only gaps <= Rcap between them.  Hits outside that run never connect to a hit inside it, so the DP
+// state of the run (predecessors, scores, the son_flag side effects) is the same whether or not they are processed.
+HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
+    const int H = r.H, rT = r.rnk[node];
+    const NodeS N = node_load(ns + node);
+    const int key = N.chr * 2 + (N.strand > 0 ? 1 : 0);
+    int lo = rT, hi = rT;
+    for (int dir = -1; dir <= 1; dir += 2) {
+        int edge = rT;                                   // last rank known to be in the run
+        for (;;) {
+            wv::Lane<int> bad;
+            WAVE_FOR(l) {
+                const int i = edge + dir * (1 + l), j = i - dir;           // j: the neighbour on the side of `node`
+                int b = 1;
+                if (i >= 0 && i < H) {
+                    const NodeS A = node_load(ns + g_srt[i]), B = node_load(ns + g_srt[j]);
+                    long long d = A.pos - B.pos; if (d < 0) d = -d;
+                    b = !((A.chr * 2 + (A.strand > 0 ? 1 : 0)) == key && d <= Rcap);
+                }
+                bad[l] = b;
+            }
+            const unsigned long long m = wv::ballot(bad);
+            if (m) { edge += dir * __builtin_ctzll(m); break; }
+            edge += dir * 64;
+        }
+        if (dir < 0) lo = edge; else hi = edge;
+    }
+    *rlo = lo; *rhi = hi;
+}
+
 // ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150
 // left / right are node indices (left may be -1 = START); right_x is right's slot, which may be the
 // virtual slot seed_out (then right < 0 and _tail == 0).  Returns the number of nodes written to line[].
@@ -672,8 +743,24 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
     else { old_score = 2 + score_table(r.nd[right].match_flag); old_NM = left_NM + r.h_nm[right]; }
     const int dp_flag = MULTI_FLAG;
-    nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0);
+    int rlo = 0, rhi = 0x7fffffff;
+    if (head < 0 && _tail != 0 && right >= 0) {
+        // From START every hit of the range would be active, but only the chain into `right` is used afterwards
+        // (:1129-1147): restrict the pass to the hits that can reach `right` at all (exact, see reach_run).
+        const lamsa_hp_para *P = r.cx.P;
+        const int did_max = r.seed_id[right_x] - r.seed_id[left_x + 1];
+        const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
+        long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
+        if (mdm + 1 > Rw) Rw = mdm + 1;
+        Rw += 128 + (long long)did_max * P->seed_step;
+        reach_run(r, right, Rw, &rlo, &rhi);
+    }
+    nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0, rlo, rhi);
     dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false);      // callers guarantee left_x + 2 <= right_x
+#ifdef HP_PROF
+    const long long tm0_ = wv::clock();
+    if (r.prof) r.prof[21] += 1;
+#endif
     int max_score, max_NM = 0, max_n = 0, max_node = head;
     if (_tail == 0) {
         // best end node: score desc, NM asc, then the reference's scan order (seeds descending, hits ascending), :1105-1123
@@ -717,6 +804,9 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     if (node_i >= 0) { r.cx.status |= ST_REFEXIT; return 0; }
     *de_score += max_score - old_score;
     *de_NM += max_NM - old_NM;
+#ifdef HP_PROF
+    if (r.prof) r.prof[20] += wv::clock() - tm0_;
+#endif
     return max_n;
 }
 

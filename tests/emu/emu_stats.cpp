@@ -1,0 +1,16 @@
+// emu_stats.cpp -- TEST/DIAGNOSTIC ONLY: histogram of the chaining passes (range size, active hits, due targets) when the
+// device sources are compiled with -DHP_EMU_STATS on the CPU lane emulation:
+//   g++ -O1 -std=c++17 -fPIC -shared -DHP_EMU_STATS -I tests/emu -I lamsa_amd/csrc -o /tmp/libemu_stats.so tests/emu/emu_api.cpp tests/emu/emu_stats.cpp
+#include <stdio.h>
+#include <map>
+namespace hp { void hp_emu_stat_call(int, int, int, bool); void hp_emu_stat_due(int, int, int); }
+static std::map<int, long> calls, due_by_span, targets_by_range;
+static long forced = 0;
+static int bucket(int x) { int b = 0; while ((1 << b) < x) ++b; return b; }
+void hp::hp_emu_stat_call(int range, int lo, int hi, bool force) { if (force) { ++forced; return; } ++calls[bucket(range)]; }
+void hp::hp_emu_stat_due(int range, int due, int span) { targets_by_range[bucket(range)] += due; due_by_span[bucket(span)] += due; }
+extern "C" void hp_emu_stat_dump() {
+    fprintf(stderr, "forced %ld\n", forced);
+    for (auto &k : calls) fprintf(stderr, "range<=%6d calls %8ld due targets %9ld\n", 1 << k.first, k.second, targets_by_range[k.first]);
+    for (auto &k : due_by_span) fprintf(stderr, "candidate span (hits in [start_slot,k1)) <=%6d : due targets %9ld\n", 1 << k.first, k.second);
+}
