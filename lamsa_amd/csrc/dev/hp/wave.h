@@ -18,6 +18,7 @@
 // pointers that the hot loops dereference are cast to the global address space so that hipcc emits
 // global_load/global_store instead of flat_* (which also wait on the LDS counter)
 #define HP_G __attribute__((address_space(1)))
+#define HP_L __attribute__((address_space(3)))     // LDS
 
 typedef int hp_v4i __attribute__((ext_vector_type(4)));
 typedef int hp_v2i __attribute__((ext_vector_type(2)));

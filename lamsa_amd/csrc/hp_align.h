@@ -97,18 +97,18 @@ HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap,
 
 // ---- the per-read entry point ----
 #ifdef HP_PROF
-#define HP_STAMP(k) do { const long long now_ = wv::clock(); if (a.prof) a.prof[(size_t)rd * 32 + (k)] += now_ - t_last_; t_last_ = now_; } while (0)
+#define HP_STAMP(k) do { const long long now_ = wv::clock(); if (a.prof) a.prof[(size_t)rd * 64 + (k)] += now_ - t_last_; t_last_ = now_; } while (0)
 #else
 #define HP_STAMP(k) do { } while (0)
 #endif
 
-HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
+HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t *lds)
 {
 #ifdef HP_PROF
     long long t_last_ = wv::clock();
 #endif
     ReadCtx r;
-    r.cx.P = &a.P; r.cx.status = 0;
+    r.cx.P = &a.P; r.cx.status = 0; r.cx.lds = lds; r.cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
     arena_init(r.cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
     r.ref = a.ref;
     const BatchIn &in = a.in;
@@ -124,7 +124,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot)
     r.srt = in.h_sort + r.hb; r.rnk = in.h_rank + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
-    r.prof = a.prof ? a.prof + (size_t)rd * 32 : nullptr;
+    r.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
     Ctx &cx = r.cx;
     const int H = r.H;
     // read-lifetime allocations

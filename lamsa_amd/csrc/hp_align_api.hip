@@ -17,13 +17,14 @@ using namespace hp;
 #endif
 __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs a)
 {
+    __shared__ int32_t lds[HP_LDS_WORDS];            // this wave's DP rows, query window and direction matrix (hp_ksw.h)
     const int slot = blockIdx.x;
     for (;;) {
         int u = 0;
         if (wv::leader()) u = atomicAdd(a.counter, 1);
         u = wv::uni(u);
         if (u >= a.n_units) break;          // every wave reaches this exit: the queue head only grows
-        align_read(a, a.order ? a.order[u] : u, slot);
+        align_read(a, a.order ? a.order[u] : u, slot, (HP_L int32_t *)lds);
     }
 }
 
@@ -175,7 +176,7 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr;
 #ifdef HP_PROF
     static DevBuf profbuf;
-    if (profbuf.ensure(sizeof(long long) * 32 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 32 * (size_t)n); a.prof = (long long *)profbuf.p; }
+    if (profbuf.ensure(sizeof(long long) * 64 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 64 * (size_t)n); a.prof = (long long *)profbuf.p; }
 #endif
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemsetAsync(S->misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
@@ -187,16 +188,18 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     if (ms) hipEventElapsedTime(ms, h->ev0, h->ev1);
 #ifdef HP_PROF
     if (a.prof) {
-        std::vector<long long> pr((size_t)n * 32);
+        std::vector<long long> pr((size_t)n * 64);
         hipMemcpy(pr.data(), a.prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost);
         std::vector<int> idx((size_t)n); for (int i = 0; i < n; ++i) idx[i] = i;
-        auto tot = [&](int r) { long long t = 0; for (int k = 0; k < 6; ++k) t += pr[(size_t)r * 32 + k]; return t; };
+        auto tot = [&](int r) { long long t = 0; for (int k = 0; k < 6; ++k) t += pr[(size_t)r * 64 + k]; return t; };
         std::sort(idx.begin(), idx.end(), [&](int x, int y) { return tot(x) > tot(y); });
-        long long sum[32] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 32; ++k) sum[k] += pr[(size_t)r * 32 + k];
+        long long sum[64] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 64; ++k) sum[k] += pr[(size_t)r * 64 + k];
         fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
         fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles) targets %lld trips %lld init_Mcyc %lld\n", sum[11], sum[12], sum[13] / 1000000);
         fprintf(stderr, "[HP_PROF] update_range: calls %lld total %lld prefilter %lld prologue %lld (Mcyc) chunks %lld | mini_line calls %lld tail+walk %lld Mcyc | forced %lld\n", sum[19], sum[16] / 1000000, sum[17] / 1000000, sum[18] / 1000000, sum[22], sum[21], sum[20] / 1000000, sum[23]);
-        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 32 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 32 + 14], pr[(size_t)r * 32 + 15], pr[(size_t)r * 32 + 11], pr[(size_t)r * 32 + 12], pr[(size_t)r * 32 + 13] / 1000000); }
+        { const char *nm[] = {"ksw_global", "ksw_extend", "backtrack", "ref_fetch", "head_fix", "frag_extend", "split_mapping", "tail_fix", "res_split", "res_aux", "merge_cigar", "split_indel_map"};
+          for (int k = 0; k < 12; ++k) fprintf(stderr, "[HP_PROF] %-16s %8lld Mcyc %10lld calls\n", nm[k], sum[24 + 2 * k] / 1000000, sum[25 + 2 * k]); }
+        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }
     }
 #endif
     return LAMSA_HP_OK;

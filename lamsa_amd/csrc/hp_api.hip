@@ -16,13 +16,14 @@ using namespace hp;
 // One wavefront (64 threads) per workgroup; a persistent grid pulls units from a queue head.
 __global__ __launch_bounds__(64) void k_dp_batch(DpBatchArgs a)
 {
+    __shared__ int32_t lds[HP_LDS_WORDS];
     const int slot = blockIdx.x;
     for (;;) {
         int job = 0;
         if (wv::leader()) job = atomicAdd(a.counter, 1);
         job = wv::uni(job);
         if (job >= a.n_jobs) break;
-        dp_run_job(a, job, slot);
+        dp_run_job(a, job, slot, (HP_L int32_t *)lds);
     }
 }
 

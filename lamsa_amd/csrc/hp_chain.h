@@ -498,50 +498,86 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
 }
 HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true); }
 
-// ---------------------------------------------------------------- frag_min_extend for one MIN hit, :1031-1066
-// For every seed with more than min_n hits, the first hit (ascending) that is match-class
-// colinear with `m` joins the MIN pass.  Lanes scan all hits; "first within its seed" is a
-// segmented ballot.  The result is a set union, so the order over MIN hits is irrelevant.
-HP_NOINL void min_extend(ReadCtx &r, int m, int min_n)
+// ---------------------------------------------------------------- frag_min_extend for every MIN hit, :1031-1066, :1335-1343
+// For every MIN hit m (a hit of a seed with at most min_n hits) and every seed with more than min_n hits, the first
+// hit (ascending) of that seed that is match-class colinear with m joins the MIN pass.  The result is a set union, so
+// the order over MIN hits is free: the hits are walked in chunks of 64 (one coalesced load per chunk, records kept in
+// registers), the MIN hits of a chunk are broadcast out of the lanes that hold them, and "first within its seed" is a
+// segmented ballot.  No dependent memory round trip inside the pair loop.
+HP_NOINL void min_extend_all(ReadCtx &r, int min_n)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
-    const NodeS M = node_load(ns + m);
-    const int xm = M.slot_j >> 14;
-    int carry_seed = -1, carry_found = 0;
-    for (int base = 0; base < r.H; base += 64) {
-        wv::Lane<int> q, seg, sd;
+    const int H = r.H;
+    for (int mbase = 0; mbase < H; mbase += 64) {
+        // the MIN hits of this chunk, one per lane
+        wv::Lane<int> Ma0, Ma1, Ma2, Ma3, Mb0, Mb1, Mb2, Mb3, ism;
         WAVE_FOR(l) {
-            const int k = base + l;
-            q[l] = 0; seg[l] = 0; sd[l] = -1;
-            if (k < r.H) {
-                const NodeS Q = node_load(ns + k);
-                const int s = Q.slot_j >> 14;
+            const int k = mbase + l, kk = k < H ? k : H - 1;
+            int a[4], b[4];
+            hp_load16(ns + kk, a); hp_load16((const HP_G char *)(ns + kk) + 16, b);
+            Ma0[l] = a[0]; Ma1[l] = a[1]; Ma2[l] = a[2]; Ma3[l] = a[3]; Mb0[l] = b[0]; Mb1[l] = b[1]; Mb2[l] = b[2]; Mb3[l] = b[3];
+            const int s = a[3] >> 14;
+            ism[l] = k < H && (int)(g_hoff[s + 1] - g_hoff[s]) <= min_n;
+        }
+        const unsigned long long mset = wv::ballot(ism);
+        if (!mset) continue;
+        unsigned long long carry = 0;                     // bit j: MIN hit j already found its hit in seed carry_seed
+        int carry_seed = -1;
+        for (int base = 0; base < H; base += 64) {
+            wv::Lane<int> Qa0, Qa1, Qa2, Qa3, Qb0, Qb1, Qb2, Qb3, seg, sd, elig, hit;
+            WAVE_FOR(l) {
+                const int k = base + l, kk = k < H ? k : H - 1;
+                int a[4], b[4];
+                hp_load16(ns + kk, a); hp_load16((const HP_G char *)(ns + kk) + 16, b);
+                Qa0[l] = a[0]; Qa1[l] = a[1]; Qa2[l] = a[2]; Qa3[l] = a[3]; Qb0[l] = b[0]; Qb1[l] = b[1]; Qb2[l] = b[2]; Qb3[l] = b[3];
+                const int s = a[3] >> 14;
                 const int h0 = (int)(g_hoff[s] - hb), h1 = (int)(g_hoff[s + 1] - hb);
-                int st = h0 - base; seg[l] = st > 0 ? st : 0; sd[l] = s;
-                if (s != xm && h1 - h0 > min_n) {
-                    const int f = s < xm ? edge_flag_packed(K, Q, M) : edge_flag_packed(K, M, Q);
-                    q[l] = (f == F_MATCH || f == F_MISMATCH || f == F_LONG_MISMATCH);
+                const int st = h0 - base;
+                seg[l] = st > 0 ? st : 0; sd[l] = k < H ? s : -1;
+                elig[l] = k < H && h1 - h0 > min_n;
+                hit[l] = 0;
+            }
+            const int last = H - 1 - base < 63 ? H - 1 - base : 63;
+            const int s_last = wv::bcast(sd, last), st_last = wv::bcast(seg, last);
+            unsigned long long next_carry = 0;
+            for (unsigned long long mm = mset; mm; mm &= mm - 1) {
+                const int j = __builtin_ctzll(mm);
+                NodeS M;
+                {
+                    int a[4] = { wv::bcast(Ma0, j), wv::bcast(Ma1, j), wv::bcast(Ma2, j), wv::bcast(Ma3, j) };
+                    int b[4] = { wv::bcast(Mb0, j), wv::bcast(Mb1, j), wv::bcast(Mb2, j), wv::bcast(Mb3, j) };
+                    M = node_unpack(a, b);
                 }
+                const int xm = M.slot_j >> 14;
+                wv::Lane<int> q;
+                WAVE_FOR(l) {
+                    int v = 0;
+                    if (elig[l] && sd[l] != xm) {
+                        int a[4] = { Qa0[l], Qa1[l], Qa2[l], Qa3[l] }, b[4] = { Qb0[l], Qb1[l], Qb2[l], Qb3[l] };
+                        const NodeS Q = node_unpack(a, b);
+                        const int f = sd[l] < xm ? edge_flag_packed(K, Q, M) : edge_flag_packed(K, M, Q);
+                        v = (f == F_MATCH || f == F_MISMATCH || f == F_LONG_MISMATCH);
+                    }
+                    q[l] = v;
+                }
+                const unsigned long long qb = wv::ballot(q);
+                if (!qb) { if (carry_seed == s_last && ((carry >> j) & 1)) next_carry |= 1ull << j; continue; }
+                const bool cj = (carry >> j) & 1;
+                WAVE_FOR(l) {
+                    if (q[l]) {
+                        const unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
+                        if (earlier == 0 && !(sd[l] == carry_seed && cj)) hit[l] = 1;
+                    }
+                }
+                if ((qb >> st_last) != 0 || (carry_seed == s_last && cj)) next_carry |= 1ull << j;
             }
+            WAVE_FOR(l) { if (hit[l]) gd[base + l].dp_flag = MIN_FLAG; }
+            carry = next_carry; carry_seed = s_last;
         }
-        const unsigned long long qb = wv::ballot(q);
-        WAVE_FOR(l) {
-            const int k = base + l;
-            if (k < r.H && q[l]) {
-                unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
-                if (earlier == 0 && !(sd[l] == carry_seed && carry_found)) gd[k].dp_flag = MIN_FLAG;
-            }
-        }
-        const int klast = base + 63 < r.H ? base + 63 : r.H - 1;
-        const int s_last = ns[klast].slot_j >> 14;
-        int st = hoff(r, s_last) - base; st = st > 0 ? st : 0;
-        const int found_here = (qb >> st) != 0;
-        carry_found = found_here || (carry_seed == s_last && carry_found);
-        carry_seed = s_last;
     }
     wv::sync();
 }
@@ -1094,10 +1130,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     wv::sync();
     if (all_min) min_n = P->per_aln_m;
     if (min_n != P->per_aln_m) {                                                                  // :1335-1343
-        for (int i = 0; i < seed_out; ++i) {
-            if (mapn(r, i) > min_n) continue;
-            for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k) min_extend(r, k, min_n);
-        }
+        min_extend_all(r, min_n);
     }
     HP_CSTAMP(6);
     if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false);                      // main pass, :1345-1350

@@ -21,11 +21,25 @@ HP_INL void arena_init(Arena &a, void *base, size_t cap) { a.base = (char *)base
 HP_INL size_t arena_mark(const Arena &a) { return a.top; }
 HP_INL void arena_release(Arena &a, size_t m) { a.top = m; }
 
+// LDS of one wave (= one workgroup): circular H and E rows, staged query bases, direction matrix (see hp_ksw.h)
+#define HP_LDS_CELLS 1024
+#define HP_LDS_Z_BYTES 10240
+#define HP_LDS_WORDS (2 * HP_LDS_CELLS + HP_LDS_CELLS / 4 + HP_LDS_Z_BYTES / 4)
+
 struct Ctx {
     const lamsa_hp_para *P;   // parameters (kernel argument copy)
+    HP_L int32_t *lds;        // HP_LDS_WORDS words of LDS owned by this wave
     Arena tmp;                // scratch slab of this wave
     int status;               // ST_* bits for the unit (read / job) being processed
+    long long *prof;          // per-read cycle counters of diagnostic builds (-DHP_PROF), else nullptr
 };
+#ifdef HP_PROF
+#define HP_T0(v) const long long v = wv::clock()
+#define HP_TADD(cx, slot, v) do { if ((cx).prof) { (cx).prof[slot] += wv::clock() - (v); (cx).prof[(slot) + 1] += 1; } } while (0)
+#else
+#define HP_T0(v) do { } while (0)
+#define HP_TADD(cx, slot, v) do { } while (0)
+#endif
 
 // returns nullptr (and flags overflow) when the slab is exhausted; callers must cope
 HP_INL void *arena_alloc(Ctx &cx, size_t bytes) {

@@ -17,11 +17,11 @@ struct DpBatchArgs {
     int32_t *counter;             // dynamic job queue head
 };
 
-HP_FN void dp_run_job(const DpBatchArgs &a, int job, int wave_slot)
+HP_FN void dp_run_job(const DpBatchArgs &a, int job, int wave_slot, HP_L int32_t *lds)
 {
     Ctx cx;
     cx.P = &a.P;
-    cx.status = 0;
+    cx.status = 0; cx.prof = nullptr; cx.lds = lds;
     arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
     const int ql = a.qlen[job], tl = a.tlen[job];
     Seq q = seq_fwd(a.seq + a.q_off[job]), t = seq_fwd(a.seq + a.t_off[job]);

@@ -30,6 +30,7 @@ struct LineRes {                 // line_aln_res, frag_check.h:61-73
 // ---------------------------------------------------------------- pac2fa_core, bntseq.c:465-477
 HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t *dst)
 {
+    HP_T0(tr0_);
     const int32_t clen = r.ref.seq_len[chr - 1];
     if (start0 > clen || start0 < 0) { r.cx.status |= ST_REFEXIT; return false; }      // exit(1), :469-472
     if (start0 + *len > clen) *len = (int32_t)(clen - start0);                          // :474
@@ -44,6 +45,7 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
         }
     }
     wv::sync();
+    HP_TADD(r.cx, 30, tr0_);
     return true;
 }
 
@@ -445,6 +447,12 @@ HP_NOINL bool res_aux(ReadCtx &r, LineRes &la)
 }
 
 // ---------------------------------------------------------------- one line of frag_check, :886-955
+
+#ifdef HP_PROF
+#define HP_TIMED(slot, call) ([&]() { HP_T0(t_); const bool ok_ = (call); HP_TADD(r.cx, slot, t_); return ok_; }())
+#else
+#define HP_TIMED(slot, call) (call)
+#endif
 HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur_buf, int cur_cap, cig_t *rec_buf, int rec_cap)
 {
     Ctx &cx = r.cx;
@@ -460,9 +468,9 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
     if (strand == 1) {
         r.cur_read = r.read; r.flip = false;
         if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
-        ok = head_fix(r, F, line, r0);
-        for (int i = nfr - 1; i > 0 && ok; --i) ok = frag_extend(r, F, f0 + i, r0) && split_mapping(r, F, f0 + i, f0 + i - 1, r0);
-        ok = ok && frag_extend(r, F, f0, r0) && tail_fix(r, F, line, r0);
+        ok = HP_TIMED(32, head_fix(r, F, line, r0));
+        for (int i = nfr - 1; i > 0 && ok; --i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i - 1, r0));
+        ok = ok && HP_TIMED(34, frag_extend(r, F, f0, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
         if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = ((r.L - (F.right_bound[line] - 1) * P->seed_step) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
     } else {
         if (!r.rc_ready) {                                            // :922-925 (buffer reserved when the read was set up)
@@ -474,12 +482,12 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
         const int tmp = F.left_bound[line];
         F.left_bound[line] = r.seed_all + 1 - F.right_bound[line]; F.right_bound[line] = r.seed_all + 1 - tmp;
         if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv + r.last_len) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
-        ok = head_fix(r, F, line, r0);
-        for (int i = 0; i < nfr - 1 && ok; ++i) ok = frag_extend(r, F, f0 + i, r0) && split_mapping(r, F, f0 + i, f0 + i + 1, r0);
-        ok = ok && frag_extend(r, F, f0 + nfr - 1, r0) && tail_fix(r, F, line, r0);
+        ok = HP_TIMED(32, head_fix(r, F, line, r0));
+        for (int i = 0; i < nfr - 1 && ok; ++i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i + 1, r0));
+        ok = ok && HP_TIMED(34, frag_extend(r, F, f0 + nfr - 1, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
         if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = (((r.seed_all - F.right_bound[line] + 1) * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
     }
-    ok = ok && res_split(r, la, rec_buf, rec_cap) && res_aux(r, la);
+    ok = ok && HP_TIMED(40, res_split(r, la, rec_buf, rec_cap)) && HP_TIMED(42, res_aux(r, la));
     r.flip = false;                                                   // :953
     return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
 }

@@ -19,15 +19,18 @@
 
 namespace hp {
 
-// ---- traceback (src/ksw.c:638-649 and :792-801); rowb == nullptr: every band cell was written ----
-HP_FN void dp_backtrack(Ctx &cx, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out)
+// ---- traceback (src/ksw.c:638-649 and :792-801).  The direction matrix lives in LDS (lz) when it fits, else in the
+// wave's HBM slab (gz).  Cells outside the row's window read as 255 = never written (src/ksw.c:707); inside the
+// window the forward pass has written every cell (255 where the band did not reach).
+HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, int n_col, int w, int i, int k, CigV &out)
 {
+    const HP_G uint8_t *gz = (const HP_G uint8_t *)z;
     int which = 0;
     out.n = 0;
     while (i >= 0 && k >= 0) {
-        int off = i > w ? i - w : 0;
-        int cell = 255;                                   // never-written cells read as 255 (src/ksw.c:707)
-        if (!rowb || (k >= rowb[2 * i] && k < rowb[2 * i + 1])) cell = z[(long)i * n_col + (k - off)];
+        const int off = i > w ? i - w : 0;
+        int cell = 255;
+        if (k >= off && k - off < n_col) cell = lz ? lz[i * n_col + (k - off)] : gz[(long)i * n_col + (k - off)];
         which = cell >> (which << 1) & 3;
         if (which == 0) { cig_push0(cx, out, 1 << 4 | C_M); --i; --k; }
         else if (which == 1) { cig_push0(cx, out, 1 << 4 | C_D); --i; }
@@ -40,13 +43,11 @@ HP_FN void dp_backtrack(Ctx &cx, const uint8_t *z, const int32_t *rowb, int n_co
 
 #define HP_SCAN_IDENT (-0x7f000000)
 
-// ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
-HP_NOINL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
+// ---- ksw_global2 (src/ksw.c:543-653) with the H/E row in the wave's HBM slab: only for bands wider than the LDS row.
+HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                         int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
-    if (out) out->n = 0;
-    if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
-    { int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }                   // :549
+    HP_T0(tg0_);
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
     const size_t mark = arena_mark(cx.tmp);
@@ -121,44 +122,34 @@ HP_NOINL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     if (out) {
         int i = tlen - 1;
         int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;                 // :638
-        dp_backtrack(cx, z, nullptr, n_col, w, i, k, *out);
+        HP_T0(tb0_);
+        dp_backtrack(cx, nullptr, z, n_col, w, i, k, *out);
+        HP_TADD(cx, 28, tb0_);
     }
     arena_release(cx.tmp, mark);
+    HP_TADD(cx, 24, tg0_);
     return score;
 }
 
-// ---- ksw_extend_core (src/ksw.c:667-807).  Uses the *extension* gap penalties. ----
-HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
-                        int *qle, int *tle, CigV *out)
+// ---- ksw_extend_core (src/ksw.c:667-807) with the H/E row in the wave's HBM slab: only for bands wider than the LDS row.
+// w is already adjusted (see ksw_extend).
+HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
+                             int *qle, int *tle, CigV *out)
 {
-    if (out) out->n = 0;
-    if (qle) *qle = 0;
-    if (tle) *tle = 0;
-    if (qlen < 0 || tlen < 0 || h0 <= 0) { cx.status |= ST_REFEXIT; return 0; }   // :672, assert :682
+    HP_T0(te0_);
     const lamsa_hp_para *P = cx.P;
     const int o_ins = P->ins_ext_o, e_ins = P->ins_ext_e, o_del = P->del_ext_o, e_del = P->del_ext_e;
     const int end_bonus = P->end_bonus, zdrop = P->zdrop;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    {   // adjust w, :696-704 (double arithmetic, truncation toward zero as in the reference)
-        int mx = P->match > 0 ? P->match : 0;               // max over the 5x5 matrix (N cells are -1)
-        if (-P->mis > mx) mx = -P->mis;
-        int max_ins = (int)((double)(qlen * mx + end_bonus - o_ins) / e_ins + 1.);
-        max_ins = max_ins > 1 ? max_ins : 1;
-        w = w < max_ins ? w : max_ins;
-        int max_del = (int)((double)(qlen * mx + end_bonus - o_del) / e_del + 1.);
-        max_del = max_del > 1 ? max_del : 1;
-        w = w < max_del ? w : max_del;
-    }
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     const size_t mark = arena_mark(cx.tmp);
     int32_t *H = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
     int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
-    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
     uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
-    if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return 0; }
+    if (!H || !E || !z) { arena_release(cx.tmp, mark); return 0; }
 
     const int sc_match = P->match, sc_mis = -P->mis;
-    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E, *growb = (HP_G int32_t *)rowb;
+    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E;
     HP_G uint8_t *gz = (HP_G uint8_t *)z;
     const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
     const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
@@ -191,7 +182,9 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
-        growb[2 * i] = beg; growb[2 * i + 1] = end;
+        for (int c0 = 0; c0 < n_col; c0 += 64) {                           // window cells the band does not reach: never written
+            WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) gz[(long)i * n_col + c] = 255; }
+        }
         int carryH = gH[beg];
         int Fin = 0;
         long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
@@ -284,9 +277,298 @@ HP_NOINL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
     else { i = max_ie; k = qlen - 1; }
     if (qle) *qle = k + 1;
     if (tle) *tle = i + 1;
-    if (out) dp_backtrack(cx, z, rowb, n_col, w, i, k, *out);
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
     return max;
+}
+
+// =====================================================================================================
+// LDS-resident rows.  The H/E row is a circular buffer of HP_LDS_CELLS cells indexed by (column & mask): a row only
+// touches the columns [beg, end], beg never decreases and end grows by at most two per row, so the live window is
+// narrower than 2w+4 cells.  A column enters the window exactly once, when it first exceeds the high-water mark `hw`;
+// it is given the value the reference's first-row initialisation left there (:569-572, :692-694), which is what the
+// reference reads from its full-length array when the band reaches a cell it has never written ("stale cells").
+// Query bases are staged into LDS 64 at a time as the window advances, target bases 64 rows at a time into a lane
+// register; the direction matrix goes to LDS when it fits.  Inside the row loop there is no HBM round trip.
+// =====================================================================================================
+#define HP_LDS_MASK (HP_LDS_CELLS - 1)
+
+HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
+                            int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
+{
+    HP_T0(tg0_);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
+    const size_t mark = arena_mark(cx.tmp);
+    const bool zl = (size_t)n_col * tlen <= HP_LDS_Z_BYTES;
+    uint8_t *z = (out && !zl) ? (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1) : nullptr;
+    if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
+    HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
+    HP_L uint8_t *LQ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS), *LZ = LQ + HP_LDS_CELLS;
+    HP_G uint8_t *gz = (HP_G uint8_t *)z;
+    const int sc_match = cx.P->match, sc_mis = -cx.P->mis;
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
+#define HP_GH0(j) ((j) == 0 ? 0 : ((j) <= w ? -(o_ins + e_ins * (j)) : HP_NEG_INF))
+    int hw = -1, qw = -1;
+    wv::Lane<int> tl;
+    WAVE_FOR(l) { tl[l] = 4; }
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { WAVE_FOR(l) { const int ii = i + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti = wv::bcast(tl, i & 63);
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        if (end > hw) {                                                    // columns entering the window
+            for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_GH0(j); LE[j & HP_LDS_MASK] = HP_NEG_INF; } } }
+            hw = end;
+        }
+        while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
+        wv::sync();
+        const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
+        int carryH = LH[beg & HP_LDS_MASK];          // H(i-1,beg-1), read before the in-place update below
+        int Fin = HP_NEG_INF;                        // F(i,beg)
+        wv::sync();
+        LH[beg & HP_LDS_MASK] = h1_init;             // eh[beg].h = H(i,beg-1)
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int nxt = j0 + 64;
+            const int carry_next = LH[nxt & HP_LDS_MASK];   // old value, lane 63 is about to overwrite it
+            wv::Lane<int> m, e, key;
+            WAVE_FOR(l) {
+                const int j = j0 + l;
+                if (j < end) {
+                    const int hm = l == 0 ? carryH : LH[j & HP_LDS_MASK];
+                    const int qb = LQ[j & HP_LDS_MASK];
+                    m[l] = hm + HP_SUB(ti, qb);
+                    e[l] = LE[j & HP_LDS_MASK];
+                    key[l] = m[l] - oe_ins + j * e_ins;
+                } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            wv::sync();
+            wv::Lane<int> fnext;
+            WAVE_FOR(l) {
+                const int j = j0 + l;
+                fnext[l] = 0;
+                if (j < end) {
+                    int f = Fin - l * e_ins;                               // F(i,j) carried in from the left
+                    if (l > 0) { const int g = key[l] - (j - 1) * e_ins; f = g > f ? g : f; }
+                    int mm = m[l], ee = e[l], h, tt;
+                    int dir = mm >= ee ? 0 : 1; h = mm >= ee ? mm : ee;    // ties: M over E   :598-599
+                    dir = h >= f ? dir : 2;     h = h >= f ? h : f;        //       then over F :600-601
+                    tt = mm - oe_del; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;              // :603-607
+                    tt = mm - oe_ins; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4; else f = tt;                // :608-611
+                    LE[j & HP_LDS_MASK] = ee;
+                    LH[(j + 1) & HP_LDS_MASK] = h;                         // eh[j+1].h = H(i,j)
+                    if (out) { if (zl) LZ[i * n_col + (j - beg)] = (uint8_t)dir; else gz[(long)i * n_col + (j - beg)] = (uint8_t)dir; }
+                    fnext[l] = f;
+                }
+            }
+            Fin = wv::bcast(fnext, 63);
+            carryH = carry_next;
+        }
+        LE[end & HP_LDS_MASK] = HP_NEG_INF;                                // :632
+        if (end > hw) hw = end;
+        wv::sync();
+    }
+    const int score = tlen > 0 ? (int)LH[qlen & HP_LDS_MASK] : HP_GH0(qlen);
+#undef HP_GH0
+    if (out) {
+        const int i = tlen - 1;
+        const int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;           // :638
+        HP_T0(tb0_);
+        dp_backtrack(cx, zl ? LZ : nullptr, z, n_col, w, i, k, *out);
+        HP_TADD(cx, 28, tb0_);
+    }
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 24, tg0_);
+    return score;
+}
+
+// ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
+HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
+                      int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
+{
+    if (out) out->n = 0;
+    if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
+    { const int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }             // :549
+    if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_global_lds(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
+    return ksw_global_wide(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
+}
+
+HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
+                            int *qle, int *tle, CigV *out)
+{
+    HP_T0(te0_);
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = P->ins_ext_o, e_ins = P->ins_ext_e, o_del = P->del_ext_o, e_del = P->del_ext_e;
+    const int end_bonus = P->end_bonus, zdrop = P->zdrop;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const size_t mark = arena_mark(cx.tmp);
+    const bool zl = (size_t)n_col * tlen <= HP_LDS_Z_BYTES;
+    uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
+    if (!zl && !z) { arena_release(cx.tmp, mark); return 0; }
+    HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
+    HP_L uint8_t *LQ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS), *LZ = LQ + HP_LDS_CELLS;
+    HP_G uint8_t *gz = (HP_G uint8_t *)z;
+    const int sc_match = P->match, sc_mis = -P->mis;
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
+    // first row, :692-694: h0, h0-oe_ins, then -e_ins per column while the previous cell is > e_ins
+    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+#define HP_EH0(j) ((j) == 0 ? h0 : ((j) == 1 ? h1v : (((j) <= qlen && h1v - ((j) - 2) * e_ins > e_ins) ? h1v - ((j) - 1) * e_ins : 0)))
+    int hw = -1, qw = -1;
+    wv::Lane<int> tl;
+    WAVE_FOR(l) { tl[l] = 4; }
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { WAVE_FOR(l) { const int ii = i + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti = wv::bcast(tl, i & 63);
+        const int d_beg = i > w ? i - w : 0;
+        if (beg < i - w) beg = i - w;                                      // :718-720
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (end > hw) {                                                    // columns entering the window
+            for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_EH0(j); LE[j & HP_LDS_MASK] = 0; } } }
+            hw = end;
+        }
+        while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
+        for (int c0 = 0; c0 < n_col; c0 += 64) {                           // window cells the band does not reach: never written
+            WAVE_FOR(l) {
+                const int c = c0 + l, j = d_beg + c;
+                if (c < n_col && (j < beg || j >= end)) { if (zl) LZ[i * n_col + c] = 255; else gz[(long)i * n_col + c] = 255; }
+            }
+        }
+        wv::sync();
+        int h1_init;
+        if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+        else h1_init = 0;
+        int carryH = LH[beg & HP_LDS_MASK];
+        int Fin = 0;
+        long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
+        int h_last = h1_init;           // H(i,end-1), or the first-column value when the row is empty
+        // band shrink bookkeeping (:775-778): nz(j) = eh[j].h != 0 || eh[j].e != 0 after this row
+        int first_nz = -1, last_nz = -1, prev_h_nz = h1_init != 0;
+        wv::sync();
+        if (beg < end) LH[beg & HP_LDS_MASK] = h1_init; else LH[end & HP_LDS_MASK] = h1_init;   // eh[end].h = h1 when the row is empty (:758)
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int nxt = j0 + 64;
+            const int carry_next = LH[nxt & HP_LDS_MASK];
+            wv::Lane<int> m, e, key;
+            WAVE_FOR(l) {
+                const int j = j0 + l;
+                if (j < end) {
+                    const int hm = l == 0 ? carryH : LH[j & HP_LDS_MASK];
+                    const int qb = LQ[j & HP_LDS_MASK];
+                    const int M = hm ? hm + HP_SUB(ti, qb) : 0;             // :737
+                    int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+                    m[l] = M; e[l] = LE[j & HP_LDS_MASK]; key[l] = tt + j * e_ins;
+                } else { m[l] = 0; e[l] = 0; key[l] = HP_SCAN_IDENT; }
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            wv::sync();
+            wv::Lane<int> fnext, hnz, enz;
+            wv::Lane<long long> rk;
+            WAVE_FOR(l) {
+                const int j = j0 + l;
+                fnext[l] = 0; hnz[l] = 0; enz[l] = 0; rk[l] = -1;
+                if (j < end) {
+                    int f = Fin - l * e_ins;
+                    if (l > 0) { const int g = key[l] - (j - 1) * e_ins; f = g > f ? g : f; }
+                    int M = m[l], ee = e[l], h, tt;
+                    int dir = M > ee ? 0 : 1; h = M > ee ? M : ee;          // ties: E over M   :738-739
+                    dir = h > f ? dir : 2;    h = h > f ? h : f;            //       F over both :740-741
+                    tt = M - oe_del; tt = tt > 0 ? tt : 0; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;               // :745-750
+                    tt = M - oe_ins; tt = tt > 0 ? tt : 0; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4; else f = tt;                 // :751-755
+                    LE[j & HP_LDS_MASK] = ee;
+                    LH[(j + 1) & HP_LDS_MASK] = h;
+                    if (zl) LZ[i * n_col + (j - d_beg)] = (uint8_t)dir; else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
+                    fnext[l] = f; hnz[l] = h != 0; enz[l] = ee != 0;
+                    rk[l] = ((long long)h << 32) | (unsigned)j;
+                }
+            }
+            Fin = wv::bcast(fnext, 63);
+            carryH = carry_next;
+            {
+                const long long b = wv::reduce_max64(rk);
+                if (b > best) best = b;
+                const int cnt = end - j0 < 64 ? end - j0 : 64;            // active lanes
+                const unsigned long long bh = wv::ballot(hnz), be = wv::ballot(enz);
+                // nz for index j0+l: E bit l | H bit (l-1); index j0+cnt (== end on the last chunk) gets H bit cnt-1
+                const unsigned long long nzm = be | (bh << 1) | (unsigned long long)(prev_h_nz ? 1 : 0);
+                const unsigned long long inrow = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+                if (first_nz < 0 && (nzm & inrow)) first_nz = j0 + __builtin_ctzll(nzm & inrow);
+                if (nzm & inrow) last_nz = j0 + 63 - __builtin_clzll(nzm & inrow);
+                prev_h_nz = (int)((bh >> (cnt - 1)) & 1);
+            }
+        }
+        // H(i,end-1): value of the last computed cell (needed for gscore / eh[end].h)
+        wv::sync();
+        if (beg < end) h_last = LH[end & HP_LDS_MASK];
+        LE[end & HP_LDS_MASK] = 0;                                         // :758
+        if (end > hw) hw = end;
+        const int jj = beg < end ? end : beg;                              // loop variable j after the row
+        if (jj == qlen) {                                                  // :759-762
+            max_ie = gscore > h_last ? max_ie : i;
+            gscore = gscore > h_last ? gscore : h_last;
+        }
+        int mrow = 0, mj = -1;
+        if (best >= 0) { mrow = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
+        if (mrow == 0) break;                                              // :763
+        if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+        else if (zdrop > 0) {                                              // :767-773
+            if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        // shrink the band for the next row, :775-778.  index `end` itself: eh[end].h = h_last, eh[end].e = 0
+        {
+            const int nb = first_nz >= 0 ? first_nz : end;                 // first j in [beg,end) that is non-zero
+            int jl;                                                        // last j in [nb,end] that is non-zero, else nb-1
+            if (h_last != 0 && end >= nb) jl = end;
+            else if (last_nz >= nb && last_nz >= 0) jl = last_nz;
+            else jl = nb - 1;
+            beg = nb;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+    }
+#undef HP_EH0
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    if (qle) *qle = k + 1;
+    if (tle) *tle = i + 1;
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
+    return max;
+}
+
+// ---- ksw_extend_core (src/ksw.c:667-807).  Uses the *extension* gap penalties. ----
+HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, int *qle, int *tle, CigV *out)
+{
+    if (out) out->n = 0;
+    if (qle) *qle = 0;
+    if (tle) *tle = 0;
+    if (qlen < 0 || tlen < 0 || h0 <= 0) { cx.status |= ST_REFEXIT; return 0; }   // :672, assert :682
+    {   // adjust w, :696-704 (double arithmetic, truncation toward zero as in the reference)
+        const lamsa_hp_para *P = cx.P;
+        int mx = P->match > 0 ? P->match : 0;               // max over the 5x5 matrix (N cells are -1)
+        if (-P->mis > mx) mx = -P->mis;
+        int max_ins = (int)((double)(qlen * mx + P->end_bonus - P->ins_ext_o) / P->ins_ext_e + 1.);
+        max_ins = max_ins > 1 ? max_ins : 1;
+        w = w < max_ins ? w : max_ins;
+        int max_del = (int)((double)(qlen * mx + P->end_bonus - P->del_ext_o) / P->del_ext_e + 1.);
+        max_del = max_del > 1 ? max_del : 1;
+        w = w < max_del ? w : max_del;
+    }
+    if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, qle, tle, out);
+    return ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, qle, tle, out);
 }
 
 // ksw_extend_c (src/ksw.c:809): 0 query-to-end, 1 target-to-end, 2 neither

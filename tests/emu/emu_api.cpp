@@ -20,7 +20,8 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
     a.cig_cap_off = cig_cap_off; a.cig = cig;
     std::vector<char> slab(slab_bytes);
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr;
-    for (int j = 0; j < n; ++j) dp_run_job(a, j, 0);
+    static int32_t lds[HP_LDS_WORDS];
+    for (int j = 0; j < n; ++j) dp_run_job(a, j, 0, lds);
     return 0;
 }
 
@@ -45,7 +46,8 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;
     std::vector<char> slab(slab_bytes);
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
-    for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0);
+    static int32_t lds[HP_LDS_WORDS];
+    for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0, lds);
     *n_words = (int64_t)cursor;
     return 0;
 }

@@ -11,6 +11,7 @@
 #define HP_NOINL static
 
 #define HP_G
+#define HP_L
 
 HP_INL void hp_load16(const void *p, int *o) { memcpy(o, p, 16); }
 HP_INL void hp_load8(const void *p, int *o) { memcpy(o, p, 8); }
