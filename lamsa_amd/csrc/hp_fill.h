@@ -350,56 +350,74 @@ HP_NOINL bool tail_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
 }
 
 // ---------------------------------------------------------------- lamsa_res_split, :712-776
-// The whole-line CIGAR in rec[0] is cut into records whose CIGARs live back to back in `buf`.
+// The whole-line CIGAR in rec[0] (in its own buffer) is cut into records whose CIGARs live back to back in `buf`.
+// Sequential by nature (every element is pushed with _push_cigar1's merge rule), so it is organised to touch memory
+// as little as possible: 64 input words per coalesced load, handed out by readlane; the run being built, the read
+// bases consumed so far (what the reference recomputes with readInCigar at every cut, :738,:748,:762) and the
+// reference bases of the current record (refInCigar in push_res, :228) stay in registers; outputs are only stored.
 HP_NOINL bool res_split(ReadCtx &r, LineRes &la, cig_t *buf, int buf_cap)
 {
     Ctx &cx = r.cx;
     const lamsa_hp_para *P = cx.P;
-    const int read_len = r.L;
+    const int read_len = r.L, split_len = P->split_len;
     const int n = la.rec[0].cig.n;
-    const size_t mark = arena_mark(cx.tmp);
-    cig_t *cg = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(n + 1));
-    if (!cg) return false;
-    for (int j = 0; j < n; ++j) cg[j] = la.rec[0].cig.c[j];
-    int res_n = 0, used = 0;
-    cig_bind(la.rec[0].cig, buf, buf_cap);
-#define CUR (la.rec[res_n].cig)
-#define NEW_REC(extra_ref) do { \
-        used += CUR.n; CUR.cap = CUR.n; \
-        if (res_n + 1 >= HP_REC_MAX) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return false; } \
+    const HP_G cig_t *src = (const HP_G cig_t *)la.rec[0].cig.c;
+    if (la.rec[0].cig.c == buf) { cx.status |= ST_REFEXIT; return false; }           // in and out must be different buffers
+    HP_G cig_t *oc = (HP_G cig_t *)buf;
+    int res_n = 0, used = 0;                  // current record, words of `buf` taken by finished records
+    int wn = 0, pend = 0; bool have = false;  // words stored for the current record, run being built
+    int rd_tot = 0, ref_rec = 0;              // read bases consumed by all elements so far; reference bases of the current record
+#define HP_RS_PUSH(w_) do { const int v_ = (w_); if ((v_ >> 4) != 0) { \
+        if (have && (pend & 0xf) == (v_ & 0xf)) pend += (v_ >> 4) << 4; \
+        else { if (have) { if (used + wn < buf_cap) oc[used + wn++] = pend; else cx.status |= ST_OVERFLOW; } pend = v_; have = true; } } } while (0)
+#define HP_RS_NEW_REC(extra_ref) do { \
+        if (have) { if (used + wn < buf_cap) oc[used + wn++] = pend; else cx.status |= ST_OVERFLOW; have = false; } \
+        cig_bind(la.rec[res_n].cig, buf + used, wn); la.rec[res_n].cig.n = wn; \
+        used += wn; wn = 0; \
+        if (res_n + 1 >= HP_REC_MAX) { cx.status |= ST_OVERFLOW; return false; } \
         ++res_n; ++la.cur_res_n; \
         la.rec[res_n].chr = la.rec[res_n - 1].chr; la.rec[res_n].nstrand = la.rec[res_n - 1].nstrand;        /* push_res, :228 */ \
-        la.rec[res_n].offset = la.rec[res_n - 1].offset + cig_reflen(la.rec[res_n - 1].cig.c, la.rec[res_n - 1].cig.n) + (extra_ref); \
-        cig_bind(la.rec[res_n].cig, buf + used, buf_cap - used); } while (0)
-    for (int j = 0; j < n; ++j) {
-        const int op = cg[j] & 0xf, len = cg[j] >> 4;
-        int len1;
-        if (op == C_M) cig_push1(cx, CUR, cg[j]);
-        else if (op == C_I && len >= P->split_len) {
-            len1 = cig_readlen(CUR.c, CUR.n);
-            cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
-            NEW_REC(0);
-            cig_push1(cx, CUR, ((len + len1) << 4) | C_S);
-        } else if (op == C_D && len >= P->split_len) {
-            len1 = cig_readlen(CUR.c, CUR.n);
-            cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
-            NEW_REC(len);
-            cig_push1(cx, CUR, (len1 << 4) | C_S);
-        } else if (op == C_I || op == C_D) cig_push1(cx, CUR, cg[j]);
-        else if (op == C_S) {
-            if (j > 0 && j < n - 1 && (cg[j + 1] & 0xf) == C_H) {
-                const int Sn = cg[j] >> 4, Hn = cg[j + 1] >> 4;
-                len1 = cig_readlen(CUR.c, CUR.n);
-                cig_push1(cx, CUR, ((read_len - len1) << 4) | C_S);
-                NEW_REC(Hn);
-                cig_push1(cx, CUR, ((len1 + Sn) << 4) | C_S);
-                j += 1;
-            } else cig_push1(cx, CUR, cg[j]);
-        } else if (op != C_H) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); return false; }
+        la.rec[res_n].offset = la.rec[res_n - 1].offset + ref_rec + (extra_ref); ref_rec = 0; } while (0)
+    bool skip = false;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        wv::Lane<int> W;
+        WAVE_FOR(l) { const int j = j0 + l; W[l] = j < n ? src[j] : 0; }
+        const int peek = j0 + 64 < n ? (int)src[j0 + 64] : 0;
+        const int cnt = n - j0 < 64 ? n - j0 : 64;
+        for (int jj = 0; jj < cnt; ++jj) {
+            if (skip) { skip = false; continue; }
+            const int j = j0 + jj;
+            const int cw = wv::bcast(W, jj), nw = jj < 63 ? wv::bcast(W, jj + 1) : peek;
+            const int op = cw & 0xf, len = cw >> 4;
+            if (op == C_M) { HP_RS_PUSH(cw); rd_tot += len; if (len != 0) ref_rec += len; }
+            else if (op == C_I && len >= split_len) {
+                HP_RS_PUSH(((read_len - rd_tot) << 4) | C_S);
+                HP_RS_NEW_REC(0);
+                HP_RS_PUSH(((len + rd_tot) << 4) | C_S);
+                rd_tot += len;
+            } else if (op == C_D && len >= split_len) {
+                HP_RS_PUSH(((read_len - rd_tot) << 4) | C_S);
+                HP_RS_NEW_REC(len);
+                HP_RS_PUSH((rd_tot << 4) | C_S);
+            } else if (op == C_I) { HP_RS_PUSH(cw); rd_tot += len; }
+            else if (op == C_D) { HP_RS_PUSH(cw); ref_rec += len; }
+            else if (op == C_S) {
+                if (j > 0 && j < n - 1 && (nw & 0xf) == C_H) {
+                    const int Sn = len, Hn = nw >> 4;
+                    HP_RS_PUSH(((read_len - rd_tot) << 4) | C_S);
+                    HP_RS_NEW_REC(Hn);
+                    HP_RS_PUSH(((rd_tot + Sn) << 4) | C_S);
+                    rd_tot += Sn;
+                    skip = true;
+                } else { HP_RS_PUSH(cw); rd_tot += len; }
+            } else if (op != C_H) { cx.status |= ST_REFEXIT; return false; }
+        }
     }
-#undef CUR
-#undef NEW_REC
-    arena_release(cx.tmp, mark);
+    if (have) { if (used + wn < buf_cap) oc[used + wn++] = pend; else cx.status |= ST_OVERFLOW; }
+    cig_bind(la.rec[res_n].cig, buf + used, buf_cap - used); la.rec[res_n].cig.n = wn;
+#undef HP_RS_PUSH
+#undef HP_RS_NEW_REC
+    wv::sync();
     return !(cx.status & ST_OVERFLOW);
 }
 

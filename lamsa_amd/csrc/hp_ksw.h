@@ -25,20 +25,32 @@ namespace hp {
 HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, int n_col, int w, int i, int k, CigV &out)
 {
     const HP_G uint8_t *gz = (const HP_G uint8_t *)z;
-    int which = 0;
-    out.n = 0;
+    HP_G cig_t *oc = (HP_G cig_t *)out.c;
+    const int cap = out.cap;
+    // the run being built stays in registers; finished runs are stored and never read back (_push_cigar0 semantics)
+    int n = 0, pend = 0, which = 0;
+    bool have = false;
+#define HP_BT_PUSH(w_) do { const int v_ = (w_); if (have && (pend & 0xf) == (v_ & 0xf)) pend += (v_ >> 4) << 4; \
+        else { if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; } pend = v_; have = true; } } while (0)
     while (i >= 0 && k >= 0) {
         const int off = i > w ? i - w : 0;
         int cell = 255;
         if (k >= off && k - off < n_col) cell = lz ? lz[i * n_col + (k - off)] : gz[(long)i * n_col + (k - off)];
         which = cell >> (which << 1) & 3;
-        if (which == 0) { cig_push0(cx, out, 1 << 4 | C_M); --i; --k; }
-        else if (which == 1) { cig_push0(cx, out, 1 << 4 | C_D); --i; }
-        else { cig_push0(cx, out, 1 << 4 | C_I); --k; }
+        if (which == 0) { HP_BT_PUSH(1 << 4 | C_M); --i; --k; }
+        else if (which == 1) { HP_BT_PUSH(1 << 4 | C_D); --i; }
+        else { HP_BT_PUSH(1 << 4 | C_I); --k; }
     }
-    if (i >= 0) cig_push0(cx, out, (i + 1) << 4 | C_D);
-    if (k >= 0) cig_push0(cx, out, (k + 1) << 4 | C_I);
-    cig_invert(out.c, out.n);
+    if (i >= 0) HP_BT_PUSH((i + 1) << 4 | C_D);
+    if (k >= 0) HP_BT_PUSH((k + 1) << 4 | C_I);
+    if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; }
+#undef HP_BT_PUSH
+    wv::sync();
+    for (int b0 = 0; b0 < n / 2; b0 += 64) {                               // _invert_cigar, lane-parallel
+        WAVE_FOR(l) { const int a = b0 + l; if (a < n / 2) { const cig_t x = oc[a], y = oc[n - 1 - a]; oc[a] = y; oc[n - 1 - a] = x; } }
+    }
+    wv::sync();
+    out.n = n;
 }
 
 #define HP_SCAN_IDENT (-0x7f000000)
