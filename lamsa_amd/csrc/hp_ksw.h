@@ -558,6 +558,9 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
+#ifdef HP_PROF
+    { const int bk_ = qlen == 0 ? 0 : (qlen <= 16 ? 1 : (qlen <= 32 ? 2 : (qlen <= 64 ? 3 : (qlen <= 128 ? 4 : (qlen <= 256 ? 5 : (qlen <= 512 ? 6 : 7)))))); HP_TADD(cx, 48 + 2 * bk_, te0_); }
+#endif
     return max;
 }
 
