@@ -222,6 +222,9 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 //   * every lane remembers node id and edge class of its running best, so the winner is read out of a lane
 //     instead of being re-fetched.
 // One dependent round trip per target instead of seven.
+// `sons`: maintain the son lists (fnode_add_son).  They are read only by branch tracking, which runs after the main
+// pass of the first round and after the pass of frag_mini_dp_multi_line; both start from nodes that fnode_set has just
+// reset, so the lists a frag_mini_dp_line pass would leave behind are never read and that pass skips them.
 #ifdef HP_EMU_STATS
 void hp_emu_stat_call(int range, int lo, int hi, bool force);
 void hp_emu_stat_due(int range, int due, int span);
@@ -265,7 +268,7 @@ HP_INL void scan_eval(const EdgeK &K, const ScanT &S, const NodeS &Q, int p, int
     oka |= ok;
 }
 
-HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force)
+HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force, bool sons)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
@@ -481,6 +484,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             }
             if (changed) {
                 g_node_n[t] = g_node_n[max_from] + 1;
+            }
+            if (changed && sons) {
                 const int sn = g_son_n[max_from], la = g_last[max_from];      // fnode_add_son, :683
                 g_in_de[max_from] = g_in_de[max_from] + 1;
                 g_next[t] = -1;
@@ -496,7 +501,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     if (r.prof) r.prof[16] += wv::clock() - tu0_;
 #endif
 }
-HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true); }
+HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag, bool sons) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true, sons); }
 
 // ---------------------------------------------------------------- frag_min_extend for every MIN hit, :1031-1066, :1335-1343
 // For every MIN hit m (a hit of a seed with at most min_n hits) and every seed with more than min_n hits, the first
@@ -792,7 +797,7 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
         reach_run(r, right, Rw, &rlo, &rhi);
     }
     nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0, rlo, rhi);
-    dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false);      // callers guarantee left_x + 2 <= right_x
+    dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false, false);      // callers guarantee left_x + 2 <= right_x
 #ifdef HP_PROF
     const long long tm0_ = wv::clock();
     if (r.prof) r.prof[21] += 1;
@@ -828,7 +833,7 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     } else {
         r.n_from[right] = head; r.nd[right].score = old_score; r.nd[right].NM = old_NM; r.n_node_n[right] = 1;
         wv::sync();
-        dp_update(r, right, left_x + 1, dp_flag);
+        dp_update(r, right, left_x + 1, dp_flag, false);
         max_score = r.nd[right].score; max_NM = r.nd[right].NM; max_node = r.n_from[right]; max_n = r.n_node_n[right] - 1;
     }
     int cur = max_node, node_i = max_n - 1;
@@ -1133,7 +1138,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
         min_extend_all(r, min_n);
     }
     HP_CSTAMP(6);
-    if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false);                      // main pass, :1345-1350
+    if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, true);                      // main pass, :1345-1350
 
     HP_CSTAMP(7);
     NScore ns;
@@ -1225,7 +1230,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
     const lamsa_hp_para *P = r.cx.P;
     const int start = left_b + 1, end = right_b - 1, dp_flag = WHOLE_FLAG;
     nodes_per_init(r, hoff(r, start), hoff(r, end + 1), -1, dp_flag, 1);
-    if (start + 1 <= end) dp_update_range(r, hoff(r, start + 1), hoff(r, end + 1), start, dp_flag, false);
+    if (start + 1 <= end) dp_update_range(r, hoff(r, start + 1), hoff(r, end + 1), start, dp_flag, false, true);
     const size_t mark = arena_mark(r.cx.tmp);
     NScore ns;
     if (!ns_alloc(r.cx, ns, hoff(r, end + 1) - hoff(r, start) + 1, 0)) return 0;

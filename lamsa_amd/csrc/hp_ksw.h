@@ -20,13 +20,16 @@
 namespace hp {
 
 // ---- traceback (src/ksw.c:638-649 and :792-801).  The direction matrix lives in LDS (lz) when it fits, else in the
-// wave's HBM slab (gz).  Cells outside the row's window read as 255 = never written (src/ksw.c:707); inside the
-// window the forward pass has written every cell (255 where the band did not reach).
-HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, int n_col, int w, int i, int k, CigV &out)
+// wave's HBM slab (gz).  Cells the forward pass never wrote read as 255 (src/ksw.c:707): outside the row's window
+// always; inside it the LDS matrix holds 255 where the band did not reach, and for the HBM matrix of the extension
+// routine the per-row band limits (rowb) say which cells were written.
+HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out)
 {
-    const HP_G uint8_t *gz = (const HP_G uint8_t *)z;
-    HP_G cig_t *oc = (HP_G cig_t *)out.c;
-    const int cap = out.cap;
+    const HP_G uint8_t *gz = (const HP_G uint8_t *)wv::uni64((long long)z);
+    const HP_G hp_v2i *grb = (const HP_G hp_v2i *)wv::uni64((long long)rowb);     // HBM matrix of the extension routine: [beg, end) of every row
+    HP_G cig_t *oc = (HP_G cig_t *)wv::uni64((long long)out.c);
+    const int cap = wv::uni(out.cap);
+    n_col = wv::uni(n_col); w = wv::uni(w); i = wv::uni(i); k = wv::uni(k);
     // the run being built stays in registers; finished runs are stored and never read back (_push_cigar0 semantics)
     int n = 0, pend = 0, which = 0;
     bool have = false;
@@ -35,7 +38,13 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, int n
     while (i >= 0 && k >= 0) {
         const int off = i > w ? i - w : 0;
         int cell = 255;
-        if (k >= off && k - off < n_col) cell = lz ? lz[i * n_col + (k - off)] : gz[(long)i * n_col + (k - off)];
+        if (k >= off && k - off < n_col) {
+            if (lz) cell = lz[i * n_col + (k - off)];
+            else {
+                const int zc = gz[(long)i * n_col + (k - off)];
+                if (grb) { const hp_v2i be = grb[i]; cell = (k >= be.x && k < be.y) ? zc : 255; } else cell = zc;
+            }
+        }
         which = cell >> (which << 1) & 3;
         if (which == 0) { HP_BT_PUSH(1 << 4 | C_M); --i; --k; }
         else if (which == 1) { HP_BT_PUSH(1 << 4 | C_D); --i; }
@@ -135,7 +144,7 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         int i = tlen - 1;
         int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;                 // :638
         HP_T0(tb0_);
-        dp_backtrack(cx, nullptr, z, n_col, w, i, k, *out);
+        dp_backtrack(cx, nullptr, z, nullptr, n_col, w, i, k, *out);
         HP_TADD(cx, 28, tb0_);
     }
     arena_release(cx.tmp, mark);
@@ -157,11 +166,12 @@ HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, i
     const size_t mark = arena_mark(cx.tmp);
     int32_t *H = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
     int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
+    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
     uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
-    if (!H || !E || !z) { arena_release(cx.tmp, mark); return 0; }
+    if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return 0; }
 
     const int sc_match = P->match, sc_mis = -P->mis;
-    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E;
+    HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E, *growb = (HP_G int32_t *)rowb;
     HP_G uint8_t *gz = (HP_G uint8_t *)z;
     const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
     const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
@@ -194,9 +204,7 @@ HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, i
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
-        for (int c0 = 0; c0 < n_col; c0 += 64) {                           // window cells the band does not reach: never written
-            WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) gz[(long)i * n_col + c] = 255; }
-        }
+        growb[2 * i] = beg; growb[2 * i + 1] = end;
         int carryH = gH[beg];
         int Fin = 0;
         long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
@@ -289,7 +297,7 @@ HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, i
     else { i = max_ie; k = qlen - 1; }
     if (qle) *qle = k + 1;
     if (tle) *tle = i + 1;
-    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
     return max;
@@ -310,6 +318,8 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                             int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
     HP_T0(tg0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);            // wave-uniform: keep them in scalar registers
+    o_del = wv::uni(o_del); e_del = wv::uni(e_del); o_ins = wv::uni(o_ins); e_ins = wv::uni(e_ins);
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
     const size_t mark = arena_mark(cx.tmp);
@@ -318,10 +328,10 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
     HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
     HP_L uint8_t *LQ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS), *LZ = LQ + HP_LDS_CELLS;
-    HP_G uint8_t *gz = (HP_G uint8_t *)z;
-    const int sc_match = cx.P->match, sc_mis = -cx.P->mis;
-    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
-    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    const int sc_match = wv::uni(cx.P->match), sc_mis = -wv::uni(cx.P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
 #define HP_GH0(j) ((j) == 0 ? 0 : ((j) <= w ? -(o_ins + e_ins * (j)) : HP_NEG_INF))
     int hw = -1, qw = -1;
     wv::Lane<int> tl;
@@ -338,13 +348,13 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
         wv::sync();
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
-        int carryH = LH[beg & HP_LDS_MASK];          // H(i-1,beg-1), read before the in-place update below
+        int carryH = wv::uni(LH[beg & HP_LDS_MASK]);          // H(i-1,beg-1), read before the in-place update below
         int Fin = HP_NEG_INF;                        // F(i,beg)
         wv::sync();
         LH[beg & HP_LDS_MASK] = h1_init;             // eh[beg].h = H(i,beg-1)
         for (int j0 = beg; j0 < end; j0 += 64) {
             const int nxt = j0 + 64;
-            const int carry_next = LH[nxt & HP_LDS_MASK];   // old value, lane 63 is about to overwrite it
+            const int carry_next = wv::uni(LH[nxt & HP_LDS_MASK]);   // old value, lane 63 is about to overwrite it
             wv::Lane<int> m, e, key;
             WAVE_FOR(l) {
                 const int j = j0 + l;
@@ -385,13 +395,13 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         if (end > hw) hw = end;
         wv::sync();
     }
-    const int score = tlen > 0 ? (int)LH[qlen & HP_LDS_MASK] : HP_GH0(qlen);
+    const int score = tlen > 0 ? wv::uni((int)LH[qlen & HP_LDS_MASK]) : HP_GH0(qlen);
 #undef HP_GH0
     if (out) {
         const int i = tlen - 1;
         const int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;           // :638
         HP_T0(tb0_);
-        dp_backtrack(cx, zl ? LZ : nullptr, z, n_col, w, i, k, *out);
+        dp_backtrack(cx, zl ? LZ : nullptr, z, nullptr, n_col, w, i, k, *out);
         HP_TADD(cx, 28, tb0_);
     }
     arena_release(cx.tmp, mark);
@@ -414,21 +424,26 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
                             int *qle, int *tle, CigV *out)
 {
     HP_T0(te0_);
+    // Arguments of a non-inlined device function arrive in vector registers: tell the compiler that they are
+    // wave-uniform, so that loop counters, band limits and branches live in scalar registers.
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
     const lamsa_hp_para *P = cx.P;
-    const int o_ins = P->ins_ext_o, e_ins = P->ins_ext_e, o_del = P->del_ext_o, e_del = P->del_ext_e;
-    const int end_bonus = P->end_bonus, zdrop = P->zdrop;
+    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
+    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     const size_t mark = arena_mark(cx.tmp);
     const bool zl = (size_t)n_col * tlen <= HP_LDS_Z_BYTES;
     uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
-    if (!zl && !z) { arena_release(cx.tmp, mark); return 0; }
+    int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return 0; }
     HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
     HP_L uint8_t *LQ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS), *LZ = LQ + HP_LDS_CELLS;
-    HP_G uint8_t *gz = (HP_G uint8_t *)z;
-    const int sc_match = P->match, sc_mis = -P->mis;
-    const HP_G uint8_t *gq = (const HP_G uint8_t *)q.p; const int qs = q.stride;
-    const HP_G uint8_t *gt = (const HP_G uint8_t *)t.p; const int ts = t.stride;
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
+    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
     // first row, :692-694: h0, h0-oe_ins, then -e_ins per column while the previous cell is > e_ins
     const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
 #define HP_EH0(j) ((j) == 0 ? h0 : ((j) == 1 ? h1v : (((j) <= qlen && h1v - ((j) - 2) * e_ins > e_ins) ? h1v - ((j) - 1) * e_ins : 0)))
@@ -449,17 +464,14 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
             hw = end;
         }
         while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
-        for (int c0 = 0; c0 < n_col; c0 += 64) {                           // window cells the band does not reach: never written
-            WAVE_FOR(l) {
-                const int c = c0 + l, j = d_beg + c;
-                if (c < n_col && (j < beg || j >= end)) { if (zl) LZ[i * n_col + c] = 255; else gz[(long)i * n_col + c] = 255; }
-            }
-        }
+        if (zl) {                                                          // window cells the band does not reach: never written
+            for (int c0 = 0; c0 < n_col; c0 += 64) { WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) LZ[i * n_col + c] = 255; } }
+        } else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
         wv::sync();
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
-        int carryH = LH[beg & HP_LDS_MASK];
+        int carryH = wv::uni(LH[beg & HP_LDS_MASK]);
         int Fin = 0;
         long long best = -1;            // (h << 32 | j): row maximum, last j among equals (:743-744)
         int h_last = h1_init;           // H(i,end-1), or the first-column value when the row is empty
@@ -469,7 +481,7 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
         if (beg < end) LH[beg & HP_LDS_MASK] = h1_init; else LH[end & HP_LDS_MASK] = h1_init;   // eh[end].h = h1 when the row is empty (:758)
         for (int j0 = beg; j0 < end; j0 += 64) {
             const int nxt = j0 + 64;
-            const int carry_next = LH[nxt & HP_LDS_MASK];
+            const int carry_next = wv::uni(LH[nxt & HP_LDS_MASK]);
             wv::Lane<int> m, e, key;
             WAVE_FOR(l) {
                 const int j = j0 + l;
@@ -522,7 +534,7 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
         }
         // H(i,end-1): value of the last computed cell (needed for gscore / eh[end].h)
         wv::sync();
-        if (beg < end) h_last = LH[end & HP_LDS_MASK];
+        if (beg < end) h_last = wv::uni(LH[end & HP_LDS_MASK]);
         LE[end & HP_LDS_MASK] = 0;                                         // :758
         if (end > hw) hw = end;
         const int jj = beg < end ? end : beg;                              // loop variable j after the row
@@ -555,7 +567,7 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     else { i = max_ie; k = qlen - 1; }
     if (qle) *qle = k + 1;
     if (tle) *tle = i + 1;
-    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
 #ifdef HP_PROF

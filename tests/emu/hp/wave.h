@@ -13,6 +13,8 @@
 #define HP_G
 #define HP_L
 
+struct hp_v2i { int x, y; };
+struct hp_v4i { int x, y, z, w; };
 HP_INL void hp_load16(const void *p, int *o) { memcpy(o, p, 16); }
 HP_INL void hp_load8(const void *p, int *o) { memcpy(o, p, 8); }
 
