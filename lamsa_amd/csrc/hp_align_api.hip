@@ -5,6 +5,7 @@
 // collectives, no inter-workgroup communication except two atomics per read.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include "hp_align.h"
 #include "hp_handle.h"
@@ -89,24 +90,32 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     // ---- validate everything the kernels index with, on the host, before anything is launched
     S->h_len.assign((size_t)n, 0); S->h_H.assign((size_t)n, 0); S->max_L = 0; S->max_H = 0;
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
-    for (int r = 0; r < n; ++r) {
-        const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
-        if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { h->err = "read too long / too many seeds"; return LAMSA_HP_EINVAL; }
-        int64_t H = 0;
-        for (int64_t s = B->seed_off[r]; s < B->seed_off[r + 1]; ++s) {
-            const int64_t m = B->hit_off[s + 1] - B->hit_off[s];
-            if (m < 0 || m > HP_MAX_HITS_PER_SEED) { h->err = "too many hits in one seed"; return LAMSA_HP_EINVAL; }
-            if (B->seed_id[s] < 1 || B->seed_id[s] > B->seed_all[r] || (s > B->seed_off[r] && B->seed_id[s] <= B->seed_id[s - 1])) { h->err = "seed ids must be ascending in [1, seed_all]"; return LAMSA_HP_EINVAL; }
-            H += m;
-        }
-        if (H > (1 << 22)) { h->err = "too many hits in one read"; return LAMSA_HP_EINVAL; }
-        for (int64_t i = B->read_off[r]; i < B->read_off[r + 1]; ++i) if (B->read_seq[i] > 4) { h->err = "read base code > 4"; return LAMSA_HP_EINVAL; }
-        S->h_len[r] = (int32_t)L; S->h_H[r] = (int32_t)H;
-        S->max_L = std::max(S->max_L, (int32_t)L); S->max_H = std::max(S->max_H, (int32_t)H);
+    {
+        std::atomic<int> bad(0);                         // 1..6: which check failed (the first one reported wins)
+        hp_parallel_blocks(n, [&](int r0, int r1) {
+            for (int r = r0; r < r1 && !bad.load(std::memory_order_relaxed); ++r) {
+                const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
+                if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { bad = 1; return; }
+                int64_t H = 0;
+                for (int64_t s = B->seed_off[r]; s < B->seed_off[r + 1]; ++s) {
+                    const int64_t m = B->hit_off[s + 1] - B->hit_off[s];
+                    if (m < 0 || m > HP_MAX_HITS_PER_SEED) { bad = 2; return; }
+                    if (B->seed_id[s] < 1 || B->seed_id[s] > B->seed_all[r] || (s > B->seed_off[r] && B->seed_id[s] <= B->seed_id[s - 1])) { bad = 3; return; }
+                    H += m;
+                }
+                if (H > (1 << 22)) { bad = 4; return; }
+                for (int64_t i = B->read_off[r]; i < B->read_off[r + 1]; ++i) if (B->read_seq[i] > 4) { bad = 5; return; }
+                for (int64_t k = B->hit_off[B->seed_off[r]]; k < B->hit_off[B->seed_off[r + 1]]; ++k)
+                    if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) ||
+                        B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig) { bad = 6; return; }
+                S->h_len[r] = (int32_t)L; S->h_H[r] = (int32_t)H;
+            }
+        });
+        static const char *why[] = {"", "read too long / too many seeds", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
+                                    "too many hits in one read", "read base code > 4", "bad hit record"};
+        if (bad) { h->err = why[bad.load()]; return LAMSA_HP_EINVAL; }
+        for (int r = 0; r < n; ++r) { S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
     }
-    for (int64_t k = 0; k < n_hits; ++k)
-        if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) ||
-            B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig) { h->err = "bad hit record"; return LAMSA_HP_EINVAL; }
     // ---- processing order: costliest first (chaining ~ H^2/64 lane steps, extension ~ L * band)
     S->order.resize((size_t)n);
     for (int r = 0; r < n; ++r) S->order[r] = r;

@@ -75,34 +75,65 @@ HP_INL void cig_push0(Ctx &cx, CigV &v, cig_t w) {
 }
 // _push_cigar1, src/frag_check.h:153-156
 HP_INL void cig_push1(Ctx &cx, CigV &v, cig_t w) { if ((w >> 4) == 0) return; cig_push0(cx, v, w); }
-// _push_cigar, src/frag_check.h:158-184 (first word merges; I+S and S+I fuse into S)
+// _push_cigar, src/frag_check.h:158-184 (first word merges; I+S and S+I fuse into S).  The body is copied by the
+// lanes (one coalesced pass); source and destination never overlap.
 HP_FN void cig_pushv(Ctx &cx, CigV &v, const cig_t *c, int n) {
     if (n == 0) return;
+    const HP_G cig_t *src = (const HP_G cig_t *)c;
+    HP_G cig_t *dst = (HP_G cig_t *)v.c;
+    const int vn = v.n;
     int j = 0;
-    if (v.n > 0) {
-        cig_t last = v.c[v.n - 1];
-        if ((last & 0xf) == (c[0] & 0xf)) { v.c[v.n - 1] += (c[0] >> 4) << 4; j = 1; }
-        else if (((last & 0xf) == C_I && (c[0] & 0xf) == C_S) || ((last & 0xf) == C_S && (c[0] & 0xf) == C_I)) {
-            v.c[v.n - 1] = (((last >> 4) + (c[0] >> 4)) << 4) | C_S; j = 1;
+    if (vn > 0) {
+        const cig_t last = dst[vn - 1], c0 = src[0];
+        if ((last & 0xf) == (c0 & 0xf)) { dst[vn - 1] = last + ((c0 >> 4) << 4); j = 1; }
+        else if (((last & 0xf) == C_I && (c0 & 0xf) == C_S) || ((last & 0xf) == C_S && (c0 & 0xf) == C_I)) {
+            dst[vn - 1] = (((last >> 4) + (c0 >> 4)) << 4) | C_S; j = 1;
         }
     }
-    if (v.n + (n - j) > v.cap) { cx.status |= ST_OVERFLOW; return; }
-    for (; j < n; ++j) v.c[v.n++] = c[j];
+    const int m = n - j;
+    if (vn + m > v.cap) { cx.status |= ST_OVERFLOW; return; }
+    for (int b0 = 0; b0 < m; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < m) dst[vn + i] = src[j + i]; } }
+    v.n = vn + m;
+    wv::sync();
+}
+// _push_cigar with a one-word source held in a register
+HP_FN void cig_pushw(Ctx &cx, CigV &v, cig_t w) {
+    if (v.n > 0) {
+        const cig_t last = v.c[v.n - 1];
+        if ((last & 0xf) == (w & 0xf)) { v.c[v.n - 1] = last + ((w >> 4) << 4); return; }
+        if (((last & 0xf) == C_I && (w & 0xf) == C_S) || ((last & 0xf) == C_S && (w & 0xf) == C_I)) { v.c[v.n - 1] = (((last >> 4) + (w >> 4)) << 4) | C_S; return; }
+    }
+    if (v.n + 1 > v.cap) { cx.status |= ST_OVERFLOW; return; }
+    v.c[v.n++] = w;
 }
 // _invert_cigar, src/frag_check.h:124
 HP_FN void cig_invert(cig_t *c, int n) {
-    for (int i = 0; i < n / 2; ++i) { cig_t t = c[i]; c[i] = c[n - 1 - i]; c[n - 1 - i] = t; }
+    HP_G cig_t *g = (HP_G cig_t *)c;
+    for (int b0 = 0; b0 < n / 2; b0 += 64) {
+        WAVE_FOR(l) { const int a = b0 + l; if (a < n / 2) { const cig_t x = g[a], y = g[n - 1 - a]; g[a] = y; g[n - 1 - a] = x; } }
+    }
+    wv::sync();
 }
 // readInCigar (M,I,S) / refInCigar (M,D,H), src/frag_check.c:179,205
 HP_FN int cig_readlen(const cig_t *c, int n) {
-    int l = 0;
-    for (int i = 0; i < n; ++i) { int op = c[i] & 0xf; if (op == C_M || op == C_I || op == C_S) l += c[i] >> 4; }
-    return l;
+    const HP_G cig_t *g = (const HP_G cig_t *)c;
+    int tot = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+        wv::Lane<int> x;
+        WAVE_FOR(l) { const int i = b0 + l; int v = 0; if (i < n) { const cig_t w = g[i]; const int op = w & 0xf; if (op == C_M || op == C_I || op == C_S) v = w >> 4; } x[l] = v; }
+        tot += wv::reduce_sum(x);
+    }
+    return tot;
 }
 HP_FN int cig_reflen(const cig_t *c, int n) {
-    int l = 0;
-    for (int i = 0; i < n; ++i) { int op = c[i] & 0xf; if (op == C_M || op == C_D || op == C_H) l += c[i] >> 4; }
-    return l;
+    const HP_G cig_t *g = (const HP_G cig_t *)c;
+    int tot = 0;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+        wv::Lane<int> x;
+        WAVE_FOR(l) { const int i = b0 + l; int v = 0; if (i < n) { const cig_t w = g[i]; const int op = w & 0xf; if (op == C_M || op == C_D || op == C_H) v = w >> 4; } x[l] = v; }
+        tot += wv::reduce_sum(x);
+    }
+    return tot;
 }
 
 // strided view of a base sequence (stride -1 = reversed), 1 byte/base codes 0..4

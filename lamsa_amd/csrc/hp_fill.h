@@ -485,11 +485,11 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
     bool ok = true;
     if (strand == 1) {
         r.cur_read = r.read; r.flip = false;
-        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
         ok = HP_TIMED(32, head_fix(r, F, line, r0));
         for (int i = nfr - 1; i > 0 && ok; --i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i - 1, r0));
         ok = ok && HP_TIMED(34, frag_extend(r, F, f0, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
-        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = ((r.L - (F.right_bound[line] - 1) * P->seed_step) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = ((r.L - (F.right_bound[line] - 1) * P->seed_step) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
     } else {
         if (!r.rc_ready) {                                            // :922-925 (buffer reserved when the read was set up)
             for (int b = 0; b < r.L; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < r.L) { const int c = r.read[r.L - 1 - i]; r.rc_read[i] = c < 4 ? 3 - c : 4; } } }
@@ -499,11 +499,11 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
         r.cur_read = r.rc_read; r.flip = true;                        // :926
         const int tmp = F.left_bound[line];
         F.left_bound[line] = r.seed_all + 1 - F.right_bound[line]; F.right_bound[line] = r.seed_all + 1 - tmp;
-        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv + r.last_len) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv + r.last_len) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
         ok = HP_TIMED(32, head_fix(r, F, line, r0));
         for (int i = 0; i < nfr - 1 && ok; ++i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i + 1, r0));
         ok = ok && HP_TIMED(34, frag_extend(r, F, f0 + nfr - 1, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
-        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = (((r.seed_all - F.right_bound[line] + 1) * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += cig_readlen(&w, 1); }
+        if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = (((r.seed_all - F.right_bound[line] + 1) * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
     }
     ok = ok && HP_TIMED(40, res_split(r, la, rec_buf, rec_cap)) && HP_TIMED(42, res_aux(r, la));
     r.flip = false;                                                   // :953

@@ -6,7 +6,20 @@
 #pragma once
 #include <stdint.h>
 #include <algorithm>
+#include <thread>
 #include <vector>
+
+// fn(first, last) over [0, n) split into contiguous blocks, one per host thread (reads are independent)
+template <class F> static inline void hp_parallel_blocks(int n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int T = (int)(hw ? hw : 1); if (T > 32) T = 32;
+    if (n < 256 || T < 2) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + T - 1) / T;
+    for (int t = 0; t < T; ++t) { const int a = t * per, b = std::min(n, a + per); if (a < b) th.emplace_back([=]() { fn(a, b); }); }
+    for (auto &x : th) x.join();
+}
 
 static inline void hp_build_sort_index(int n_reads, const int64_t *seed_off, const int64_t *hit_off,
                                        const int64_t *h_pos, const int32_t *h_chr, const int8_t *h_strand,
@@ -14,9 +27,10 @@ static inline void hp_build_sort_index(int n_reads, const int64_t *seed_off, con
 {
     const int64_t n_hits = n_reads ? hit_off[seed_off[n_reads]] : 0;
     srt.assign((size_t)n_hits + 1, 0); rnk.assign((size_t)n_hits + 1, 0);
+    hp_parallel_blocks(n_reads, [&](int r0, int r1) {
     std::vector<uint64_t> key;
     std::vector<int32_t> idx;
-    for (int r = 0; r < n_reads; ++r) {
+    for (int r = r0; r < r1; ++r) {
         const int64_t hb = hit_off[seed_off[r]], he = hit_off[seed_off[r + 1]];
         const int H = (int)(he - hb);
         key.resize((size_t)H); idx.resize((size_t)H);
@@ -27,4 +41,5 @@ static inline void hp_build_sort_index(int n_reads, const int64_t *seed_off, con
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
         for (int i = 0; i < H; ++i) { srt[hb + i] = idx[i]; rnk[hb + idx[i]] = i; }
     }
+    });
 }

@@ -661,6 +661,13 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
     const lamsa_hp_para *P = cx.P;
     out.n = 0;
     if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }
+    if (qlen == 0 && lh0 > 0) {
+        // Nothing to align (adjacent seeds that overlap, the most frequent call): the left extension ends at the query
+        // end immediately, whatever row it stops in (:785-789 gives tle 0 or 1 and a "1D" or empty traceback), and :875-880
+        // completes it to a deletion of the whole target.
+        if (tlen > 0) cig_raw_push(cx, out, (tlen << 4) | C_D);
+        return 0;
+    }
     const size_t mark = arena_mark(cx.tmp);
     int ret = 0, res, lqe, lte, rqe, rte;
     CigV L, R;

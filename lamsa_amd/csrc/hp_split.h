@@ -258,7 +258,7 @@ HP_NOINL int split_indel_map(Ctx &cx, CigV &out, const uint8_t *read_seq, int re
             cig_pushv(cx, out, tmp.c, tmp.n);
         } else {
             indel_cigar(cx, -1, -1, _refi, _readi, g, &_clen, split_len, &res);
-            cig_pushv(cx, out, g, _clen);
+            if (_clen) cig_pushw(cx, out, g[0]);
             cig_push1(cx, out, (tail_in << 4) | C_M);
         }
         int start_i = 0, overlap = 0;                                     // 2. between anchors, :718-784
@@ -298,7 +298,7 @@ HP_NOINL int split_indel_map(Ctx &cx, CigV &out, const uint8_t *read_seq, int re
             } else {
                 cig_push1(cx, out, (head_in << 4) | C_M);
                 overlap = indel_cigar(cx, l_refi, l_readi, r_refi, r_readi, g, &_clen, split_len, &res);
-                cig_pushv(cx, out, g, _clen);
+                if (_clen) cig_pushw(cx, out, g[0]);
                 cig_push1(cx, out, (tail_in << 4) | C_M);
             }
             start_i = i + 1;
@@ -313,7 +313,7 @@ HP_NOINL int split_indel_map(Ctx &cx, CigV &out, const uint8_t *read_seq, int re
         } else {
             cig_push1(cx, out, (head_in << 4) | C_M);
             indel_cigar(cx, _refi, _readi, ref_len, read_len, g, &_clen, split_len, &res);
-            cig_pushv(cx, out, g, _clen);
+            if (_clen) cig_pushw(cx, out, g[0]);
         }
     } else {                                                              // no anchors, :807-819
         _t_len = ref_len; _q_len = read_len;

@@ -44,10 +44,10 @@ def test_params_match_reference_presets():
     assert list(d.sc_mat)[:6] == [1, -3, -3, -3, -1, -3] and list(d.sc_mat)[20:] == [-1] * 5
 
 
-def hp_para_like(rt):
+def hp_para_like(rt, **over):
     """lamsa_hp_para filled without the HIP library (host logic mirror for the emulation tests)."""
     from lamsa_amd.hp import HpPara
-    lp = reflib.lo_para(rt)
+    lp = reflib.lo_para(rt, **over)
     P = HpPara()
     for name, _ in HpPara._fields_:
         setattr(P, name, getattr(lp, name))
@@ -71,6 +71,33 @@ def test_emulated_kernels_edge_cases():
             (t200[:130], t200[:64]), (t200[:64], t200[:65]), (t200[:129], t200[:128])]
     for kind, w, h0 in ((0, 100, 0), (0, 1, 0), (1, 100, 50), (1, 2, 1), (2, 0, 100)):
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == []
+
+
+@pytest.mark.parametrize("rt,over", [("default", {}), ("pacbio", {}), ("ont2d", {}), ("default", {"end_bonus": 40}),
+                                     ("ont2d", {"del_ext_o": 30, "del_ext_e": 9}), ("pacbio", {"end_bonus": 0, "ins_ext_o": 9})])
+def test_emulated_bi_extend_with_empty_query(rt, over):
+    """ksw_bi_extend with nothing to align on the query side (overlapping neighbour seeds) takes a shortcut in the
+    kernels; the oracle runs the full extension.  Also checked against the compiled reference when present."""
+    lp, P = reflib.lo_para(rt, **over), hp_para_like(rt, **over)
+    rng = np.random.default_rng(3)
+    e = np.zeros(0, np.uint8)
+    jobs = [(e, rng.integers(0, 5, n, dtype=np.uint8)) for n in (0, 1, 2, 3, 5, 17, 60, 64, 65, 300)]
+    for h0 in (1, 2, 3, 8, 10, 50, 100):
+        want = reflib.oracle_dp(jobs, lp, 2, 0, h0)
+        assert goldenlib.same_dp(want, reflib.emu_dp(jobs, P, 2, 0, h0), 2) == []
+        if reflib.ref() is not None:
+            assert goldenlib.same_dp(reflib.ref_dp(jobs, reflib.ref_para(rt, **over), 2, 0, h0), want, 2) == []
+
+
+def test_emulated_wide_band_uses_hbm_rows():
+    """Bands wider than the LDS row (w > 222) take the HBM-row variants of both routines."""
+    lp, P = reflib.lo_para("default"), hp_para_like("default")
+    rng = np.random.default_rng(12)
+    t = rng.integers(0, 4, 1500, dtype=np.uint8)
+    q = dpjobs.mutate(rng, t[:1200], 0.02, 0.02, 0.02)
+    jobs = [(q, t), (q[:700], t[:900]), (q[:300], t[:1300])]
+    for kind, w, h0 in ((0, 400, 0), (1, 600, 5000), (1, 300, 20000)):
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == [], (kind, w)
 
 
 def test_emulated_kernels_long_extension():

@@ -64,3 +64,26 @@ def test_hip_whole_read_extension(handles):
         for kind, w, h0 in ((1, lp.band_w, 50), (2, 0, 100)):
             got = handles[rt].dp_batch(jobs, kind, w, h0)
             assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (rt, kind)
+
+
+def test_hip_bi_extend_with_empty_query(handles):
+    """The shortcut for overlapping neighbour seeds (query side empty) against the full extension of the oracle."""
+    rng = np.random.default_rng(3)
+    e = np.zeros(0, np.uint8)
+    jobs = [(e, rng.integers(0, 5, n, dtype=np.uint8)) for n in (0, 1, 2, 3, 5, 17, 60, 64, 65, 300)]
+    for rt in ("default", "pacbio", "ont2d"):
+        lp = reflib.lo_para(rt)
+        for h0 in (1, 2, 3, 8, 10, 50, 100):
+            assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 2, 0, h0), handles[rt].dp_batch(jobs, 2, 0, h0), 2) == [], (rt, h0)
+
+
+def test_hip_wide_band_uses_hbm_rows(handles):
+    """Bands wider than the LDS row (w > 222) take the HBM-row variants of both routines."""
+    lp = reflib.lo_para("default")
+    rng = np.random.default_rng(12)
+    t = rng.integers(0, 4, 1500, dtype=np.uint8)
+    q = dpjobs.mutate(rng, t[:1200], 0.02, 0.02, 0.02)
+    jobs = [(q, t), (q[:700], t[:900]), (q[:300], t[:1300])]
+    for kind, w, h0 in ((0, 400, 0), (1, 600, 5000), (1, 300, 20000)):
+        got = handles["default"].dp_batch(jobs, kind, w, h0)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (kind, w)
