@@ -159,6 +159,12 @@ int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
  * measured with HIP events on the stream the kernels ran on; n-th kernel of that call. */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
 
+/* Cap the per-wave scratch slab of the first pass at `bytes` (0 = size it from the batch, the default).  The slab
+ * replaces the reference's per-thread malloc/realloc arenas (src/lamsa_aln.c:960-990, src/frag_check.h:142-146);
+ * a read that does not fit is not truncated: it is flagged and re-run by the second pass with 8x capacities, as
+ * always.  For memory-constrained devices and for testing that second pass. */
+int lamsa_hp_set_scratch_limit(lamsa_hp_handle *h, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

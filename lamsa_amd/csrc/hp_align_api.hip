@@ -167,7 +167,8 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
 // one launch over `n_units` reads (order list on the device); results into `O`
 static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H, float *ms)
 {
-    const size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
+    size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
+    if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     int n_waves = h->n_cu * per_cu;
@@ -267,6 +268,13 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
     if (used1) HIPCHK(h, hipMemcpy(S->stream.data(), S->out1.stream(n), 4 * (size_t)used1, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     if (used2) HIPCHK(h, hipMemcpy(S->stream.data() + used1, S->out2.stream(n), 4 * (size_t)used2, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
     R->stream = S->stream.data(); R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data();
+    return LAMSA_HP_OK;
+}
+
+extern "C" int lamsa_hp_set_scratch_limit(lamsa_hp_handle *h, size_t bytes)
+{
+    if (!h || (bytes && bytes < ((size_t)64 << 10))) return LAMSA_HP_EINVAL;
+    h->scratch_limit = bytes;
     return LAMSA_HP_OK;
 }
 

@@ -55,7 +55,7 @@ class HpResult(C.Structure):
 
 
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
-           "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms",
+           "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms", "lamsa_hp_set_scratch_limit",
            "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded")
 
 _lib = None
@@ -85,6 +85,8 @@ def load_library(path=LIB_PATH):
         L.lamsa_hp_run_uploaded.restype = C.c_int
         L.lamsa_hp_last_kernel_ms.argtypes = [C.c_void_p, C.c_int]
         L.lamsa_hp_last_kernel_ms.restype = C.c_float
+        L.lamsa_hp_set_scratch_limit.argtypes = [C.c_void_p, C.c_size_t]
+        L.lamsa_hp_set_scratch_limit.restype = C.c_int
         _lib = L
     return _lib
 
@@ -145,6 +147,12 @@ class LamsaHp:
             self.close()
         except Exception:
             pass
+
+    def set_scratch_limit(self, nbytes):
+        """Cap the first pass's per-wave scratch (0 = automatic); reads that do not fit go to the 8x retry pass."""
+        rc = self.L.lamsa_hp_set_scratch_limit(self._h, int(nbytes))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_set_scratch_limit failed: %d" % rc)
 
     def last_kernel_ms(self, which=0):
         return float(self.L.lamsa_hp_last_kernel_ms(self._h, which))

@@ -65,3 +65,100 @@ def test_hip_rejects_malformed_batches(tmp_path):
     with pytest.raises(RuntimeError):
         h.align_batch(bad)
     h.close()
+
+
+def test_hip_second_pass_after_scratch_overflow(tmp_path):
+    """With the first pass's scratch capped far too low every read is flagged, nothing is written out of bounds, and
+    the second pass (8x capacities) delivers the same streams as the oracle."""
+    ref, reads, args, _ = goldenlib.stage_scenario("c3_ont", str(tmp_path))
+    rt, over = goldenlib.para_from_args(args)
+    lp = reflib.lo_para(rt, **over)
+    B = reflib.Batch(ref, reads, lp)
+    want = reflib.oracle_streams(B, lp)
+    h = _handle(B, rt, over)
+    h.set_scratch_limit(600 << 10)
+    got, st = h.align_batch(B)
+    assert h.last_kernel_ms(1) > 0                      # the retry kernel ran
+    assert got == want and (st == 0).all()
+    h.set_scratch_limit(0)
+    got, st = h.align_batch(B)
+    assert h.last_kernel_ms(1) == 0 and got == want
+    h.close()
+
+
+def _records(stream):
+    """(line, offset, chr, nstrand, score, NM, cigar words) of every record of one read's stream."""
+    out, i = [], 3
+    for ln in range(stream[1] + stream[2]):
+        n_res = stream[i + 3]; i += 4
+        for _ in range(n_res):
+            off = (stream[i] & 0xffffffff) | (stream[i + 1] << 32)
+            cn = stream[i + 6]
+            out.append((ln, off, stream[i + 2], stream[i + 3], stream[i + 4], stream[i + 5], stream[i + 7:i + 7 + cn]))
+            i += 7 + cn
+    assert i == len(stream)
+    return out
+
+
+def test_hip_full_size_batch_properties():
+    """A bench-sized batch (8192 x 10 kbp ONT-like reads, repeat-rich 400 Mbp reference): properties that do not
+    need the oracle on every read -- CIGARs consume exactly the read, records lie inside their contig, AS and NM
+    recomputed from CIGAR + sequences agree, almost every read finds its true locus, running twice or in another
+    order changes nothing -- plus word-for-word equality with the oracle on a sample."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import simbatch
+    from lamsa_amd import hp
+    n, L = 8192, 10000
+    ref = simbatch.SimRef(400_000_000, n_contigs=8, seed=5, threads=8)
+    B = simbatch.SimBatch(ref, n, L, "ont2d", seed=4242, threads=8)
+    P = hp.make_para("ont2d")
+    h = hp.LamsaHp(P, ref=(ref.pac, ref.l_pac, ref.seq_off, ref.seq_len))
+    h.upload_batch(B)
+    got, st = h.run_uploaded()
+    again, _ = h.run_uploaded()
+    assert got == again                                                  # idempotent on a resident batch
+    assert (st == 0).all()
+    mapped = 0
+    rng = np.random.default_rng(1)
+    check_as = set(rng.choice(n, 96, replace=False).tolist())
+    lp = reflib.lo_para("ont2d")
+    for r in range(n):
+        recs = _records(got[r])
+        mapped += bool(recs)
+        read = B.read_seq[int(B.read_off[r]):int(B.read_off[r + 1])]
+        for ln, off, chrom, nstrand, score, NM, cig in recs:
+            ops = [(w & 0xf, w >> 4) for w in cig]
+            assert all(o in (0, 1, 2, 4) and l > 0 for o, l in ops)
+            assert sum(l for o, l in ops if o in (0, 1, 4)) == L          # M, I, S consume the whole read
+            rl = sum(l for o, l in ops if o in (0, 2))
+            assert 1 <= chrom <= len(ref.seq_len) and off >= 1 and off - 1 + rl <= int(ref.seq_len[chrom - 1])
+            if r in check_as:                                             # lamsa_res_aux, src/frag_check.c:793-853
+                q = read if nstrand == 1 else np.where(read[::-1] < 4, 3 - read[::-1], 4)
+                k0 = int(ref.seq_off[chrom - 1]) + off - 1
+                ks = np.arange(k0, k0 + rl, dtype=np.int64)
+                t = (ref.pac[ks >> 2] >> ((~ks & 3) << 1)) & 3
+                qi = ti = mm = m = io = ie = do = de = 0
+                for o, l in ops:
+                    if o == 0:
+                        d = int((q[qi:qi + l] != t[ti:ti + l]).sum()); mm += d; m += l - d; qi += l; ti += l
+                    elif o == 1:
+                        qi += l; io += 1; ie += l
+                    elif o == 2:
+                        ti += l; do += 1; de += l
+                    else:
+                        qi += l
+                assert NM == mm + ie + de
+                assert score == m * lp.match - mm * lp.mis - io * lp.ins_gapo - ie * lp.ins_gape - do * lp.del_gapo - de * lp.del_gape
+    assert mapped >= 0.98 * n
+    # another order, a subset: per-read streams must not depend on what else is in the batch
+    sub = rng.choice(n, 512, replace=False).tolist()
+    got_sub, _ = h.align_batch(simbatch.take(B, sub))
+    assert got_sub == [got[i] for i in sub]
+    # the oracle on a sample
+    import bench
+    first = bench.take_first(B, 96)
+    want = reflib.oracle_streams(first, lp, 8)
+    assert [i for i in range(96) if want[i] != got[i]] == []
+    h.close()

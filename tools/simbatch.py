@@ -111,3 +111,32 @@ class SimBatch:
         self.n_slots, self.n_hits = int(ns), int(nh)
         L.sim_batch_free(bp)
         self.pac, self.l_pac, self.seq_off, self.seq_len = ref.pac, ref.l_pac, ref.seq_off, ref.seq_len
+
+
+def take(B, idx):
+    """The reads `idx` of a batch, in that order, as a new batch object (the seed-CIGAR arena is shared)."""
+    class _Sub:
+        pass
+    s = _Sub()
+    idx = [int(i) for i in idx]
+    n = len(idx)
+    s.n_reads = n
+    lens = np.array([B.read_off[i + 1] - B.read_off[i] for i in idx], np.int64)
+    s.read_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    s.read_seq = np.concatenate([B.read_seq[int(B.read_off[i]):int(B.read_off[i + 1])] for i in idx] + [np.zeros(8, np.uint8)])
+    s.seed_all = np.ascontiguousarray(B.seed_all[idx]) if n else np.zeros(4, np.int32)
+    s.last_len = np.ascontiguousarray(B.last_len[idx]) if n else np.zeros(4, np.int32)
+    ns = np.array([B.seed_off[i + 1] - B.seed_off[i] for i in idx], np.int64)
+    s.seed_off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    slots = np.concatenate([np.arange(B.seed_off[i], B.seed_off[i + 1]) for i in idx] + [np.zeros(0, np.int64)]).astype(np.int64)
+    s.seed_id = np.concatenate([B.seed_id[slots], np.zeros(4, np.int32)]).astype(np.int32)
+    nh = (B.hit_off[slots + 1] - B.hit_off[slots]) if len(slots) else np.zeros(0, np.int64)
+    s.hit_off = np.concatenate([[0], np.cumsum(nh)]).astype(np.int64)
+    hits = np.concatenate([np.arange(B.hit_off[B.seed_off[i]], B.hit_off[B.seed_off[i + 1]]) for i in idx] + [np.zeros(0, np.int64)]).astype(np.int64)
+    for k in ("h_pos", "h_chr", "h_strand", "h_nm", "h_len_dif", "h_cig_off", "h_cig_n"):
+        a = getattr(B, k)
+        setattr(s, k, np.concatenate([a[hits], np.zeros(4, a.dtype)]))
+    s.cig = B.cig
+    s.n_slots, s.n_hits = int(len(slots)), int(len(hits))
+    s.pac, s.l_pac, s.seq_off, s.seq_len = B.pac, B.l_pac, B.seq_off, B.seq_len
+    return s
