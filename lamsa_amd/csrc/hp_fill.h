@@ -50,8 +50,8 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
 }
 
 // ---------------------------------------------------------------- merge_cigar, frag_check.c:251-328
-HP_NOINL bool merge_cigar(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_readend, int chr,
-                          const cig_t *_c2, int c2_n, int c2_reflen, int c2_readlen)
+HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_readend, int chr,
+                               const cig_t *_c2, int c2_n, int c2_reflen, int c2_readlen)
 {
     if (c2_n == 0) return true;
     Ctx &cx = r.cx;
@@ -128,6 +128,26 @@ HP_NOINL bool merge_cigar(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_read
     return true;
 }
 
+// The junction test of merge_cigar (:256-263) decides between a plain append -- by far the common case, done here
+// without a call -- and the boundary repair, which is the only part worth a call frame.  _c2 must lie in HBM.
+HP_INL bool merge_cigar(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_readend, int chr,
+                        const cig_t *_c2, int c2_n, int c2_reflen, int c2_readlen)
+{
+    if (c2_n == 0) return true;
+    const int n1 = c1.n;
+    if (n1 > 1) {
+        const cig_t t = ((const HP_G cig_t *)c1.c)[n1 - 1], h = ((const HP_G cig_t *)_c2)[0];
+        const int top = t & 0xf, hop = h & 0xf;
+        if ((((top == C_I || top == C_D) && (t >> 4) <= 3) && hop != C_S && hop != C_H) ||
+            (((hop == C_I || hop == C_D) && (h >> 4) <= 3) && top != C_S && top != C_H))
+            return merge_cigar_full(r, c1, c1_refend, c1_readend, chr, _c2, c2_n, c2_reflen, c2_readlen);
+    }
+    cig_pushv(r.cx, c1, _c2, c2_n);
+    *c1_refend += c2_reflen;
+    *c1_readend += c2_readlen;
+    return true;
+}
+
 // read interval between two chained seeds (get_read_intv, :116): pointer into the strand-appropriate read
 HP_INL int read_gap(const ReadCtx &r, int s1, int s2, const uint8_t **p)
 {
@@ -140,7 +160,7 @@ HP_INL int read_gap(const ReadCtx &r, int s1, int s2, const uint8_t **p)
 }
 
 // ---------------------------------------------------------------- frag_extend, :332-410
-HP_NOINL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
+HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
 {
     Ctx &cx = r.cx;
     const lamsa_hp_para *P = cx.P;
@@ -187,32 +207,41 @@ HP_NOINL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
     return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
 }
 
+// A fragment of one seed (every fragment of a noisy read whose neighbours are not exactly colinear): the loop of
+// :360-400 does not run and the seed's own CIGAR is merged as it is (:402-405).
+HP_INL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
+{
+    const int o0 = F.fr_seed_off[frag], o1 = F.fr_seed_off[frag + 1];
+    if (o1 - o0 != 1) return frag_extend_multi(r, F, frag, res);
+    const lamsa_hp_para *P = r.cx.P;
+    const int s = F.fr_seed[o0];
+    const bool ok = merge_cigar(r, res.cig, &res.refend, &res.readend, r.h_chr[s], r.cig + r.h_cig_off[s], r.h_cig_n[s],
+                                P->seed_len + r.h_len_dif[s], P->seed_len);
+    return ok && !(r.cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
 // ---------------------------------------------------------------- split_mapping, :416-564
-HP_NOINL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &res)
+// Geometry of the junction between two fragments (:424-470), computed once and handed to whichever branch applies.
+struct SplitGeo {
+    const uint8_t *qp; int64_t at1_off, at2_off; int at1_ld, at1_chr, at2_chr, did, s_qlen, dis, match_dis;
+};
+
+// DEL / INS / DUP branches (:475-546): the structural-variant cases, rare on ordinary reads
+HP_NOINL bool split_sv(ReadCtx &r, const SplitGeo &g, Rec &res)
 {
     Ctx &cx = r.cx;
     const lamsa_hp_para *P = cx.P;
-    const int32_t *sd1 = F.fr_seed + F.fr_seed_off[f1], *sd2 = F.fr_seed + F.fr_seed_off[f2];
-    const int n1 = F.fr_seed_off[f1 + 1] - F.fr_seed_off[f1], n2 = F.fr_seed_off[f2 + 1] - F.fr_seed_off[f2];
-    int s1, s2;
-    if (r.h_strand[sd1[0]] == 1) { s1 = sd1[0]; s2 = sd2[n2 - 1]; }
-    else { s1 = sd1[n1 - 1]; s2 = sd2[0]; }
-    const int64_t at1_off = r.h_pos[s1], at2_off = r.h_pos[s2];
-    const int at1_ld = r.h_len_dif[s1], at1_chr = r.h_chr[s1], at2_chr = r.h_chr[s2];
-    const int hash_len = P->hash_len, did = sid(r, r.n_seed[s2]) - sid(r, r.n_seed[s1]);
-    const int s_qlen = did * P->seed_step - P->seed_len;
-    if (s_qlen < 0) { cx.status |= ST_REFEXIT; return false; }
-    const uint8_t *qp; read_gap(r, s1, s2, &qp);
-    const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
-    const int dis = (int)(at2_off - exp);
-    const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
+    const int hash_len = P->hash_len, s_qlen = g.s_qlen, dis = g.dis;
+    const uint8_t *qp = g.qp;
+    const int64_t at1_off = g.at1_off, at2_off = g.at2_off;
+    const int at1_ld = g.at1_ld, at1_chr = g.at1_chr, at2_chr = g.at2_chr;
     const int gh0 = hash_len * P->match;
     const size_t mark = arena_mark(cx.tmp);
     int s_tlen = 0;
     int32_t tl;
     CigV sc;
     bool ok = true;
-    if (dis > match_dis) {                                        // DEL, :475-489
+    if (dis > g.match_dis) {                                      // DEL, :475-489
         s_tlen = s_qlen + dis; tl = s_tlen;
         uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)(s_tlen > 0 ? s_tlen : 0) + 16);
         ok = tb && cig_alloc(cx, sc, s_qlen + s_tlen + 64) && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld - 1, &tl, tb);
@@ -221,7 +250,7 @@ HP_NOINL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &re
             if (s_qlen < hash_len) ksw_bi_extend(cx, s_qlen, seq_fwd(qp), s_tlen, seq_fwd(tb), gh0, gh0, sc);
             else split_indel_map(cx, sc, qp, s_qlen, tb, s_tlen, 0);
         }
-    } else if (dis < -match_dis) {                                // INS, :490-546
+    } else {                                                      // INS, :490-546
         s_tlen = s_qlen + dis;
         if (s_tlen < 2 * P->hash_step) {                          // overlapped insertion: extend from both sides
             int32_t _s_tlen = s_qlen + hash_len;
@@ -253,16 +282,75 @@ HP_NOINL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &re
                 else split_indel_map(cx, sc, qp, s_qlen, tb + hash_len - dis, s_tlen, off_dis);
             }
         }
-    } else {                                                      // mismatch class, :547-559
-        s_tlen = s_qlen + dis; tl = s_tlen;
-        if (s_tlen < 0) { cx.status |= ST_REFEXIT; ok = false; }  // ksw_extend_core exit(-1), ksw.c:672
-        else {
-            uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)s_tlen + 16);
-            ok = tb && cig_alloc(cx, sc, s_qlen + s_tlen + 64) && ref_fetch(r, at1_chr, at1_off + P->seed_len + at1_ld - 1, &tl, tb);
-            if (ok) { s_tlen = tl; ksw_bi_extend(cx, s_qlen, seq_fwd(qp), s_tlen, seq_fwd(tb), 100, 100, sc); }
-        }
     }
     if (ok) ok = merge_cigar(r, res.cig, &res.refend, &res.readend, at1_chr, sc.c, sc.n, s_tlen, s_qlen);
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+// mismatch class with read bases between the seeds (:547-559): two-sided extension
+HP_NOINL bool split_mismatch(ReadCtx &r, const SplitGeo &g, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    int s_tlen = g.s_qlen + g.dis;
+    if (s_tlen < 0) { cx.status |= ST_REFEXIT; return false; }                 // ksw_extend_core exit(-1), ksw.c:672
+    const size_t mark = arena_mark(cx.tmp);
+    int32_t tl = s_tlen;
+    CigV sc;
+    uint8_t *tb = (uint8_t *)arena_alloc(cx, (size_t)s_tlen + 16);
+    bool ok = tb && cig_alloc(cx, sc, g.s_qlen + s_tlen + 64) && ref_fetch(r, g.at1_chr, g.at1_off + P->seed_len + g.at1_ld - 1, &tl, tb);
+    if (ok) {
+        s_tlen = tl;
+        ksw_bi_extend(cx, g.s_qlen, seq_fwd(g.qp), s_tlen, seq_fwd(tb), 100, 100, sc);
+        ok = merge_cigar(r, res.cig, &res.refend, &res.readend, g.at1_chr, sc.c, sc.n, s_tlen, g.s_qlen);
+    }
+    arena_release(cx.tmp, mark);
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+}
+
+HP_INL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int32_t *sd1 = F.fr_seed + F.fr_seed_off[f1], *sd2 = F.fr_seed + F.fr_seed_off[f2];
+    const int n1 = F.fr_seed_off[f1 + 1] - F.fr_seed_off[f1], n2 = F.fr_seed_off[f2 + 1] - F.fr_seed_off[f2];
+    int s1, s2;
+    if (r.h_strand[sd1[0]] == 1) { s1 = sd1[0]; s2 = sd2[n2 - 1]; }
+    else { s1 = sd1[n1 - 1]; s2 = sd2[0]; }
+    SplitGeo g;
+    g.at1_off = r.h_pos[s1]; g.at2_off = r.h_pos[s2];
+    g.at1_ld = r.h_len_dif[s1]; g.at1_chr = r.h_chr[s1]; g.at2_chr = r.h_chr[s2];
+    g.did = sid(r, r.n_seed[s2]) - sid(r, r.n_seed[s1]);
+    g.s_qlen = g.did * P->seed_step - P->seed_len;
+    if (g.s_qlen < 0) { cx.status |= ST_REFEXIT; return false; }
+    read_gap(r, s1, s2, &g.qp);
+    const int64_t exp = g.at1_off + g.at1_ld + (int64_t)(g.did * P->seed_step);
+    g.dis = (int)(g.at2_off - exp);
+    g.match_dis = P->match_dis * ((P->aln_mode & 2) ? g.did : 1);
+    if (g.dis > g.match_dis || g.dis < -g.match_dis) return split_sv(r, g, res);
+    if (g.s_qlen > 0) return split_mismatch(r, g, res);
+    // Mismatch class with no read base between the seeds (neighbouring seeds overlap by design, so this is most
+    // junctions of a noisy read): ksw_bi_extend has nothing to align and returns "delete the whole target"
+    // (see the shortcut in ksw_bi_extend).  The reference still cuts the window at the contig end (bntseq.c:469-474),
+    // which is reproduced here; the window itself is not needed.
+    int s_tlen = g.dis;
+    if (s_tlen < 0) { cx.status |= ST_REFEXIT; return false; }                 // ksw_extend_core exit(-1), ksw.c:672
+    {
+        const int64_t start0 = g.at1_off + P->seed_len + g.at1_ld - 1;
+        const int32_t clen = r.ref.seq_len[g.at1_chr - 1];
+        if (start0 > clen || start0 < 0) { cx.status |= ST_REFEXIT; return false; }
+        if (start0 + s_tlen > clen) s_tlen = (int)(clen - start0);
+    }
+    if (s_tlen <= 0) return !(cx.status & (ST_REFEXIT | ST_OVERFLOW));          // empty CIGAR: merge_cigar returns at once (:254)
+    const size_t mark = arena_mark(cx.tmp);
+    cig_t *w = (cig_t *)arena_alloc(cx, sizeof(cig_t));
+    bool ok = w != nullptr;
+    if (ok) {
+        ((HP_G cig_t *)w)[0] = (s_tlen << 4) | C_D;
+        wv::sync();
+        ok = merge_cigar(r, res.cig, &res.refend, &res.readend, g.at1_chr, w, 1, s_tlen, 0);
+    }
     arena_release(cx.tmp, mark);
     return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
 }

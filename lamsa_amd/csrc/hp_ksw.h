@@ -668,12 +668,14 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
         if (tlen > 0) cig_raw_push(cx, out, (tlen << 4) | C_D);
         return 0;
     }
+    HP_T0(tbi0_);
     const size_t mark = arena_mark(cx.tmp);
     int ret = 0, res, lqe, lte, rqe, rte;
     CigV L, R;
     if (!cig_alloc(cx, L, qlen + tlen + 4) || !cig_alloc(cx, R, qlen + tlen + 4)) { arena_release(cx.tmp, mark); return 0; }
     const int w = iabs(qlen - tlen) + 3 > P->band_w ? iabs(qlen - tlen) + 3 : P->band_w;   // :873
     res = ksw_extend_c(cx, qlen, q, tlen, t, w, lh0, &lqe, &lte, &L);
+    HP_T0(tbi1_);
     if (res < 2) {                                                                          // :875-880
         cig_pushv(cx, out, L.c, L.n);
         cig_push1(cx, out, res == 0 ? ((tlen - lte) << 4) | C_D : ((qlen - lqe) << 4) | C_I);
@@ -694,6 +696,8 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
         }
     }
     arena_release(cx.tmp, mark);
+    HP_TADD(cx, 50, tbi1_);
+    HP_TADD(cx, 48, tbi0_);
     return ret;
 }
 
