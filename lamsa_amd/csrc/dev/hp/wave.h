@@ -25,6 +25,7 @@ typedef int hp_v2i __attribute__((ext_vector_type(2)));
 // whole-vector loads: the compiler cannot sink individual members of a record behind later branches
 HP_INL void hp_load16(const HP_G void *p, int *o) { hp_v4i v = *(const HP_G hp_v4i *)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 HP_INL void hp_load8(const HP_G void *p, int *o) { hp_v2i v = *(const HP_G hp_v2i *)p; o[0] = v.x; o[1] = v.y; }
+HP_INL void hp_store16(HP_G void *p, int a, int b, int c, int d) { hp_v4i v; v.x = a; v.y = b; v.z = c; v.w = d; *(HP_G hp_v4i *)p = v; }
 
 namespace wv {
 

@@ -772,10 +772,250 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
     *rlo = lo; *rhi = hi;
 }
 
+// ---------------------------------------------------------------- frag_mini_dp_line with the whole pass in registers
+// Most mini-DP passes involve few hits: either the seed range between the two anchors is short, or (pass from START)
+// only the hits that can reach the right anchor matter (reach_run).  Up to HP_MS_SETS x 64 such hits are loaded once,
+// one per lane and set, and frag_dp_per_init, frag_dp_update over the range, the forced update of the right anchor
+// (or the choice of the best end node), the walk back along the chosen predecessors and the final state of every
+// touched hit are computed on those registers; memory sees one gather at the start and one scatter at the end.
+// Candidates of a target are then simply all loaded hits of earlier seeds -- what the reference scans -- so no
+// window pruning is involved.  Hits of the range that are not loaded (pass from START, outside the run) keep their
+// previous state: they can neither be candidates nor targets of this pass (see reach_run), and every later pass
+// re-initialises the hits it uses (fnode_set) before reading them.
+// Returns -1 when the hits do not fit; the caller then runs the pass through memory (mini_line).
+#define HP_MS_SETS 4
+HP_INL int ms_pick(const wv::Lane<int> *f, int c) {
+    const int l = c & 63, j = c >> 6;
+    const int v0 = wv::bcast(f[0], l), v1 = wv::bcast(f[1], l), v2 = wv::bcast(f[2], l), v3 = wv::bcast(f[3], l);
+    return j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
+}
+HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+{
+    left = wv::uni(left); right = wv::uni(right); right_x = wv::uni(right_x); _head = wv::uni(_head); _tail = wv::uni(_tail);
+    const int head = _head ? left : -1;
+    const int left_x = nx(r, left);
+    const int dp_flag = MULTI_FLAG;
+    const int start_slot = left_x + 1;
+    const int k_lo = wv::uni(hoff(r, start_slot)), k_hi = wv::uni(hoff(r, right_x)), k_t0 = wv::uni(hoff(r, left_x + 2));
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
+    const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
+    const EdgeK K = edge_consts(r.cx.P);
+    const int POSMAX = (1 << 28) - 1;
+    // ---- which hits
+    int n_ids, rlo = 0;
+    bool by_run = false;
+    if (k_hi - k_lo <= 64 * HP_MS_SETS) n_ids = k_hi - k_lo;
+    else if (head < 0 && _tail != 0 && right >= 0) {
+        const lamsa_hp_para *P = r.cx.P;
+        const int did_max = r.seed_id[right_x] - r.seed_id[left_x + 1];
+        const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
+        long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
+        if (mdm + 1 > Rw) Rw = mdm + 1;
+        Rw += 128 + (long long)did_max * P->seed_step;
+        int rhi;
+        reach_run(r, right, Rw, &rlo, &rhi);
+        rlo = wv::uni(rlo); rhi = wv::uni(rhi);
+        if (rhi - rlo + 1 > 64 * HP_MS_SETS) return -1;
+        by_run = true; n_ids = rhi - rlo + 1;
+    } else return -1;
+    // ---- anchors
+    NodeS Fh; Fh.pos = 0; Fh.chr = 0; Fh.slot_j = 0; Fh.sid = 0; Fh.strand = 0; Fh.len_dif8 = 0; Fh.pad_ = 0; Fh.dp_flag = 0; Fh.son_flag = 0; Fh.match_flag = 0; Fh.score = 0; Fh.NM = 0;
+    NodeS Rt = Fh;
+    int head_nm = 0, right_nm = 0;
+    if (head >= 0) { Fh = node_load(ns + head); head_nm = g_hnm[head]; }
+    if (right >= 0) { Rt = node_load(ns + right); right_nm = g_hnm[right]; }
+    const int left_NM = left < 0 ? 0 : (left == head ? head_nm : (int)g_hnm[left]);
+    int old_score, old_NM;
+    if (_tail == 0) { old_score = 1; old_NM = left_NM; }
+    else { old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm; }
+    // ---- gather + frag_dp_per_init (:766-784, :1086-1091)
+    wv::Lane<int> A0[HP_MS_SETS], A1[HP_MS_SETS], A2[HP_MS_SETS], A3[HP_MS_SETS], B0[HP_MS_SETS];
+    wv::Lane<int> Dpf[HP_MS_SETS], Son[HP_MS_SETS], Mf[HP_MS_SETS], Sc[HP_MS_SETS], Nm[HP_MS_SETS], Fr[HP_MS_SETS], Nn[HP_MS_SETS], Cf[HP_MS_SETS], Id[HP_MS_SETS], Tk[HP_MS_SETS];
+#pragma unroll
+    for (int j = 0; j < HP_MS_SETS; ++j) {
+        WAVE_FOR(l) {
+            const int idx = 64 * j + l;
+            const bool valid = idx < n_ids;
+            const int id = valid ? (by_run ? (int)g_srt[rlo + idx] : k_lo + idx) : 0;
+            int a[4], b[4];
+            hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
+            const int nm0 = g_hnm[id];
+            const int slot = a[3] >> 14;
+            const int df = (int)(int8_t)(b[1] & 0xff);
+            const bool take = valid && slot >= start_slot && slot < right_x && (df == dp_flag || df == 0 - dp_flag);
+            int dpf = df, son = (b[1] >> 8) & 0xff, mf = (b[1] >> 16) & 0xff, sc = b[2], nm = b[3], fr = -1;
+            if (take) {
+                if (head < 0) { dpf = dp_flag; son = F_INIT; mf = F_MATCH; sc = 1; nm = nm0; fr = -1; }
+                else {
+                    const NodeS Q = node_unpack(a, b);
+                    const int flag = edge_flag_packed(K, Fh, Q);
+                    if (flag != F_UNCONNECT && flag != F_CHR_DIF) { dpf = dp_flag; son = F_INIT; mf = flag; sc = 2 + score_table(flag); nm = nm0 + head_nm; fr = head; }
+                    else dpf = 0 - dp_flag;
+                }
+            }
+            A0[j][l] = a[0]; A1[j][l] = a[1]; A2[j][l] = a[2]; A3[j][l] = a[3]; B0[j][l] = b[0];
+            Dpf[j][l] = dpf; Son[j][l] = son; Mf[j][l] = mf; Sc[j][l] = sc; Nm[j][l] = nm; Fr[j][l] = fr; Nn[j][l] = 1; Cf[j][l] = -1;
+            Id[j][l] = id; Tk[j][l] = take ? 1 : 0;
+        }
+    }
+#define HP_MS_Q(j, l, Q) do { int a_[4] = { A0[j][l], A1[j][l], A2[j][l], A3[j][l] }; \
+        int b_[4] = { B0[j][l], (Dpf[j][l] & 0xff) | (Son[j][l] << 8) | (Mf[j][l] << 16), Sc[j][l], Nm[j][l] }; Q = node_unpack(a_, b_); } while (0)
+    // one target T against every loaded hit; returns the winner (cidx, or -1) and its edge class, score and NM
+#define HP_MS_SCAN(S, t_from_id, w_c, w_flag, w_score, w_nm, changed_) do { \
+        wv::Lane<long long> key; wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl; \
+        WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; } \
+        _Pragma("unroll") for (int j = 0; j < HP_MS_SETS; ++j) { \
+            WAVE_FOR(l) { NodeS Q; HP_MS_Q(j, l, Q); int ow_, oka_ = 0; \
+                scan_eval(K, S, Q, 64 * j + l, Tk[j][l] & (Dpf[j][l] == dp_flag), start_slot, dp_flag, key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow_, oka_); \
+                okl[l] |= oka_; } } \
+        w_c = -1; changed_ = false; \
+        if (wv::ballot(okl) != 0) { \
+            const int npos = wv::reduce_max(negp); \
+            if (npos != -0x7fffffff) { \
+                wv::Lane<int> w_; WAVE_FOR(l) w_[l] = negp[l] == npos; \
+                const int wl = __builtin_ctzll(wv::ballot(w_)); \
+                w_c = wv::bcast(n_p, wl); w_flag = wv::bcast(n_f, wl); w_score = wv::bcast(n_c, wl); w_nm = wv::bcast(n_n, wl); \
+                changed_ = ms_pick(Id, w_c) != (t_from_id); \
+            } else { \
+                const long long best_key = wv::reduce_max64(key); \
+                if (best_key >= 0) { \
+                    const int nm_ = 524287 - (int)((best_key >> 28) & 524287), cand_ = (int)(best_key >> 47) - 32768; \
+                    if (cand_ > w_score || (cand_ == w_score && nm_ < w_nm)) { \
+                        wv::Lane<int> w_; WAVE_FOR(l) w_[l] = key[l] == best_key; \
+                        const int wl = __builtin_ctzll(wv::ballot(w_)); \
+                        w_c = wv::bcast(bp, wl); w_flag = wv::bcast(bf, wl); w_score = cand_; w_nm = nm_; \
+                        changed_ = ms_pick(Id, w_c) != (t_from_id); \
+                    } } } } } while (0)
+    // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
+    for (int k_next = k_t0;;) {
+        wv::Lane<int> m;
+        WAVE_FOR(l) {
+            int v = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < HP_MS_SETS; ++j) { const int id = Id[j][l]; if (Tk[j][l] && Dpf[j][l] == dp_flag && id >= k_next && id < v) v = id; }
+            m[l] = 0 - v;
+        }
+        const int kmin = 0 - wv::reduce_max(m);
+        if (kmin == 0x7fffffff) break;
+        k_next = kmin + 1;
+        int tc = 0;
+#pragma unroll
+        for (int j = 0; j < HP_MS_SETS; ++j) {
+            wv::Lane<int> e;
+            WAVE_FOR(l) e[l] = Tk[j][l] && Id[j][l] == kmin;
+            const unsigned long long bm = wv::ballot(e);
+            if (bm) tc = 64 * j + __builtin_ctzll(bm);
+        }
+        ScanT S;
+        {
+            int a[4] = { ms_pick(A0, tc), ms_pick(A1, tc), ms_pick(A2, tc), ms_pick(A3, tc) };
+            int b[4] = { ms_pick(B0, tc), 0, ms_pick(Sc, tc), ms_pick(Nm, tc) };
+            S.T = node_unpack(a, b);
+        }
+        S.x = S.T.slot_j >> 14; S.t_NM = S.T.NM; S.tkey = S.T.chr * 2 + (S.T.strand > 0 ? 1 : 0); S.Rw = 0x7fffffffffffll;
+        const int t_from = ms_pick(Fr, tc);
+        int w_c, w_flag = 0, w_score = S.T.score, w_nm = S.t_NM; bool changed;
+        HP_MS_SCAN(S, t_from, w_c, w_flag, w_score, w_nm, changed);
+        if (changed) {
+            const int from_id = ms_pick(Id, w_c), nn = ms_pick(Nn, w_c) + 1;
+#pragma unroll
+            for (int j = 0; j < HP_MS_SETS; ++j) {
+                WAVE_FOR(l) {
+                    const int c = 64 * j + l;
+                    if (c == tc) { Fr[j][l] = from_id; Cf[j][l] = w_c; Sc[j][l] = w_score; Nm[j][l] = w_nm; Mf[j][l] = w_flag; Nn[j][l] = nn; }
+                    if (c == w_c) Son[j][l] = w_flag;
+                }
+            }
+        }
+    }
+    // ---- the end of the line: best end node (:1105-1123) or the forced update of the right anchor (:1125-1134)
+    int max_score, max_NM = 0, max_n = 0, max_c = -1;
+    if (_tail == 0) {
+        max_score = old_score;
+        wv::Lane<long long> key;
+        WAVE_FOR(l) {
+            long long kb = -1;
+#pragma unroll
+            for (int j = 0; j < HP_MS_SETS; ++j) {
+                if (Tk[j][l] && Dpf[j][l] == dp_flag) {
+                    const int sj = A3[j][l];
+                    const int pos = ((right_x - 1 - (sj >> 14)) << 14) | (sj & 16383);
+                    const long long kk = ((long long)(Sc[j][l] + 32768) << 47) | ((long long)(524287 - Nm[j][l]) << 28) | (long long)(POSMAX - pos);
+                    kb = kk > kb ? kk : kb;
+                }
+            }
+            key[l] = kb;
+        }
+        const long long bk = wv::reduce_max64(key);
+        if (bk >= 0) {
+            const int pos = POSMAX - (int)(bk & POSMAX);
+            const int nm = 524287 - (int)((bk >> 28) & 524287), sc = (int)(bk >> 47) - 32768;
+            if (sc > max_score || (sc == max_score && nm < max_NM)) {
+                const int want_sj = ((right_x - 1 - (pos >> 14)) << 14) | (pos & 16383);
+#pragma unroll
+                for (int j = 0; j < HP_MS_SETS; ++j) {
+                    wv::Lane<int> e;
+                    WAVE_FOR(l) e[l] = Tk[j][l] && Dpf[j][l] == dp_flag && A3[j][l] == want_sj;
+                    const unsigned long long bm = wv::ballot(e);
+                    if (bm) max_c = 64 * j + __builtin_ctzll(bm);
+                }
+                max_score = sc; max_NM = nm; max_n = ms_pick(Nn, max_c);
+            }
+        }
+    } else {
+        ScanT S;
+        S.T = Rt; S.T.score = old_score; S.T.NM = old_NM;
+        S.x = right_x; S.t_NM = old_NM; S.tkey = Rt.chr * 2 + (Rt.strand > 0 ? 1 : 0); S.Rw = 0x7fffffffffffll;
+        int w_c, w_flag = 0, w_score = old_score, w_nm = old_NM; bool changed;
+        HP_MS_SCAN(S, head, w_c, w_flag, w_score, w_nm, changed);
+        int r_from = head, r_nn = 1;
+        if (changed) {
+            r_from = ms_pick(Id, w_c); r_nn = ms_pick(Nn, w_c) + 1; max_c = w_c;
+#pragma unroll
+            for (int j = 0; j < HP_MS_SETS; ++j) { WAVE_FOR(l) { if (64 * j + l == w_c) Son[j][l] = w_flag; } }
+            gd[right].match_flag = (uint8_t)w_flag;
+        }
+        g_from[right] = r_from; gd[right].score = w_score; gd[right].NM = w_nm; g_node_n[right] = r_nn;
+        max_score = w_score; max_NM = w_nm; max_n = r_nn - 1;
+    }
+    // ---- walk back to the head (:1136-1147)
+    bool bad = false;
+    {
+        int c = max_c, node_i = max_n - 1;
+        while (c >= 0) {
+            if (node_i < 0) { bad = true; break; }                            // "[frag mini dp] BUG" exit, :1140
+            line[node_i--] = ms_pick(Id, c);
+            c = ms_pick(Cf, c);
+        }
+        if (node_i >= 0) bad = true;
+    }
+    // ---- final state of every hit the pass touched
+#pragma unroll
+    for (int j = 0; j < HP_MS_SETS; ++j) {
+        WAVE_FOR(l) {
+            if (Tk[j][l]) {
+                const int id = Id[j][l];
+                hp_store16((HP_G char *)(gd + id) + 16, B0[j][l], (Dpf[j][l] & 0xff) | (Son[j][l] << 8) | (Mf[j][l] << 16), Sc[j][l], Nm[j][l]);
+                if (Dpf[j][l] == dp_flag) { g_from[id] = Fr[j][l]; g_node_n[id] = Nn[j][l]; }
+            }
+        }
+    }
+    wv::sync();
+#undef HP_MS_Q
+#undef HP_MS_SCAN
+    if (bad) { r.cx.status |= ST_REFEXIT; return 0; }
+    *de_score += max_score - old_score;
+    *de_NM += max_NM - old_NM;
+    return max_n;
+}
+
 // ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150
 // left / right are node indices (left may be -1 = START); right_x is right's slot, which may be the
 // virtual slot seed_out (then right < 0 and _tail == 0).  Returns the number of nodes written to line[].
-HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
 {
     const int head = _head ? left : -1;
     const int left_x = nx(r, left), head_x = nx(r, head);
@@ -849,6 +1089,12 @@ HP_NOINL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *li
     if (r.prof) r.prof[20] += wv::clock() - tm0_;
 #endif
     return max_n;
+}
+
+HP_INL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+{
+    const int n = mini_line_regs(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+    return n >= 0 ? n : mini_line_mem(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
 }
 
 // ---------------------------------------------------------------- lines

@@ -17,6 +17,7 @@ struct hp_v2i { int x, y; };
 struct hp_v4i { int x, y, z, w; };
 HP_INL void hp_load16(const void *p, int *o) { memcpy(o, p, 16); }
 HP_INL void hp_load8(const void *p, int *o) { memcpy(o, p, 8); }
+HP_INL void hp_store16(void *p, int a, int b, int c, int d) { int v[4] = {a, b, c, d}; memcpy(p, v, 16); }
 
 namespace wv {
 
