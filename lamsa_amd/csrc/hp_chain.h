@@ -1093,7 +1093,13 @@ HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t
 
 HP_INL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
 {
+#ifdef HP_PROF
+    const long long t0_ = wv::clock();
+#endif
     const int n = mini_line_regs(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+#ifdef HP_PROF
+    if (r.prof) { r.prof[44] += wv::clock() - t0_; r.prof[45] += 1; if (n < 0) r.prof[47] += 1; }
+#endif
     return n >= 0 ? n : mini_line_mem(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
 }
 

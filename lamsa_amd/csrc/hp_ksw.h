@@ -336,9 +336,16 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     int hw = -1, qw = -1;
     wv::Lane<int> tl;
     WAVE_FOR(l) { tl[l] = 4; }
-    for (int i = 0; i < tlen; ++i) {
-        if ((i & 63) == 0) { WAVE_FOR(l) { const int ii = i + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
-        const int ti = wv::bcast(tl, i & 63);
+    // Rows in blocks of 64: the block's target bases are loaded (and waited for) once per block, so that the row loop
+    // itself never waits on the vector-memory counter -- which would also wait for the direction-matrix stores of the
+    // previous rows whenever that matrix lives in HBM.
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+    { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+    const int ti_first = wv::bcast(tl, 0);                                // consumed here: the wait for the load stays outside the row loop
+    const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+    for (int i = ib; i < ie; ++i) {
+        const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         if (end > hw) {                                                    // columns entering the window
@@ -394,6 +401,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         LE[end & HP_LDS_MASK] = HP_NEG_INF;                                // :632
         if (end > hw) hw = end;
         wv::sync();
+    }
     }
     const int score = tlen > 0 ? wv::uni((int)LH[qlen & HP_LDS_MASK]) : HP_GH0(qlen);
 #undef HP_GH0
@@ -452,9 +460,16 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     WAVE_FOR(l) { tl[l] = 4; }
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
     int beg = 0, end = qlen;
-    for (int i = 0; i < tlen; ++i) {
-        if ((i & 63) == 0) { WAVE_FOR(l) { const int ii = i + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
-        const int ti = wv::bcast(tl, i & 63);
+    // Rows in blocks of 64: the block's target bases are loaded (and waited for) once per block, so that the row loop
+    // itself never waits on the vector-memory counter -- which would also wait for the direction-matrix stores of the
+    // previous rows whenever that matrix lives in HBM.
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+    { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+    const int ti_first = wv::bcast(tl, 0);                                // consumed here: the wait for the load stays outside the row loop
+    const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+    for (int i = ib; i < ie; ++i) {
+        const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
         const int d_beg = i > w ? i - w : 0;
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
@@ -544,11 +559,11 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
         }
         int mrow = 0, mj = -1;
         if (best >= 0) { mrow = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
-        if (mrow == 0) break;                                              // :763
+        if (mrow == 0) { stop_rows = true; break; }                                              // :763
         if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
         else if (zdrop > 0) {                                              // :767-773
-            if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
-            else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+            if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
+            else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
         }
         // shrink the band for the next row, :775-778.  index `end` itself: eh[end].h = h_last, eh[end].e = 0
         {
@@ -560,6 +575,7 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
             beg = nb;
             end = jl + 2 < qlen ? jl + 2 : qlen;
         }
+    }
     }
 #undef HP_EH0
     int i, k;
