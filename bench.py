@@ -67,6 +67,22 @@ def count_mapped_bases(B, streams):
     return tot
 
 
+def measured_traffic(workload, reads):
+    """HBM bytes per launch of k_align_batch from the committed PMC passes (profiles/*_final_pmc.json: FETCH_SIZE doubled
+    per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command).
+    bench.py cannot collect counters itself; None when no profile of this workload and batch size is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_final_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("reads_per_step") == reads and "hbm_bytes_per_dispatch_upper" in d:
+            best = (float(d["hbm_bytes_per_dispatch_upper"]), "profiles/" + os.path.basename(f))
+    return best if best else (None, None)
+
+
 def shard_seed(rank):
     """Every rank simulates its own shard of the read stream (same reference, different reads)."""
     return 1000 + rank
@@ -160,7 +176,8 @@ def main():
         alg_bytes, parts = algorithmic_bytes(B, streams, tbases)
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
+        traffic, traffic_src = measured_traffic(a.workload, a.reads)
+        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_align_batch", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
         # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
