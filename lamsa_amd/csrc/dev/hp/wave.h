@@ -67,12 +67,17 @@ HP_INL unsigned long long ballot(const Lane<int> &p) { return __ballot(p.v != 0)
 template <int CTRL, int ROW_MASK = 0xf>
 HP_INL int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
 
+// v = max(v, v[source lane]) in ONE VALU instruction: v_max_i32 with a DPP source operand.  Lanes whose DPP source is
+// invalid or masked off keep v.  The s_nop covers the "VALU write -> DPP read of the same VGPR" hazard (2 wait states),
+// which the assembler does not insert inside inline asm.
+#define HP_MAX_DPP(v, CTRL) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " CTRL : "+v"(v))
+
 HP_INL int reduce_max(const Lane<int> &x) {
-    int v = x.v, o;
-    o = dpp<0xB1>(v, v); v = o > v ? o : v;
-    o = dpp<0x4E>(v, v); v = o > v ? o : v;
-    o = dpp<0x141>(v, v); v = o > v ? o : v;
-    o = dpp<0x140>(v, v); v = o > v ? o : v;          // every lane of a 16-lane row now holds the row maximum
+    int v = x.v;
+    HP_MAX_DPP(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_mirror row_mask:0xf bank_mask:0xf");          // every lane of a 16-lane row now holds the row maximum
     const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     const int ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
@@ -97,13 +102,13 @@ HP_INL long long reduce_max64(const Lane<long long> &x) {
 }
 // exclusive prefix max over lanes; lane 0 receives `ident` (which must be <= every input)
 HP_INL void scan_max_excl(Lane<int> &x, int ident) {
-    int v = x.v, o;
-    o = dpp<0x111>(ident, v); v = o > v ? o : v;      // Hillis-Steele inside each 16-lane row
-    o = dpp<0x112>(ident, v); v = o > v ? o : v;
-    o = dpp<0x114>(ident, v); v = o > v ? o : v;
-    o = dpp<0x118>(ident, v); v = o > v ? o : v;
-    o = dpp<0x142, 0xA>(ident, v); v = o > v ? o : v; // row 0 -> row 1, row 2 -> row 3
-    o = dpp<0x143, 0xC>(ident, v); v = o > v ? o : v; // rows 0-1 -> rows 2,3
+    int v = x.v;
+    HP_MAX_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf");           // Hillis-Steele inside each 16-lane row
+    HP_MAX_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");        // row 0 -> row 1, row 2 -> row 3
+    HP_MAX_DPP(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");        // rows 0-1 -> rows 2,3
     x.v = dpp<0x138>(ident, v);                        // shift the inclusive scan right by one lane
 }
 

@@ -783,20 +783,25 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
 // previous state: they can neither be candidates nor targets of this pass (see reach_run), and every later pass
 // re-initialises the hits it uses (fnode_set) before reading them.
 // Returns -1 when the hits do not fit; the caller then runs the pass through memory (mini_line).
-#define HP_MS_SETS 4
-HP_INL int ms_pick(const wv::Lane<int> *f, int c) {
+#define HP_MS_MAX_SETS 4
+template <int NS> HP_INL int ms_pick(const wv::Lane<int> *f, int c) {
     const int l = c & 63, j = c >> 6;
-    const int v0 = wv::bcast(f[0], l), v1 = wv::bcast(f[1], l), v2 = wv::bcast(f[2], l), v3 = wv::bcast(f[3], l);
-    return j == 0 ? v0 : (j == 1 ? v1 : (j == 2 ? v2 : v3));
+    int v = wv::bcast(f[0], l);
+#pragma unroll
+    for (int q = 1; q < NS; ++q) { const int u = wv::bcast(f[q], l); v = j == q ? u : v; }
+    return v;
 }
-HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+// ids: by_run ? srt[rlo + idx] : k_lo + idx, idx < n_ids <= 64 * NS
+template <int NS>
+HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail,
+                            int n_ids, int by_run_, int rlo)
 {
     left = wv::uni(left); right = wv::uni(right); right_x = wv::uni(right_x); _head = wv::uni(_head); _tail = wv::uni(_tail);
     const int head = _head ? left : -1;
     const int left_x = nx(r, left);
     const int dp_flag = MULTI_FLAG;
     const int start_slot = left_x + 1;
-    const int k_lo = wv::uni(hoff(r, start_slot)), k_hi = wv::uni(hoff(r, right_x)), k_t0 = wv::uni(hoff(r, left_x + 2));
+    const int k_lo = wv::uni(hoff(r, start_slot)), k_t0 = wv::uni(hoff(r, left_x + 2));
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
@@ -804,23 +809,8 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
     const EdgeK K = edge_consts(r.cx.P);
     const int POSMAX = (1 << 28) - 1;
-    // ---- which hits
-    int n_ids, rlo = 0;
-    bool by_run = false;
-    if (k_hi - k_lo <= 64 * HP_MS_SETS) n_ids = k_hi - k_lo;
-    else if (head < 0 && _tail != 0 && right >= 0) {
-        const lamsa_hp_para *P = r.cx.P;
-        const int did_max = r.seed_id[right_x] - r.seed_id[left_x + 1];
-        const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
-        long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
-        if (mdm + 1 > Rw) Rw = mdm + 1;
-        Rw += 128 + (long long)did_max * P->seed_step;
-        int rhi;
-        reach_run(r, right, Rw, &rlo, &rhi);
-        rlo = wv::uni(rlo); rhi = wv::uni(rhi);
-        if (rhi - rlo + 1 > 64 * HP_MS_SETS) return -1;
-        by_run = true; n_ids = rhi - rlo + 1;
-    } else return -1;
+    n_ids = wv::uni(n_ids); rlo = wv::uni(rlo);
+    const bool by_run = wv::uni(by_run_) != 0;
     // ---- anchors
     NodeS Fh; Fh.pos = 0; Fh.chr = 0; Fh.slot_j = 0; Fh.sid = 0; Fh.strand = 0; Fh.len_dif8 = 0; Fh.pad_ = 0; Fh.dp_flag = 0; Fh.son_flag = 0; Fh.match_flag = 0; Fh.score = 0; Fh.NM = 0;
     NodeS Rt = Fh;
@@ -832,10 +822,10 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
     else { old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm; }
     // ---- gather + frag_dp_per_init (:766-784, :1086-1091)
-    wv::Lane<int> A0[HP_MS_SETS], A1[HP_MS_SETS], A2[HP_MS_SETS], A3[HP_MS_SETS], B0[HP_MS_SETS];
-    wv::Lane<int> Dpf[HP_MS_SETS], Son[HP_MS_SETS], Mf[HP_MS_SETS], Sc[HP_MS_SETS], Nm[HP_MS_SETS], Fr[HP_MS_SETS], Nn[HP_MS_SETS], Cf[HP_MS_SETS], Id[HP_MS_SETS], Tk[HP_MS_SETS];
+    wv::Lane<int> A0[NS], A1[NS], A2[NS], A3[NS], B0[NS];
+    wv::Lane<int> Dpf[NS], Son[NS], Mf[NS], Sc[NS], Nm[NS], Fr[NS], Nn[NS], Cf[NS], Id[NS], Tk[NS];
 #pragma unroll
-    for (int j = 0; j < HP_MS_SETS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         WAVE_FOR(l) {
             const int idx = 64 * j + l;
             const bool valid = idx < n_ids;
@@ -867,7 +857,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
 #define HP_MS_SCAN(S, t_from_id, w_c, w_flag, w_score, w_nm, changed_) do { \
         wv::Lane<long long> key; wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl; \
         WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; } \
-        _Pragma("unroll") for (int j = 0; j < HP_MS_SETS; ++j) { \
+        _Pragma("unroll") for (int j = 0; j < NS; ++j) { \
             WAVE_FOR(l) { NodeS Q; HP_MS_Q(j, l, Q); int ow_, oka_ = 0; \
                 scan_eval(K, S, Q, 64 * j + l, Tk[j][l] & (Dpf[j][l] == dp_flag), start_slot, dp_flag, key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow_, oka_); \
                 okl[l] |= oka_; } } \
@@ -878,7 +868,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
                 wv::Lane<int> w_; WAVE_FOR(l) w_[l] = negp[l] == npos; \
                 const int wl = __builtin_ctzll(wv::ballot(w_)); \
                 w_c = wv::bcast(n_p, wl); w_flag = wv::bcast(n_f, wl); w_score = wv::bcast(n_c, wl); w_nm = wv::bcast(n_n, wl); \
-                changed_ = ms_pick(Id, w_c) != (t_from_id); \
+                changed_ = ms_pick<NS>(Id, w_c) != (t_from_id); \
             } else { \
                 const long long best_key = wv::reduce_max64(key); \
                 if (best_key >= 0) { \
@@ -887,7 +877,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
                         wv::Lane<int> w_; WAVE_FOR(l) w_[l] = key[l] == best_key; \
                         const int wl = __builtin_ctzll(wv::ballot(w_)); \
                         w_c = wv::bcast(bp, wl); w_flag = wv::bcast(bf, wl); w_score = cand_; w_nm = nm_; \
-                        changed_ = ms_pick(Id, w_c) != (t_from_id); \
+                        changed_ = ms_pick<NS>(Id, w_c) != (t_from_id); \
                     } } } } } while (0)
     // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
     for (int k_next = k_t0;;) {
@@ -895,7 +885,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         WAVE_FOR(l) {
             int v = 0x7fffffff;
 #pragma unroll
-            for (int j = 0; j < HP_MS_SETS; ++j) { const int id = Id[j][l]; if (Tk[j][l] && Dpf[j][l] == dp_flag && id >= k_next && id < v) v = id; }
+            for (int j = 0; j < NS; ++j) { const int id = Id[j][l]; if (Tk[j][l] && Dpf[j][l] == dp_flag && id >= k_next && id < v) v = id; }
             m[l] = 0 - v;
         }
         const int kmin = 0 - wv::reduce_max(m);
@@ -903,7 +893,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         k_next = kmin + 1;
         int tc = 0;
 #pragma unroll
-        for (int j = 0; j < HP_MS_SETS; ++j) {
+        for (int j = 0; j < NS; ++j) {
             wv::Lane<int> e;
             WAVE_FOR(l) e[l] = Tk[j][l] && Id[j][l] == kmin;
             const unsigned long long bm = wv::ballot(e);
@@ -911,18 +901,18 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         }
         ScanT S;
         {
-            int a[4] = { ms_pick(A0, tc), ms_pick(A1, tc), ms_pick(A2, tc), ms_pick(A3, tc) };
-            int b[4] = { ms_pick(B0, tc), 0, ms_pick(Sc, tc), ms_pick(Nm, tc) };
+            int a[4] = { ms_pick<NS>(A0, tc), ms_pick<NS>(A1, tc), ms_pick<NS>(A2, tc), ms_pick<NS>(A3, tc) };
+            int b[4] = { ms_pick<NS>(B0, tc), 0, ms_pick<NS>(Sc, tc), ms_pick<NS>(Nm, tc) };
             S.T = node_unpack(a, b);
         }
         S.x = S.T.slot_j >> 14; S.t_NM = S.T.NM; S.tkey = S.T.chr * 2 + (S.T.strand > 0 ? 1 : 0); S.Rw = 0x7fffffffffffll;
-        const int t_from = ms_pick(Fr, tc);
+        const int t_from = ms_pick<NS>(Fr, tc);
         int w_c, w_flag = 0, w_score = S.T.score, w_nm = S.t_NM; bool changed;
         HP_MS_SCAN(S, t_from, w_c, w_flag, w_score, w_nm, changed);
         if (changed) {
-            const int from_id = ms_pick(Id, w_c), nn = ms_pick(Nn, w_c) + 1;
+            const int from_id = ms_pick<NS>(Id, w_c), nn = ms_pick<NS>(Nn, w_c) + 1;
 #pragma unroll
-            for (int j = 0; j < HP_MS_SETS; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 WAVE_FOR(l) {
                     const int c = 64 * j + l;
                     if (c == tc) { Fr[j][l] = from_id; Cf[j][l] = w_c; Sc[j][l] = w_score; Nm[j][l] = w_nm; Mf[j][l] = w_flag; Nn[j][l] = nn; }
@@ -939,7 +929,7 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         WAVE_FOR(l) {
             long long kb = -1;
 #pragma unroll
-            for (int j = 0; j < HP_MS_SETS; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 if (Tk[j][l] && Dpf[j][l] == dp_flag) {
                     const int sj = A3[j][l];
                     const int pos = ((right_x - 1 - (sj >> 14)) << 14) | (sj & 16383);
@@ -956,13 +946,13 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
             if (sc > max_score || (sc == max_score && nm < max_NM)) {
                 const int want_sj = ((right_x - 1 - (pos >> 14)) << 14) | (pos & 16383);
 #pragma unroll
-                for (int j = 0; j < HP_MS_SETS; ++j) {
+                for (int j = 0; j < NS; ++j) {
                     wv::Lane<int> e;
                     WAVE_FOR(l) e[l] = Tk[j][l] && Dpf[j][l] == dp_flag && A3[j][l] == want_sj;
                     const unsigned long long bm = wv::ballot(e);
                     if (bm) max_c = 64 * j + __builtin_ctzll(bm);
                 }
-                max_score = sc; max_NM = nm; max_n = ms_pick(Nn, max_c);
+                max_score = sc; max_NM = nm; max_n = ms_pick<NS>(Nn, max_c);
             }
         }
     } else {
@@ -973,9 +963,9 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         HP_MS_SCAN(S, head, w_c, w_flag, w_score, w_nm, changed);
         int r_from = head, r_nn = 1;
         if (changed) {
-            r_from = ms_pick(Id, w_c); r_nn = ms_pick(Nn, w_c) + 1; max_c = w_c;
+            r_from = ms_pick<NS>(Id, w_c); r_nn = ms_pick<NS>(Nn, w_c) + 1; max_c = w_c;
 #pragma unroll
-            for (int j = 0; j < HP_MS_SETS; ++j) { WAVE_FOR(l) { if (64 * j + l == w_c) Son[j][l] = w_flag; } }
+            for (int j = 0; j < NS; ++j) { WAVE_FOR(l) { if (64 * j + l == w_c) Son[j][l] = w_flag; } }
             gd[right].match_flag = (uint8_t)w_flag;
         }
         g_from[right] = r_from; gd[right].score = w_score; gd[right].NM = w_nm; g_node_n[right] = r_nn;
@@ -987,14 +977,14 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
         int c = max_c, node_i = max_n - 1;
         while (c >= 0) {
             if (node_i < 0) { bad = true; break; }                            // "[frag mini dp] BUG" exit, :1140
-            line[node_i--] = ms_pick(Id, c);
-            c = ms_pick(Cf, c);
+            line[node_i--] = ms_pick<NS>(Id, c);
+            c = ms_pick<NS>(Cf, c);
         }
         if (node_i >= 0) bad = true;
     }
     // ---- final state of every hit the pass touched
 #pragma unroll
-    for (int j = 0; j < HP_MS_SETS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         WAVE_FOR(l) {
             if (Tk[j][l]) {
                 const int id = Id[j][l];
@@ -1010,6 +1000,29 @@ HP_NOINL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_
     *de_score += max_score - old_score;
     *de_NM += max_NM - old_NM;
     return max_n;
+}
+
+HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+{
+    const int head = _head ? left : -1;
+    const int left_x = nx(r, left);
+    const int k_lo = hoff(r, left_x + 1), k_hi = hoff(r, right_x);
+    int n_ids, rlo = 0, by_run = 0;
+    if (k_hi - k_lo <= 64 * HP_MS_MAX_SETS) n_ids = k_hi - k_lo;
+    else if (head < 0 && _tail != 0 && right >= 0) {
+        const lamsa_hp_para *P = r.cx.P;
+        const int did_max = r.seed_id[right_x] - r.seed_id[left_x + 1];
+        const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
+        long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
+        if (mdm + 1 > Rw) Rw = mdm + 1;
+        Rw += 128 + (long long)did_max * P->seed_step;
+        int rhi;
+        reach_run(r, right, Rw, &rlo, &rhi);
+        if (rhi - rlo + 1 > 64 * HP_MS_MAX_SETS) return -1;
+        by_run = 1; n_ids = rhi - rlo + 1;
+    } else return -1;
+    if (n_ids <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, by_run, rlo);
+    return mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, by_run, rlo);
 }
 
 // ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150

@@ -510,11 +510,10 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
             }
             wv::scan_max_excl(key, HP_SCAN_IDENT);
             wv::sync();
-            wv::Lane<int> fnext, hnz, enz;
-            wv::Lane<long long> rk;
+            wv::Lane<int> fnext, hnz, enz, hh;
             WAVE_FOR(l) {
                 const int j = j0 + l;
-                fnext[l] = 0; hnz[l] = 0; enz[l] = 0; rk[l] = -1;
+                fnext[l] = 0; hnz[l] = 0; enz[l] = 0; hh[l] = -1;
                 if (j < end) {
                     int f = Fin - l * e_ins;
                     if (l > 0) { const int g = key[l] - (j - 1) * e_ins; f = g > f ? g : f; }
@@ -529,14 +528,19 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
                     LH[(j + 1) & HP_LDS_MASK] = h;
                     if (zl) LZ[i * n_col + (j - d_beg)] = (uint8_t)dir; else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
                     fnext[l] = f; hnz[l] = h != 0; enz[l] = ee != 0;
-                    rk[l] = ((long long)h << 32) | (unsigned)j;
+                    hh[l] = h;                                               // scores of this routine are never negative
                 }
             }
             Fin = wv::bcast(fnext, 63);
             carryH = carry_next;
             {
-                const long long b = wv::reduce_max64(rk);
-                if (b > best) best = b;
+                const int hmax = wv::reduce_max(hh);                         // tile maximum; the last lane holding it is the last j
+                if (hmax >= 0) {
+                    wv::Lane<int> eq;
+                    WAVE_FOR(l) eq[l] = hh[l] == hmax;
+                    const long long b = ((long long)hmax << 32) | (unsigned)(j0 + 63 - __builtin_clzll(wv::ballot(eq)));
+                    if (b > best) best = b;
+                }
                 const int cnt = end - j0 < 64 ? end - j0 : 64;            // active lanes
                 const unsigned long long bh = wv::ballot(hnz), be = wv::ballot(enz);
                 // nz for index j0+l: E bit l | H bit (l-1); index j0+cnt (== end on the last chunk) gets H bit cnt-1
