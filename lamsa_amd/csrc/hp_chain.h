@@ -173,6 +173,9 @@ HP_INL int edge_flag_packed(const EdgeK &k, const NodeS &pre, const NodeS &cur)
 HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, int which, int rlo = 0, int rhi = 0x7fffffff)
 {
 #ifdef HP_PROF
+    if (r.prof) { r.prof[54] += k1 - k0; r.prof[55] += 1; }
+#endif
+#ifdef HP_PROF
     const long long t0_ = wv::clock();
 #endif
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;

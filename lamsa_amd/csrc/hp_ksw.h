@@ -445,6 +445,9 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
     int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
     if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return 0; }
+#ifdef HP_PROF
+    if (!zl && cx.prof) { cx.prof[52] += (long long)n_col * tlen; cx.prof[53] += 1; }
+#endif
     HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
     HP_L uint8_t *LQ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS), *LZ = LQ + HP_LDS_CELLS;
     HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
@@ -480,7 +483,10 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
         }
         while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
         if (zl) {                                                          // window cells the band does not reach: never written
-            for (int c0 = 0; c0 < n_col; c0 += 64) { WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) LZ[i * n_col + c] = 255; } }
+            if (beg > d_beg || end < d_beg + n_col) {
+#pragma nounroll
+                for (int c0 = 0; c0 < n_col; c0 += 64) { WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) LZ[i * n_col + c] = 255; } }
+            }
         } else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
         wv::sync();
         int h1_init;
@@ -590,9 +596,6 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
-#ifdef HP_PROF
-    { const int bk_ = qlen == 0 ? 0 : (qlen <= 16 ? 1 : (qlen <= 32 ? 2 : (qlen <= 64 ? 3 : (qlen <= 128 ? 4 : (qlen <= 256 ? 5 : (qlen <= 512 ? 6 : 7)))))); HP_TADD(cx, 48 + 2 * bk_, te0_); }
-#endif
     return max;
 }
 
