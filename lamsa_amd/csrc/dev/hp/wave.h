@@ -112,4 +112,16 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     x.v = dpp<0x138>(ident, v);                        // shift the inclusive scan right by one lane
 }
 
+// exclusive prefix sum over lanes (lane 0 receives 0)
+HP_INL void scan_add_excl(Lane<int> &x) {
+    int v = x.v;
+    v += dpp<0x111>(0, v);                             // Hillis-Steele inside each 16-lane row
+    v += dpp<0x112>(0, v);
+    v += dpp<0x114>(0, v);
+    v += dpp<0x118>(0, v);
+    v += dpp<0x142, 0xA>(0, v);                        // row 0 -> row 1, row 2 -> row 3
+    v += dpp<0x143, 0xC>(0, v);                        // rows 0-1 -> rows 2,3
+    x.v = dpp<0x138>(0, v);                            // shift the inclusive scan right by one lane
+}
+
 }  // namespace wv

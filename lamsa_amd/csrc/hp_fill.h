@@ -452,6 +452,31 @@ HP_NOINL bool res_split(ReadCtx &r, LineRes &la, cig_t *buf, int buf_cap)
     const HP_G cig_t *src = (const HP_G cig_t *)la.rec[0].cig.c;
     if (la.rec[0].cig.c == buf) { cx.status |= ST_REFEXIT; return false; }           // in and out must be different buffers
     HP_G cig_t *oc = (HP_G cig_t *)buf;
+    {   // Most lines have no cut point and a CIGAR that _push_cigar1 would copy unchanged (no empty element, no two
+        // neighbours of the same kind, only M/I/D/S): checked by the lanes, then copied by the lanes.
+        bool plain = n <= buf_cap;
+        for (int j0 = 0; j0 < n && plain; j0 += 64) {
+            wv::Lane<int> bad;
+            WAVE_FOR(l) {
+                const int j = j0 + l;
+                int b = 0;
+                if (j < n) {
+                    const int w = src[j], op = w & 0xf, len = w >> 4;
+                    const int nxt = j + 1 < n ? (int)src[j + 1] : -1;
+                    b = len == 0 || (op != C_M && op != C_I && op != C_D && op != C_S) || ((op == C_I || op == C_D) && len >= split_len) ||
+                        (nxt >= 0 && (nxt & 0xf) == op) || (op == C_S && j > 0 && j < n - 1 && nxt >= 0 && (nxt & 0xf) == C_H);
+                }
+                bad[l] = b;
+            }
+            if (wv::ballot(bad) != 0) plain = false;
+        }
+        if (plain) {
+            for (int j0 = 0; j0 < n; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j < n) oc[j] = src[j]; } }
+            cig_bind(la.rec[0].cig, buf, buf_cap); la.rec[0].cig.n = n;
+            wv::sync();
+            return !(cx.status & ST_OVERFLOW);
+        }
+    }
     int res_n = 0, used = 0;                  // current record, words of `buf` taken by finished records
     int wn = 0, pend = 0; bool have = false;  // words stored for the current record, run being built
     int rd_tot = 0, ref_rec = 0;              // read bases consumed by all elements so far; reference bases of the current record
@@ -522,21 +547,47 @@ HP_NOINL bool res_aux(ReadCtx &r, LineRes &la)
         if (!ref || !ref_fetch(r, rec.chr, rec.offset - 1, &ref_len, ref)) { arena_release(cx.tmp, mark); return false; }
         int ref_i = 0, read_i = 0, n_mm = 0, n_m = 0, n_io = 0, n_ie = 0, n_do = 0, n_de = 0;
         bool bad = false;
-        for (int i = 0; i < rec.cig.n && !bad; ++i) {
-            const int op = rec.cig.c[i] & 0xf, len = rec.cig.c[i] >> 4;
-            if (op == C_M) {
-                if (read_i + len > r.L || ref_i + len > ref_len) { bad = true; break; }     // lengths cannot match any more: exit(1) at :834
-                int mm = 0;
-                for (int b = 0; b < len; b += 64) {
-                    wv::Lane<int> d;
-                    WAVE_FOR(l) { const int j = b + l; d[l] = (j < len && r.cur_read[read_i + j] != ref[ref_i + j]) ? 1 : 0; }
-                    mm += wv::reduce_sum(d);
+        // 64 CIGAR elements at a time, one per lane: where each starts on the read and on the reference is a prefix sum
+        // over the lanes; every lane then counts the mismatches of its own M run (:806-834).  Any inconsistency makes
+        // the reference exit (:834), in whatever order it is found.
+        const HP_G cig_t *gc = (const HP_G cig_t *)rec.cig.c;
+        const HP_G uint8_t *gread = (const HP_G uint8_t *)r.cur_read, *gref = (const HP_G uint8_t *)ref;
+        const int cn = rec.cig.n;
+        for (int c0 = 0; c0 < cn && !bad; c0 += 64) {
+            wv::Lane<int> rinc, finc, opl, lenl, isbad;
+            WAVE_FOR(l) {
+                const int i = c0 + l;
+                int op = -1, len = 0;
+                if (i < cn) { const cig_t w = gc[i]; op = w & 0xf; len = w >> 4; }
+                opl[l] = op; lenl[l] = len;
+                rinc[l] = (op == C_M || op == C_I || op == C_S) ? len : 0;
+                finc[l] = (op == C_M || op == C_D) ? len : 0;
+                isbad[l] = i < cn && op != C_M && op != C_I && op != C_D && op != C_S;
+            }
+            const int r_tot = wv::reduce_sum(rinc), f_tot = wv::reduce_sum(finc);
+            wv::Lane<int> rs = rinc, fs = finc;
+            wv::scan_add_excl(rs); wv::scan_add_excl(fs);
+            wv::Lane<int> mlen, mm, il, dl, io, dq;
+            WAVE_FOR(l) {
+                const int op = opl[l], len = lenl[l];
+                int ml = 0;
+                if (op == C_M) {
+                    if (len < 0 || read_i + rs[l] + len > r.L || ref_i + fs[l] + len > ref_len) isbad[l] = 1;     // lengths cannot match any more: exit(1) at :834
+                    else ml = len;
                 }
-                read_i += len; ref_i += len; n_m += len - mm; n_mm += mm;
-            } else if (op == C_I) { read_i += len; n_ie += len; ++n_io; }
-            else if (op == C_D) { ref_i += len; n_de += len; ++n_do; }
-            else if (op == C_S) read_i += len;
-            else bad = true;
+                mlen[l] = ml; mm[l] = 0;
+                il[l] = op == C_I ? len : 0; dl[l] = op == C_D ? len : 0; io[l] = op == C_I; dq[l] = op == C_D;
+            }
+            if (wv::ballot(isbad) != 0) { bad = true; break; }
+            const int maxlen = wv::reduce_max(mlen);
+            for (int b0 = 0; b0 < maxlen; ++b0) {
+                WAVE_FOR(l) { if (b0 < mlen[l]) mm[l] += gread[read_i + rs[l] + b0] != gref[ref_i + fs[l] + b0]; }
+            }
+            const int mms = wv::reduce_sum(mm);
+            n_mm += mms; n_m += wv::reduce_sum(mlen) - mms;
+            n_ie += wv::reduce_sum(il); n_de += wv::reduce_sum(dl);
+            n_io += __builtin_popcountll(wv::ballot(io)); n_do += __builtin_popcountll(wv::ballot(dq));
+            read_i += r_tot; ref_i += f_tot;
         }
         arena_release(cx.tmp, mark);
         if (bad || read_i != r.L || ref_i != ref_len) { cx.status |= ST_REFEXIT; return false; }

@@ -55,6 +55,11 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     }
 }
 
+HP_INL void scan_add_excl(Lane<int> &x) {
+    int run = 0;
+    for (int l = 0; l < 64; ++l) { const int cur = x.v[l]; x.v[l] = run; run += cur; }
+}
+
 }  // namespace wv
 
 // single-threaded stand-ins for the two device atomics the kernels use
