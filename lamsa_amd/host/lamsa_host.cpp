@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <zlib.h>
 
 namespace lamsa {
@@ -174,29 +175,83 @@ static const uint8_t *nt4_table()
     return t;
 }
 
-// one read + its seed_all GEM map lines -> batch (lamsa_read_seq, src/lamsa_aln.c:927-956; split_seed :252-253,281)
-bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err)
+// one read + its seed_all GEM map lines -> batch (lamsa_read_seq, src/lamsa_aln.c:927-956; split_seed :252-253,281).
+// `lines`: the read's seed_all map lines, NUL-separated.
+static void append_read_lines(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, const char *lines, int seed_all)
 {
     const int L = (int)rd.seq.size();
     const uint8_t *t4 = nt4_table();
     for (char c : rd.seq) B.read_seq.push_back(t4[(unsigned char)c]);
     B.read_off.push_back((int64_t)B.read_seq.size());
-    const int seed_all = L < P.seed_len ? 0 : 1 + (L - P.seed_len) / P.seed_step;
     B.seed_all.push_back(seed_all); B.last_len.push_back(L - P.seed_len - (seed_all - 1) * P.seed_step);
-    static thread_local std::vector<char> line(65536);
-    for (int sd = 0; sd < seed_all; ++sd) {
-        if (!fgets(line.data(), (int)line.size(), mapf)) { err = "seeds' GEM map result does not match the reads"; return false; }
-        size_t ll = strlen(line.data()); if (ll && line[ll - 1] == '\n') line[ll - 1] = 0;
+    const char *line = lines;
+    for (int sd = 0; sd < seed_all; ++sd, line += strlen(line) + 1) {
         int ct = 0; size_t k;
         for (k = 0; line[k]; ++k) if (line[k] == '\t') { if (ct == 3) break; ct++; }
         if (!line[k] || line[k + 1] == '-') continue;                   // no map line content: the seed gets no slot
         B.seed_id.push_back(sd + 1);
-        parse_gem_hits(B, ix, line.data() + k + 1, P.per_aln_m);
+        parse_gem_hits(B, ix, line + k + 1, P.per_aln_m);
         B.hit_off.push_back((int64_t)B.h_pos.size());
     }
     B.seed_off.push_back((int64_t)B.seed_id.size());
+}
+
+static int seeds_of(const lamsa_hp_para &P, int L) { return L < P.seed_len ? 0 : 1 + (L - P.seed_len) / P.seed_step; }
+
+// the read's map lines from the file into `raw` (NUL-separated)
+static bool read_map_lines(FILE *mapf, int seed_all, std::string &raw, std::string &err)
+{
+    static thread_local std::vector<char> line(65536);
+    raw.clear();
+    for (int sd = 0; sd < seed_all; ++sd) {
+        if (!fgets(line.data(), (int)line.size(), mapf)) { err = "seeds' GEM map result does not match the reads"; return false; }
+        size_t ll = strlen(line.data()); if (ll && line[ll - 1] == '\n') line[--ll] = 0;
+        raw.append(line.data(), ll + 1);
+    }
+    return true;
+}
+
+bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err)
+{
+    const int seed_all = seeds_of(P, (int)rd.seq.size());
+    std::string raw;
+    if (!read_map_lines(mapf, seed_all, raw, err)) return false;
+    append_read_lines(B, ix, P, rd, raw.c_str(), seed_all);
     B.reads.push_back(rd);
     return true;
+}
+
+// concatenate per-thread partial batches (offsets become absolute)
+static void merge_batches(Batch &B, std::vector<Batch> &parts)
+{
+    for (Batch &p : parts) {
+        const int64_t b0 = (int64_t)B.read_seq.size(), s0 = (int64_t)B.seed_id.size(), h0 = (int64_t)B.h_pos.size(), c0 = (int64_t)B.cig.size();
+        for (size_t i = 1; i < p.read_off.size(); ++i) B.read_off.push_back(p.read_off[i] + b0);
+        for (size_t i = 1; i < p.seed_off.size(); ++i) B.seed_off.push_back(p.seed_off[i] + s0);
+        for (size_t i = 1; i < p.hit_off.size(); ++i) B.hit_off.push_back(p.hit_off[i] + h0);
+        B.read_seq.insert(B.read_seq.end(), p.read_seq.begin(), p.read_seq.end());
+        B.seed_all.insert(B.seed_all.end(), p.seed_all.begin(), p.seed_all.end());
+        B.last_len.insert(B.last_len.end(), p.last_len.begin(), p.last_len.end());
+        B.seed_id.insert(B.seed_id.end(), p.seed_id.begin(), p.seed_id.end());
+        B.h_pos.insert(B.h_pos.end(), p.h_pos.begin(), p.h_pos.end());
+        B.h_chr.insert(B.h_chr.end(), p.h_chr.begin(), p.h_chr.end());
+        B.h_strand.insert(B.h_strand.end(), p.h_strand.begin(), p.h_strand.end());
+        B.h_nm.insert(B.h_nm.end(), p.h_nm.begin(), p.h_nm.end());
+        B.h_len_dif.insert(B.h_len_dif.end(), p.h_len_dif.begin(), p.h_len_dif.end());
+        B.h_cig_n.insert(B.h_cig_n.end(), p.h_cig_n.begin(), p.h_cig_n.end());
+        for (int32_t o : p.h_cig_off) B.h_cig_off.push_back((int32_t)(o + c0));
+        B.cig.insert(B.cig.end(), p.cig.begin(), p.cig.end());
+        p.clear();
+    }
+}
+
+template <class F> static void parallel_blocks(int n, int threads, F fn)
+{
+    if (threads < 2 || n < 2 * threads) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    const int per = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) { const int a = t * per, b = std::min(n, a + per); if (a < b) th.emplace_back([=]() { fn(t, a, b); }); }
+    for (auto &x : th) x.join();
 }
 
 // ------------------------------------------------------------------ result stream -> records
@@ -388,15 +443,30 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     Batch B; B.clear();
     Read rd; bool eof = false; int ret = 0;
     long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
+    const int threads = opt.n_thread > 0 ? opt.n_thread : 1;
+    std::vector<std::string> raw;                       // the chunk's GEM map lines, per read
     while (!eof && ret == 0) {
-        B.clear();
+        // ---- sequential part: the chunk's reads and their map lines as text
+        B.clear(); raw.clear();
         int64_t chunk_bases = 0;
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
             if (!fx.next(rd)) { eof = true; break; }
-            if (!append_read(B, ix, P, rd, mapf, err)) { fprintf(stderr, "[lamsa_read_seq] %s\n", err.c_str()); ret = 1; break; }
+            raw.emplace_back();
+            if (!read_map_lines(mapf, seeds_of(P, (int)rd.seq.size()), raw.back(), err)) { fprintf(stderr, "[lamsa_read_seq] %s\n", err.c_str()); ret = 1; break; }
+            B.reads.push_back(rd);
             chunk_bases += (int64_t)rd.seq.size();
         }
         if (ret || B.reads.empty()) break;
+        const int n = (int)B.reads.size();
+        // ---- text -> hit records, on all host threads (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
+        {
+            std::vector<Batch> parts((size_t)threads);
+            for (Batch &p : parts) p.clear();
+            parallel_blocks(n, threads, [&](int t, int r0, int r1) {
+                for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], raw[(size_t)r].c_str(), seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
+            });
+            merge_batches(B, parts);
+        }
         for (int32_t c : B.h_chr) if (c < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); ret = 1; break; }
         if (ret) break;
         lamsa_hp_batch hb;
@@ -412,17 +482,22 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         rc = lamsa_hp_align_batch(h, &hb, &res);
         if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_align_batch failed: %d %s\n", rc, lamsa_hp_last_error(h)); ret = 2; break; }
         kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
-        sam.clear();
-        ReadResult R;
-        for (size_t r = 0; r < B.reads.size(); ++r) {
-            const int L = (int)B.reads[r].seq.size();
-            parse_stream(res.stream + res.read_off[r], res.read_len[r], L, R);
-            if (R.status != 0) { ++n_bad; fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow"); }
-            rank_results(R, L, P);
-            write_sam(sam, R, B.reads[r], ix, opt);
-            n_bases += L;
-        }
-        fwrite(sam.data(), 1, sam.size(), out);
+        // ---- records -> MAPQ / XA -> SAM text, on all host threads; written in input order
+        std::vector<std::string> sams((size_t)threads);
+        std::vector<long> bad_of((size_t)threads, 0);
+        parallel_blocks(n, threads, [&](int t, int r0, int r1) {
+            ReadResult R;
+            std::string &o = sams[(size_t)t];
+            for (int r = r0; r < r1; ++r) {
+                const int L = (int)B.reads[(size_t)r].seq.size();
+                parse_stream(res.stream + res.read_off[r], res.read_len[r], L, R);
+                if (R.status != 0) { ++bad_of[(size_t)t]; fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[(size_t)r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow"); }
+                rank_results(R, L, P);
+                write_sam(o, R, B.reads[(size_t)r], ix, opt);
+            }
+        });
+        for (int t = 0; t < threads; ++t) { fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
+        for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
     }
     lamsa_hp_destroy(h);

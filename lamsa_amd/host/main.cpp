@@ -10,6 +10,7 @@
 #include <cstring>
 #include <getopt.h>
 #include <string>
+#include <thread>
 #include "lamsa_host.h"
 
 static int usage()
@@ -29,6 +30,7 @@ int main(int argc, char *argv[])
     for (int i = 1; i < argc; ++i) { pg += " "; pg += argv[i]; }
     lamsa_hp_para P; lamsa_hp_para_init(&P);
     lamsa::Options opt;
+    { unsigned hw = std::thread::hardware_concurrency(); opt.n_thread = hw ? (int)(hw > 32 ? 32 : hw) : 1; }   // -t: host threads for parsing and SAM text (the reference defaults to 1)
     FILE *out = stdout; char *p; int c;
     static const struct option lopt[] = {
         {"thread",1,0,'t'},{"seed-len",1,0,'l'},{"seed-inv",1,0,'i'},{"max-loci",1,0,'p'},{"SV-len",1,0,'V'},{"ovlp-rat",1,0,'v'},
