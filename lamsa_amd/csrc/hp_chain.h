@@ -516,59 +516,71 @@ HP_NOINL void min_extend_all(ReadCtx &r, int min_n)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
-    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
-    const int64_t hb = r.hb;
     const EdgeK K = edge_consts(r.cx.P);
     const int H = r.H;
+    // Which seeds have at most min_n hits is read off the pass flag the caller has just assigned (MIN / MULTI, :1315-1334);
+    // the hits that join are collected in `mark` and flagged at the end, so that the flags stay what they were while the
+    // pairs are evaluated.  A hit's index within its seed (slot_j) gives the seed's first hit without a table lookup.
+    const size_t mark_ = arena_mark(r.cx.tmp);
+    uint8_t *mk = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
+    if (!mk) return;
+    HP_G uint8_t *gmk = (HP_G uint8_t *)mk;
+    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { if (b0 + l < H) gmk[b0 + l] = 0; } }
+    wv::sync();
     for (int mbase = 0; mbase < H; mbase += 64) {
         // the MIN hits of this chunk, one per lane
-        wv::Lane<int> Ma0, Ma1, Ma2, Ma3, Mb0, Mb1, Mb2, Mb3, ism;
+        wv::Lane<int> Ma0, Ma1, Ma2, Ma3, Mb0, ism;
         WAVE_FOR(l) {
             const int k = mbase + l, kk = k < H ? k : H - 1;
             int a[4], b[4];
             hp_load16(ns + kk, a); hp_load16((const HP_G char *)(ns + kk) + 16, b);
-            Ma0[l] = a[0]; Ma1[l] = a[1]; Ma2[l] = a[2]; Ma3[l] = a[3]; Mb0[l] = b[0]; Mb1[l] = b[1]; Mb2[l] = b[2]; Mb3[l] = b[3];
-            const int s = a[3] >> 14;
-            ism[l] = k < H && (int)(g_hoff[s + 1] - g_hoff[s]) <= min_n;
+            Ma0[l] = a[0]; Ma1[l] = a[1]; Ma2[l] = a[2]; Ma3[l] = a[3]; Mb0[l] = b[0];
+            ism[l] = k < H && (int)(int8_t)(b[1] & 0xff) == MIN_FLAG;
         }
         const unsigned long long mset = wv::ballot(ism);
         if (!mset) continue;
         unsigned long long carry = 0;                     // bit j: MIN hit j already found its hit in seed carry_seed
         int carry_seed = -1;
         for (int base = 0; base < H; base += 64) {
-            wv::Lane<int> Qa0, Qa1, Qa2, Qa3, Qb0, Qb1, Qb2, Qb3, seg, sd, elig, hit;
+            wv::Lane<int> seg, sd, elig, hit, qkey, qsid, qld;
+            wv::Lane<long long> qdiag;          // position minus the seed's offset on the read: colinear hits share it
             WAVE_FOR(l) {
                 const int k = base + l, kk = k < H ? k : H - 1;
                 int a[4], b[4];
                 hp_load16(ns + kk, a); hp_load16((const HP_G char *)(ns + kk) + 16, b);
-                Qa0[l] = a[0]; Qa1[l] = a[1]; Qa2[l] = a[2]; Qa3[l] = a[3]; Qb0[l] = b[0]; Qb1[l] = b[1]; Qb2[l] = b[2]; Qb3[l] = b[3];
                 const int s = a[3] >> 14;
-                const int h0 = (int)(g_hoff[s] - hb), h1 = (int)(g_hoff[s + 1] - hb);
-                const int st = h0 - base;
+                const int st = kk - (a[3] & 16383) - base;                 // first hit of this hit's seed, relative to the chunk
                 seg[l] = st > 0 ? st : 0; sd[l] = k < H ? s : -1;
-                elig[l] = k < H && h1 - h0 > min_n;
+                elig[l] = k < H && (int)(int8_t)(b[1] & 0xff) == MULTI_FLAG;
                 hit[l] = 0;
+                const int sid_ = (int)(int16_t)(b[0] & 0xffff), st_ = (int)(int8_t)((b[0] >> 16) & 0xff);
+                qkey[l] = a[2] * 2 + (st_ > 0 ? 1 : 0); qsid[l] = sid_; qld[l] = (int)(int8_t)((b[0] >> 24) & 0xff);
+                qdiag[l] = (long long)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]) - (long long)(st_ * sid_ * K.seed_step);
             }
             const int last = H - 1 - base < 63 ? H - 1 - base : 63;
             const int s_last = wv::bcast(sd, last), st_last = wv::bcast(seg, last);
             unsigned long long next_carry = 0;
             for (unsigned long long mm = mset; mm; mm &= mm - 1) {
                 const int j = __builtin_ctzll(mm);
-                NodeS M;
-                {
-                    int a[4] = { wv::bcast(Ma0, j), wv::bcast(Ma1, j), wv::bcast(Ma2, j), wv::bcast(Ma3, j) };
-                    int b[4] = { wv::bcast(Mb0, j), wv::bcast(Mb1, j), wv::bcast(Mb2, j), wv::bcast(Mb3, j) };
-                    M = node_unpack(a, b);
-                }
-                const int xm = M.slot_j >> 14;
+                // M's record out of lane j; the edge class is evaluated directly on diagonals (position minus the seed's
+                // offset on the read): for two hits on the same contig and strand, get_fseed_dis' act - exp is the
+                // difference of their diagonals (:607-612), so "match class" (:614-619) is two subtractions and a compare.
+                const int ma0 = wv::bcast(Ma0, j), ma1 = wv::bcast(Ma1, j), ma2 = wv::bcast(Ma2, j), ma3 = wv::bcast(Ma3, j), mb0 = wv::bcast(Mb0, j);
+                const int msid = (int)(int16_t)(mb0 & 0xffff), mst = (int)(int8_t)((mb0 >> 16) & 0xff), mld = (int)(int8_t)((mb0 >> 24) & 0xff);
+                const int xm = ma3 >> 14;
+                const int mkey = ma2 * 2 + (mst > 0 ? 1 : 0);
+                const long long mdiag = (long long)(((unsigned long long)(unsigned)ma1 << 32) | (unsigned)ma0) - (long long)(mst * msid * K.seed_step);
                 wv::Lane<int> q;
                 WAVE_FOR(l) {
                     int v = 0;
-                    if (elig[l] && sd[l] != xm) {
-                        int a[4] = { Qa0[l], Qa1[l], Qa2[l], Qa3[l] }, b[4] = { Qb0[l], Qb1[l], Qb2[l], Qb3[l] };
-                        const NodeS Q = node_unpack(a, b);
-                        const int f = sd[l] < xm ? edge_flag_packed(K, Q, M) : edge_flag_packed(K, M, Q);
-                        v = (f == F_MATCH || f == F_MISMATCH || f == F_LONG_MISMATCH);
+                    if (elig[l] && qkey[l] == mkey && sd[l] != xm) {
+                        const bool q_first = sd[l] < xm;                     // the hit of the earlier seed is `pre`
+                        const int did = iabs(qsid[l] - msid);
+                        const long long D = q_first ? mdiag - qdiag[l] : qdiag[l] - mdiag;     // act - exp
+                        const int ld = mst > 0 ? (q_first ? qld[l] : mld) : (q_first ? mld : qld[l]);
+                        const int dis = (int)((long long)mst * D - (long long)ld);
+                        const int mat_dis = K.match_dis * (K.high_err ? did : 1);
+                        v = did * K.seed_step >= K.seed_len && dis <= mat_dis && dis >= -mat_dis;
                     }
                     q[l] = v;
                 }
@@ -583,11 +595,14 @@ HP_NOINL void min_extend_all(ReadCtx &r, int min_n)
                 }
                 if ((qb >> st_last) != 0 || (carry_seed == s_last && cj)) next_carry |= 1ull << j;
             }
-            WAVE_FOR(l) { if (hit[l]) gd[base + l].dp_flag = MIN_FLAG; }
+            WAVE_FOR(l) { if (hit[l]) gmk[base + l] = 1; }
             carry = next_carry; carry_seed = s_last;
         }
     }
     wv::sync();
+    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { const int k = b0 + l; if (k < H && gmk[k]) gd[k].dp_flag = MIN_FLAG; } }
+    wv::sync();
+    arena_release(r.cx.tmp, mark_);
 }
 
 // ---------------------------------------------------------------- end-node stack / bounded heaps (lamsa_heap.c)
@@ -1394,6 +1409,9 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     int min_n = P->first_loci_thd, min_exist = 0, min_num = 0;
     for (int i = 0; i < seed_out; ++i) if (mapn(r, i) <= min_n) { min_exist = 1; ++min_num; }    // :1315-1323
     const bool all_min = (!min_exist || min_num * 3 < seed_out);                                 // :1324-1331
+#ifdef HP_PROF
+    long long tq_ = wv::clock(); if (r.prof) r.prof[56] += tq_ - tc_;
+#endif
     for (int base = 0; base < H; base += 64) {
         WAVE_FOR(l) {
             const int k = base + l;
@@ -1401,10 +1419,16 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
         }
     }
     wv::sync();
+#ifdef HP_PROF
+    { const long long t2_ = wv::clock(); if (r.prof) r.prof[57] += t2_ - tq_; tq_ = t2_; }
+#endif
     if (all_min) min_n = P->per_aln_m;
     if (min_n != P->per_aln_m) {                                                                  // :1335-1343
         min_extend_all(r, min_n);
     }
+#ifdef HP_PROF
+    { const long long t2_ = wv::clock(); if (r.prof) { r.prof[58] += t2_ - tq_; r.prof[59] += all_min ? 0 : 1; } }
+#endif
     HP_CSTAMP(6);
     if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, true);                      // main pass, :1345-1350
 
