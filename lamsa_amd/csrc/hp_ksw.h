@@ -19,6 +19,25 @@
 
 namespace hp {
 
+// LDS direction matrix: a cell needs 4 bits (move into H: 2, "E extends": 1, "F extends": 1; the reference's byte is
+// h | e << 2 | f << 5), 0xF = never written.  A row is filled with 0xFF and every computed cell ANDs its nibble in.
+#ifdef HP_DBG_BYTEZ
+#define HP_ZSTRIDE(n_col) ((((n_col) + 3) >> 2) << 2)
+#else
+#define HP_ZSTRIDE(n_col) ((((n_col) + 7) >> 3) << 2)          // bytes per row
+#endif
+#define HP_ZFITS(n_col, rows) ((size_t)HP_ZSTRIDE(n_col) * (size_t)(rows) <= HP_LDS_Z_BYTES)
+HP_INL int z_nibble(int dir) { return (dir & 3) | ((dir >> 2) & 1) << 2 | ((dir >> 5) & 1) << 3; }
+HP_INL void z_row_clear(HP_L uint8_t *LZ, int row, int n_col) {
+    HP_L int *p = (HP_L int *)(LZ + row * HP_ZSTRIDE(n_col));
+    const int nd = HP_ZSTRIDE(n_col) >> 2;
+    for (int d0 = 0; d0 < nd; d0 += 64) { WAVE_FOR(l) { if (d0 + l < nd) p[d0 + l] = -1; } }
+}
+HP_INL void z_put(HP_L uint8_t *LZ, int row, int n_col, int c, int dir) {          // per lane
+    HP_L int *p = (HP_L int *)(LZ + row * HP_ZSTRIDE(n_col)) + (c >> 3);
+    wv::lds_and(p, (int)~((unsigned)(~z_nibble(dir) & 0xf) << ((c & 7) << 2)));
+}
+
 // ---- traceback (src/ksw.c:638-649 and :792-801).  The direction matrix lives in LDS (lz) when it fits, else in the
 // wave's HBM slab (gz).  Cells the forward pass never wrote read as 255 (src/ksw.c:707): outside the row's window
 // always; inside it the LDS matrix holds 255 where the band did not reach, and for the HBM matrix of the extension
@@ -39,8 +58,10 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
         const int off = i > w ? i - w : 0;
         int cell = 255;
         if (k >= off && k - off < n_col) {
-            if (lz) cell = lz[i * n_col + (k - off)];
-            else {
+            if (lz) {                                                       // 4 bits per cell, rows padded to whole dwords
+                const int c = k - off, nib = (lz[i * HP_ZSTRIDE(n_col) + (c >> 1)] >> ((c & 1) << 2)) & 0xf;
+                cell = nib == 0xf ? 255 : ((nib & 3) | ((nib & 4) ? 1 << 2 : 0) | ((nib & 8) ? 2 << 4 : 0));
+            } else {
                 const int zc = gz[(long)i * n_col + (k - off)];
                 if (grb) { const hp_v2i be = grb[i]; cell = (k >= be.x && k < be.y) ? zc : 255; } else cell = zc;
             }
@@ -63,6 +84,10 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
 }
 
 #define HP_SCAN_IDENT (-0x7f000000)
+
+// what an extension returns: by value, in registers (results handed back through pointers into the caller's frame
+// would go through scratch memory)
+struct ExtRes { int score, qle, tle; };
 
 // ---- ksw_global2 (src/ksw.c:543-653) with the H/E row in the wave's HBM slab: only for bands wider than the LDS row.
 HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
@@ -154,9 +179,9 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 
 // ---- ksw_extend_core (src/ksw.c:667-807) with the H/E row in the wave's HBM slab: only for bands wider than the LDS row.
 // w is already adjusted (see ksw_extend).
-HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
-                             int *qle, int *tle, CigV *out)
+HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     const lamsa_hp_para *P = cx.P;
     const int o_ins = P->ins_ext_o, e_ins = P->ins_ext_e, o_del = P->del_ext_o, e_del = P->del_ext_e;
@@ -168,7 +193,7 @@ HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, i
     int32_t *E = (int32_t *)arena_alloc(cx, sizeof(int32_t) * ((size_t)qlen + 2));
     int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
     uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
-    if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return 0; }
+    if (!H || !E || !rowb || !z) { arena_release(cx.tmp, mark); return er; }
 
     const int sc_match = P->match, sc_mis = -P->mis;
     HP_G int32_t *gH = (HP_G int32_t *)H, *gE = (HP_G int32_t *)E, *growb = (HP_G int32_t *)rowb;
@@ -295,12 +320,11 @@ HP_NOINL int ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, i
     int i, k;
     if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
     else { i = max_ie; k = qlen - 1; }
-    if (qle) *qle = k + 1;
-    if (tle) *tle = i + 1;
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
-    return max;
+    return er;
 }
 
 // =====================================================================================================
@@ -323,7 +347,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
     const size_t mark = arena_mark(cx.tmp);
-    const bool zl = (size_t)n_col * tlen <= HP_LDS_Z_BYTES;
+    const bool zl = HP_ZFITS(n_col, tlen);
     uint8_t *z = (out && !zl) ? (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1) : nullptr;
     if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
     HP_L int32_t *LH = cx.lds, *LE = cx.lds + HP_LDS_CELLS;
@@ -353,6 +377,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
             hw = end;
         }
         while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
+        if (out && zl) z_row_clear(LZ, i, n_col);
         wv::sync();
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
         int carryH = wv::uni(LH[beg & HP_LDS_MASK]);          // H(i-1,beg-1), read before the in-place update below
@@ -391,7 +416,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                     if (f > tt) dir |= 2 << 4; else f = tt;                // :608-611
                     LE[j & HP_LDS_MASK] = ee;
                     LH[(j + 1) & HP_LDS_MASK] = h;                         // eh[j+1].h = H(i,j)
-                    if (out) { if (zl) LZ[i * n_col + (j - beg)] = (uint8_t)dir; else gz[(long)i * n_col + (j - beg)] = (uint8_t)dir; }
+                    if (out) { if (zl) z_put(LZ, i, n_col, j - beg, dir); else gz[(long)i * n_col + (j - beg)] = (uint8_t)dir; }
                     fnext[l] = f;
                 }
             }
@@ -428,9 +453,9 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     return ksw_global_wide(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
 }
 
-HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0,
-                            int *qle, int *tle, CigV *out)
+HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     // Arguments of a non-inlined device function arrive in vector registers: tell the compiler that they are
     // wave-uniform, so that loop counters, band limits and branches live in scalar registers.
@@ -441,10 +466,10 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     const size_t mark = arena_mark(cx.tmp);
-    const bool zl = (size_t)n_col * tlen <= HP_LDS_Z_BYTES;
+    const bool zl = HP_ZFITS(n_col, tlen);
     uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
     int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
-    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return 0; }
+    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
 #ifdef HP_PROF
     if (!zl && cx.prof) { cx.prof[52] += (long long)n_col * tlen; cx.prof[53] += 1; }
 #endif
@@ -482,12 +507,8 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
             hw = end;
         }
         while (end - 1 > qw) { WAVE_FOR(l) { const int j = qw + 1 + l; if (j < qlen) LQ[j & HP_LDS_MASK] = gq[(long)j * qs]; } qw += 64; }
-        if (zl) {                                                          // window cells the band does not reach: never written
-            if (beg > d_beg || end < d_beg + n_col) {
-#pragma nounroll
-                for (int c0 = 0; c0 < n_col; c0 += 64) { WAVE_FOR(l) { const int c = c0 + l, j = d_beg + c; if (c < n_col && (j < beg || j >= end)) LZ[i * n_col + c] = 255; } }
-            }
-        } else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
+        if (zl) z_row_clear(LZ, i, n_col);                                  // cells the band does not reach stay "never written"
+        else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
         wv::sync();
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
@@ -532,7 +553,7 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
                     if (f > tt) dir |= 2 << 4; else f = tt;                 // :751-755
                     LE[j & HP_LDS_MASK] = ee;
                     LH[(j + 1) & HP_LDS_MASK] = h;
-                    if (zl) LZ[i * n_col + (j - d_beg)] = (uint8_t)dir; else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
+                    if (zl) z_put(LZ, i, n_col, j - d_beg, dir); else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
                     fnext[l] = f; hnz[l] = h != 0; enz[l] = ee != 0;
                     hh[l] = h;                                               // scores of this routine are never negative
                 }
@@ -591,12 +612,11 @@ HP_NOINL int ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, in
     int i, k;
     if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
     else { i = max_ie; k = qlen - 1; }
-    if (qle) *qle = k + 1;
-    if (tle) *tle = i + 1;
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
-    return max;
+    return er;
 }
 
 // ---- ksw_extend_core (src/ksw.c:667-807).  Uses the *extension* gap penalties. ----
@@ -617,8 +637,10 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }
-    if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, qle, tle, out);
-    return ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, qle, tle, out);
+    const ExtRes er = 2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out);
+    if (qle) *qle = er.qle;
+    if (tle) *tle = er.tle;
+    return er.score;
 }
 
 // ksw_extend_c (src/ksw.c:809): 0 query-to-end, 1 target-to-end, 2 neither
@@ -642,7 +664,7 @@ HP_INL int ksw_extend_r(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0
 }
 
 // sw_mid_fix (src/ksw.c:841-860): appends to out
-HP_FN void sw_mid_fix(Ctx &cx, CigV &out, const cig_t *lc, int ln, const cig_t *rc, int rn,
+HP_INL void sw_mid_fix(Ctx &cx, CigV &out, const cig_t *lc, int ln, const cig_t *rc, int rn,
                       int qlen, Seq q, int lqe, int rqe, int tlen, Seq t, int lte, int rte)
 {
     const lamsa_hp_para *P = cx.P;
@@ -714,6 +736,9 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
             ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
         } else {
             cig_invert(R.c, R.n);
+#ifdef HP_DBG_ENDS
+            cig_raw_push(cx, out, lqe); cig_raw_push(cx, out, lte); cig_raw_push(cx, out, rqe); cig_raw_push(cx, out, rte); cig_raw_push(cx, out, qlen); cig_raw_push(cx, out, tlen);
+#endif
             sw_mid_fix(cx, out, L.c, L.n, R.c, R.n, qlen, q, lqe, rqe, tlen, t, lte, rte);
             ret = (qlen - lqe - rqe) >= P->split_len ? 1 : 0;                                // :924
         }

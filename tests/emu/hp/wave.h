@@ -23,6 +23,8 @@ namespace wv {
 
 constexpr int W = 64;
 
+HP_INL void lds_and(int *p, int mask) { *p &= mask; }
+
 template <class T> struct Lane {
     T v[64];
     T &operator[](int l) { return v[l]; }
