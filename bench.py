@@ -183,7 +183,7 @@ def main():
         # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
         t0 = time.perf_counter(); h.upload_batch(B); h.run_uploaded(fetch=True, raw=True); t_pcie = time.perf_counter() - t0
         cpu = None
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:               # the CPU baseline is measured on rank 0 of the single-GPU run only
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
             probe = min(256, a.reads)                      # estimate the rate on a probe, then size the sample for ~cpu_seconds
             t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, threads); tp = time.perf_counter() - t0
