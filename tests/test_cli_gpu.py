@@ -26,3 +26,28 @@ def test_small_batches(tmp_path):
     p = subprocess.run([BIN, "aln", "-R", "0", "--batch", "4"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(gold)
+
+
+def test_end_to_end_files_at_scale(tmp_path):
+    """1024 simulated 6-kbp ONT-like reads written as the files `lamsa aln` reads (FASTA + GEM map text, tools/simfiles.py),
+    aligned by the product binary in several GPU batches with all host threads, against the oracle's CLI on the same
+    files: SAM byte-identical."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import reflib
+    import simbatch
+    import simfiles
+    ref = simbatch.SimRef(200_000_000, n_contigs=6, seed=5, threads=8)
+    B = simbatch.SimBatch(ref, 1024, 6000, "ont2d", seed=31, threads=8)
+    d = str(tmp_path)
+    simfiles.write_index(d + "/ref.fa", ref)
+    simfiles.write_reads(d + "/reads.fa", B)
+    reflib.build_oracle()
+    want = subprocess.run([os.path.join(ROOT, "oracle", "lamsa_oracle"), "aln", "-T", "ont2d", "-t", "16", "-R", "0", d + "/ref.fa", d + "/reads.fa"],
+                          capture_output=True, text=True)
+    assert want.returncode == 0, want.stderr[-2000:]
+    got = subprocess.run([BIN, "aln", "-T", "ont2d", "-R", "0", "--batch", "300", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+    assert got.returncode == 0, got.stderr[-2000:]
+    a, b = G.strip_pg(got.stdout), G.strip_pg(want.stdout)
+    assert len(a.splitlines()) >= 1024 + 6
+    assert a == b
