@@ -231,6 +231,7 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 #ifdef HP_EMU_STATS
 void hp_emu_stat_call(int range, int lo, int hi, bool force);
 void hp_emu_stat_due(int range, int due, int span);
+void hp_emu_stat_run(int n, int is_run);
 static int g_emu_act = 0;
 #endif
 struct ScanT { NodeS T; int tkey, x, t_NM; long long Rw; };
@@ -809,10 +810,10 @@ template <int NS> HP_INL int ms_pick(const wv::Lane<int> *f, int c) {
     for (int q = 1; q < NS; ++q) { const int u = wv::bcast(f[q], l); v = j == q ? u : v; }
     return v;
 }
-// ids: by_run ? srt[rlo + idx] : k_lo + idx, idx < n_ids <= 64 * NS
+// ids: list ? list[idx] : k_lo + idx, idx < n_ids <= 64 * NS
 template <int NS>
 HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail,
-                            int n_ids, int by_run_, int rlo)
+                            int n_ids, const int32_t *list)
 {
     left = wv::uni(left); right = wv::uni(right); right_x = wv::uni(right_x); _head = wv::uni(_head); _tail = wv::uni(_tail);
     const int head = _head ? left : -1;
@@ -822,13 +823,13 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
     const int k_lo = wv::uni(hoff(r, start_slot)), k_t0 = wv::uni(hoff(r, left_x + 2));
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
-    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
     const EdgeK K = edge_consts(r.cx.P);
     const int POSMAX = (1 << 28) - 1;
-    n_ids = wv::uni(n_ids); rlo = wv::uni(rlo);
-    const bool by_run = wv::uni(by_run_) != 0;
+    n_ids = wv::uni(n_ids);
+    const HP_G int32_t *g_list = (const HP_G int32_t *)wv::uni64((long long)list);
+    const bool by_list = list != nullptr;
     // ---- anchors
     NodeS Fh; Fh.pos = 0; Fh.chr = 0; Fh.slot_j = 0; Fh.sid = 0; Fh.strand = 0; Fh.len_dif8 = 0; Fh.pad_ = 0; Fh.dp_flag = 0; Fh.son_flag = 0; Fh.match_flag = 0; Fh.score = 0; Fh.NM = 0;
     NodeS Rt = Fh;
@@ -847,7 +848,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
         WAVE_FOR(l) {
             const int idx = 64 * j + l;
             const bool valid = idx < n_ids;
-            const int id = valid ? (by_run ? (int)g_srt[rlo + idx] : k_lo + idx) : 0;
+            const int id = valid ? (by_list ? (int)g_list[idx] : k_lo + idx) : 0;
             int a[4], b[4];
             hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
             const int nm0 = g_hnm[id];
@@ -1025,22 +1026,67 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
     const int head = _head ? left : -1;
     const int left_x = nx(r, left);
     const int k_lo = hoff(r, left_x + 1), k_hi = hoff(r, right_x);
-    int n_ids, rlo = 0, by_run = 0;
-    if (k_hi - k_lo <= 64 * HP_MS_MAX_SETS) n_ids = k_hi - k_lo;
-    else if (head < 0 && _tail != 0 && right >= 0) {
-        const lamsa_hp_para *P = r.cx.P;
-        const int did_max = r.seed_id[right_x] - r.seed_id[left_x + 1];
-        const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
-        long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
-        if (mdm + 1 > Rw) Rw = mdm + 1;
-        Rw += 128 + (long long)did_max * P->seed_step;
-        int rhi;
-        reach_run(r, right, Rw, &rlo, &rhi);
-        if (rhi - rlo + 1 > 64 * HP_MS_MAX_SETS) return -1;
-        by_run = 1; n_ids = rhi - rlo + 1;
-    } else return -1;
-    if (n_ids <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, by_run, rlo);
-    return mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, by_run, rlo);
+    if (k_hi - k_lo <= 64 * HP_MS_MAX_SETS) {
+        const int n_ids = k_hi - k_lo;
+        if (n_ids <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, nullptr);
+        return mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, nullptr);
+    }
+    // A long seed range.  The hits that take part are those that can be connected to the pass's anchor: the head when
+    // there is one (frag_dp_per_init keeps only hits that connect to it, :766-784), else the right anchor (pass from
+    // START, see reach_run).  They lie in the anchor's run of the sorted order; the hits of that run that belong to the
+    // seed range and to this kind of pass are listed, and if at most 256 remain the pass runs on registers.
+    const int anchor = head >= 0 ? head : ((_tail != 0 && right >= 0) ? right : -1);
+    if (anchor < 0) return -1;
+    const lamsa_hp_para *P = r.cx.P;
+    const int sid_hi = right_x < r.seed_out ? r.seed_id[right_x] : r.seed_id[r.seed_out - 1];
+    const int did_max = sid_hi - (head >= 0 ? r.seed_id[left_x] : r.seed_id[left_x + 1]);
+    const int mdm = P->match_dis * ((P->aln_mode & 2) ? did_max : 1);
+    long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
+    if (mdm + 1 > Rw) Rw = mdm + 1;
+    Rw += 128 + (long long)did_max * P->seed_step;
+    int rlo, rhi;
+    reach_run(r, anchor, Rw, &rlo, &rhi);
+    const int R = rhi - rlo + 1;
+#ifdef HP_EMU_STATS
+    hp_emu_stat_run(R, head < 0);
+#endif
+    if (R > 2048) return -1;
+    const size_t mark = arena_mark(r.cx.tmp);
+    int32_t *list = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(R + 64));
+    if (!list) { arena_release(r.cx.tmp, mark); return -1; }
+    int n = 0;
+    {
+        const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+        const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
+        HP_G int32_t *g_list = (HP_G int32_t *)list;
+        const int start_slot = left_x + 1;
+        for (int b0 = 0; b0 < R; b0 += 64) {
+            wv::Lane<int> keep, idl;
+            WAVE_FOR(l) {
+                int ok = 0, id = 0;
+                if (b0 + l < R) {
+                    id = g_srt[rlo + b0 + l];
+                    int b[4];
+                    hp_load16((const HP_G char *)(ns + id) + 16, b);
+                    const int slot = ns[id].slot_j >> 14, df = (int)(int8_t)(b[1] & 0xff);
+                    ok = slot >= start_slot && slot < right_x && (df == MULTI_FLAG || df == 0 - MULTI_FLAG);
+                }
+                keep[l] = ok; idl[l] = id;
+            }
+            const unsigned long long m = wv::ballot(keep);
+            WAVE_FOR(l) { if (keep[l]) g_list[n + __builtin_popcountll(m & ((1ull << l) - 1))] = idl[l]; }
+            n += __builtin_popcountll(m);
+        }
+        wv::sync();
+    }
+#ifdef HP_EMU_STATS
+    hp_emu_stat_run(n, 2 + (head < 0));
+#endif
+    int ret = -1;
+    if (n <= 64) ret = mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);
+    else if (n <= 64 * HP_MS_MAX_SETS) ret = mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);
+    arena_release(r.cx.tmp, mark);
+    return ret;
 }
 
 // ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150
