@@ -1026,17 +1026,13 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
     const int head = _head ? left : -1;
     const int left_x = nx(r, left);
     const int k_lo = hoff(r, left_x + 1), k_hi = hoff(r, right_x);
-    if (k_hi - k_lo <= 64 * HP_MS_MAX_SETS) {
-        const int n_ids = k_hi - k_lo;
-        if (n_ids <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, nullptr);
-        return mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n_ids, nullptr);
-    }
-    // A long seed range.  The hits that take part are those that can be connected to the pass's anchor: the head when
+    if (k_hi - k_lo <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, k_hi - k_lo, nullptr);
+    // A longer seed range.  The hits that take part are those that can be connected to the pass's anchor: the head when
     // there is one (frag_dp_per_init keeps only hits that connect to it, :766-784), else the right anchor (pass from
     // START, see reach_run).  They lie in the anchor's run of the sorted order; the hits of that run that belong to the
     // seed range and to this kind of pass are listed, and if at most 256 remain the pass runs on registers.
     const int anchor = head >= 0 ? head : ((_tail != 0 && right >= 0) ? right : -1);
-    if (anchor < 0) return -1;
+    if (anchor < 0) return k_hi - k_lo <= 64 * HP_MS_MAX_SETS ? mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, k_hi - k_lo, nullptr) : -1;
     const lamsa_hp_para *P = r.cx.P;
     const int sid_hi = right_x < r.seed_out ? r.seed_id[right_x] : r.seed_id[r.seed_out - 1];
     const int did_max = sid_hi - (head >= 0 ? r.seed_id[left_x] : r.seed_id[left_x + 1]);
