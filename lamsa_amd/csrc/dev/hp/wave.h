@@ -73,17 +73,10 @@ HP_INL int dpp(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, 
 // v = max(v, v[source lane]) in ONE VALU instruction: v_max_i32 with a DPP source operand.  Lanes whose DPP source is
 // invalid or masked off keep v.  The s_nop covers the "VALU write -> DPP read of the same VGPR" hazard (2 wait states),
 // which the assembler does not insert inside inline asm.
-#ifdef HP_DBG_NOASM
-#define HP_MAX_DPP(v, CTRL) do { } while (0)
-#else
 #define HP_MAX_DPP(v, CTRL) asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " CTRL : "+v"(v))
-#endif
 
 HP_INL int reduce_max(const Lane<int> &x) {
     int v = x.v;
-#ifdef HP_DBG_NOASM
-    { int o; o = dpp<0xB1>(v, v); v = o > v ? o : v; o = dpp<0x4E>(v, v); v = o > v ? o : v; o = dpp<0x141>(v, v); v = o > v ? o : v; o = dpp<0x140>(v, v); v = o > v ? o : v; }
-#endif
     HP_MAX_DPP(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
     HP_MAX_DPP(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
     HP_MAX_DPP(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
@@ -113,10 +106,6 @@ HP_INL long long reduce_max64(const Lane<long long> &x) {
 // exclusive prefix max over lanes; lane 0 receives `ident` (which must be <= every input)
 HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     int v = x.v;
-#ifdef HP_DBG_NOASM
-    { int o; o = dpp<0x111>(ident, v); v = o > v ? o : v; o = dpp<0x112>(ident, v); v = o > v ? o : v; o = dpp<0x114>(ident, v); v = o > v ? o : v; o = dpp<0x118>(ident, v); v = o > v ? o : v;
-      o = dpp<0x142, 0xA>(ident, v); v = o > v ? o : v; o = dpp<0x143, 0xC>(ident, v); v = o > v ? o : v; }
-#endif
     HP_MAX_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf");           // Hillis-Steele inside each 16-lane row
     HP_MAX_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
     HP_MAX_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf");

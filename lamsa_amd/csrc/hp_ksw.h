@@ -21,11 +21,7 @@ namespace hp {
 
 // LDS direction matrix: a cell needs 4 bits (move into H: 2, "E extends": 1, "F extends": 1; the reference's byte is
 // h | e << 2 | f << 5), 0xF = never written.  A row is filled with 0xFF and every computed cell ANDs its nibble in.
-#ifdef HP_DBG_BYTEZ
-#define HP_ZSTRIDE(n_col) ((((n_col) + 3) >> 2) << 2)
-#else
 #define HP_ZSTRIDE(n_col) ((((n_col) + 7) >> 3) << 2)          // bytes per row
-#endif
 #define HP_ZFITS(n_col, rows) ((size_t)HP_ZSTRIDE(n_col) * (size_t)(rows) <= HP_LDS_Z_BYTES)
 HP_INL int z_nibble(int dir) { return (dir & 3) | ((dir >> 2) & 1) << 2 | ((dir >> 5) & 1) << 3; }
 HP_INL void z_row_clear(HP_L uint8_t *LZ, int row, int n_col) {
@@ -736,9 +732,6 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
             ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
         } else {
             cig_invert(R.c, R.n);
-#ifdef HP_DBG_ENDS
-            cig_raw_push(cx, out, lqe); cig_raw_push(cx, out, lte); cig_raw_push(cx, out, rqe); cig_raw_push(cx, out, rte); cig_raw_push(cx, out, qlen); cig_raw_push(cx, out, tlen);
-#endif
             sw_mid_fix(cx, out, L.c, L.n, R.c, R.n, qlen, q, lqe, rqe, tlen, t, lte, rte);
             ret = (qlen - lqe - rqe) >= P->split_len ? 1 : 0;                                // :924
         }
