@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--rehearse", action="store_true", help="development only: run the N > 1 code path with the gloo backend and every rank on GPU 0 "
+                    "(a one-GPU box cannot run RCCL with two ranks); the driver never passes this")
     a = ap.parse_args()
 
     import torch
@@ -127,9 +129,15 @@ def main():
         a.gpus = world
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.rehearse:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = local if world > 1 else 0
+    red_dev = None if (world == 1 or a.rehearse) else "cuda"
 
     import simbatch
     import reflib
@@ -169,7 +177,7 @@ def main():
     n_bases = int(B.read_off[-1])
     mapped_bases = count_mapped_bases(B, streams)
     n_fail = int((status != 0).sum())
-    dt, tot = reduce_job(dt, [a.reads, mapped_bases, n_bases, n_fail], world, device="cuda" if world > 1 else None)   # whole-job totals over ranks
+    dt, tot = reduce_job(dt, [a.reads, mapped_bases, n_bases, n_fail], world, device=red_dev)   # whole-job totals over ranks
     reads_per_s, gbase_per_s = job_rates(dt, tot, a.steps)
 
     if rank == 0:
@@ -191,9 +199,9 @@ def main():
             sample = take_first(B, n_s)
             t0 = time.perf_counter(); want = reflib.oracle_streams(sample, lp, threads); tc = time.perf_counter() - t0
             same = sum(1 for i in range(n_s) if want[i] == streams[i])
-            cpu = {"value": round(n_s / tc, 3), "unit": "reads/s", "cores": threads, "kind": "port",
+            cpu = {"value": round(float(sample.read_off[-1]) / tc / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "port",
                    "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path), %d threads, %.1f s" % (n_s, threads, tc),
-                   "gbase_per_s": round(float(sample.read_off[-1]) / tc / 1e9, 6), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s)}
+                   "reads_per_s": round(n_s / tc, 3), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s)}
         hits = np.diff(B.hit_off)
         out = {
             "metric": "aligned Gbase/s, %s vs GRCh37-sized stand-in" % wl["desc"], "value": round(gbase_per_s, 6), "unit": "Gbase/s",
