@@ -14,7 +14,7 @@
 using namespace hp;
 
 #ifndef HP_WAVES_PER_SIMD
-#define HP_WAVES_PER_SIMD 5          // measured on the default workload with the final kernel: 3 -> 314 ms, 4 -> 280, 5 -> 270, 6 -> 295
+#define HP_WAVES_PER_SIMD 4          // final kernel, default workload: 3 -> 314 ms, 4 -> 280, 5 -> 270 (but 70 % more HBM traffic), 6 -> 295
 #endif
 __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs a)
 {

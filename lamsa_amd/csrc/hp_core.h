@@ -22,13 +22,13 @@ HP_INL size_t arena_mark(const Arena &a) { return a.top; }
 HP_INL void arena_release(Arena &a, size_t m) { a.top = m; }
 
 // LDS of one wave (= one workgroup): circular H and E rows, staged query bases, direction matrix (see hp_ksw.h).
-// Sized for 5 waves per SIMD = 20 workgroups per CU: 20 x 7.5 KB of the CU's 160 KB.  Bands up to w = 222 use the
+// Sized for 4 waves per SIMD = 16 workgroups per CU: 16 x 9.5 KB of the CU's 160 KB.  Bands up to w = 222 use the
 // LDS rows (the presets use 10..200); wider ones fall back to rows in HBM.
 #ifndef HP_LDS_CELLS
 #define HP_LDS_CELLS 512
 #endif
 #ifndef HP_LDS_Z_BYTES
-#define HP_LDS_Z_BYTES 3072
+#define HP_LDS_Z_BYTES 5120
 #endif
 #define HP_LDS_WORDS (2 * HP_LDS_CELLS + HP_LDS_CELLS / 4 + HP_LDS_Z_BYTES / 4)
 
