@@ -162,3 +162,27 @@ def test_hip_full_size_batch_properties():
     want = reflib.oracle_streams(first, lp, 8)
     assert [i for i in range(96) if want[i] != got[i]] == []
     h.close()
+
+
+OPTION_SETS = [
+    dict(match=2, mis=5, ins_gapo=4, del_gapo=6, ins_gape=1, del_gape=2, ins_ext_o=4, del_ext_o=6, ins_ext_e=1, del_ext_e=2, band_w=50, end_bonus=3, ovlp_rat=0.5, ske_max=5),
+    dict(split_len=50, res_mul_max=3, SV_len_thd=5000, per_aln_m=100, band_w=300),          # -g 50 -r 3 -V 5000 -p 100 -w 300 (wide band: HBM rows)
+]
+
+
+@pytest.mark.parametrize("name", ["c2_pacbio", "c3_ont", "c5_sv"])
+@pytest.mark.parametrize("k", [0, 1])
+def test_hip_scoring_and_limit_options(name, k, tmp_path):
+    """Command-line options other than the presets (-m -M -O -E -w -b -v -s / -g -r -V -p -w) reach the kernels through
+    lamsa_hp_para and give the oracle's result."""
+    ref, reads, args, _ = goldenlib.stage_scenario(name, str(tmp_path))
+    rt, over = goldenlib.para_from_args(args)
+    over = dict(over); over.update(OPTION_SETS[k])
+    lp = reflib.lo_para(rt, **over)
+    B = reflib.Batch(ref, reads, lp)
+    want = reflib.oracle_streams(B, lp)
+    h = _handle(B, rt, over)
+    got, st = h.align_batch(B)
+    h.close()
+    assert [i for i in range(B.n_reads) if want[i] != got[i]] == []
+    assert (st == 0).all()
