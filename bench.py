@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--reads", type=int, default=32768, help="reads per batch (= per step) and per GPU")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0: skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="development only: run the N > 1 code path with the gloo backend and every rank on GPU 0 "
                     "(a one-GPU box cannot run RCCL with two ranks); the driver never passes this")
