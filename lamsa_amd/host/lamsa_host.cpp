@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <thread>
 #include <zlib.h>
 
@@ -440,35 +442,47 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     std::string sam;
     sam_header(sam, ix, pg_line);
     fwrite(sam.data(), 1, sam.size(), out);
-    Batch B; B.clear();
-    Read rd; bool eof = false; int ret = 0;
     long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
     const int threads = opt.n_thread > 0 ? opt.n_thread : 1;
-    std::vector<std::string> raw;                       // the chunk's GEM map lines, per read
-    while (!eof && ret == 0) {
-        // ---- sequential part: the chunk's reads and their map lines as text
-        B.clear(); raw.clear();
+    bool eof = false; int ret = 0;
+    // One chunk = reads + their hit records, ready for the GPU.  The next chunk is read and parsed (on all host
+    // threads) while the GPU works on the current one and while the previous one's SAM text is formatted.
+    struct Chunk { Batch B; int ret = 0; };
+    auto prepare = [&]() -> std::unique_ptr<Chunk> {
+        std::unique_ptr<Chunk> c(new Chunk);
+        Batch &B = c->B;
+        B.clear();
+        if (eof) return c;
+        std::vector<std::string> raw;                   // the chunk's GEM map lines, per read
+        Read rd; std::string e;
         int64_t chunk_bases = 0;
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
             if (!fx.next(rd)) { eof = true; break; }
             raw.emplace_back();
-            if (!read_map_lines(mapf, seeds_of(P, (int)rd.seq.size()), raw.back(), err)) { fprintf(stderr, "[lamsa_read_seq] %s\n", err.c_str()); ret = 1; break; }
+            if (!read_map_lines(mapf, seeds_of(P, (int)rd.seq.size()), raw.back(), e)) { fprintf(stderr, "[lamsa_read_seq] %s\n", e.c_str()); c->ret = 1; return c; }
             B.reads.push_back(rd);
             chunk_bases += (int64_t)rd.seq.size();
         }
-        if (ret || B.reads.empty()) break;
         const int n = (int)B.reads.size();
-        // ---- text -> hit records, on all host threads (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
-        {
-            std::vector<Batch> parts((size_t)threads);
-            for (Batch &p : parts) p.clear();
-            parallel_blocks(n, threads, [&](int t, int r0, int r1) {
-                for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], raw[(size_t)r].c_str(), seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
-            });
-            merge_batches(B, parts);
-        }
-        for (int32_t c : B.h_chr) if (c < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); ret = 1; break; }
-        if (ret) break;
+        if (n == 0) return c;
+        // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
+        std::vector<Batch> parts((size_t)threads);
+        for (Batch &p : parts) p.clear();
+        parallel_blocks(n, threads, [&](int t, int r0, int r1) {
+            for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], raw[(size_t)r].c_str(), seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
+        });
+        merge_batches(B, parts);
+        for (int32_t ch : B.h_chr) if (ch < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); c->ret = 1; break; }
+        return c;
+    };
+    std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, prepare);
+    while (ret == 0) {
+        std::unique_ptr<Chunk> cur = next.get();
+        if (cur->ret) { ret = cur->ret; break; }
+        if (cur->B.reads.empty()) break;
+        next = std::async(std::launch::async, prepare);      // overlaps with everything below
+        Batch &B = cur->B;
+        const int n = (int)B.reads.size();
         lamsa_hp_batch hb;
         hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
         hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
@@ -500,6 +514,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
     }
+    if (next.valid()) next.wait();                       // the reader thread must be done before the files are closed
     lamsa_hp_destroy(h);
     fclose(mapf);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms; }
