@@ -1,11 +1,14 @@
 // hp_chain.h -- sparse-DP chaining of seed hits into lines on one wavefront
 // (reference src/lamsa_dp_con.c + src/lamsa_heap.c).
 //
-//   edge_flag      <- get_fseed_dis             lamsa_dp_con.c:596
-//   dp_update      <- frag_dp_update            :701   predecessor scan spread over the 64 lanes
-//   min_extend     <- frag_min_extend           :1031  candidate scan spread over the 64 lanes
+//   edge_flag(_packed) <- get_fseed_dis         lamsa_dp_con.c:596
+//   dp_update_range    <- frag_dp_update        :701   targets in order; candidates = the target's neighbours in the
+//                                                      (contig, strand, position) order, spread over the 64 lanes
+//   min_extend_all <- frag_min_extend           :1031  all MIN hits x all hits, blocked, records in registers
 //   branch_track / cut_branch / best_son <- :873,:831,:808   (pointer chasing, wave-uniform)
-//   mini_line      <- frag_mini_dp_line         :1068
+//   reach_run      (no counterpart)             the hits that can be connected to an anchor at all: an exact run of the sorted order
+//   mini_line      <- frag_mini_dp_line         :1068  mini_line_regs / mini_line_sets: the whole pass on registers;
+//                                                      mini_line_mem: through memory, for passes with more than 256 listed hits
 //   multi_line     <- frag_mini_dp_multi_line   :923
 //   set_bound      <- line_set_bound(1)         :425,:496 (minus E_LB/E_RB, which nothing reads)
 //   build_flines   <- frag_dp_path              :1152 (+ line_filter_overlap :568)
