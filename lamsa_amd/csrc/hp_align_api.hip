@@ -211,6 +211,7 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
           for (int k = 0; k < 12; ++k) fprintf(stderr, "[HP_PROF] %-16s %8lld Mcyc %10lld calls\n", nm[k], sum[24 + 2 * k] / 1000000, sum[25 + 2 * k]);
           fprintf(stderr, "[HP_PROF] direction-matrix bytes in HBM %lld (%lld jobs); hits passed through nodes_per_init %lld (%lld calls)\n", sum[52], sum[53], sum[54], sum[55]);
           fprintf(stderr, "[HP_PROF] chain_first start: seed loop %lld, node_set loop %lld, min_extend %lld Mcyc (%lld reads with a MIN pass)\n", sum[56] / 1000000, sum[57] / 1000000, sum[58] / 1000000, sum[59]);
+          fprintf(stderr, "[HP_PROF] query <= 62: ksw_extend %lld Mcyc %lld calls, ksw_global %lld Mcyc %lld calls\n", sum[60] / 1000000, sum[61], sum[62] / 1000000, sum[63]);
           const char *bn[] = {"[bi_extend total]", "[bi_extend after left ext]", "17-32", "33-64", "65-128", "129-256", "257-512", ">512"};
           for (int k = 0; k < 2; ++k) fprintf(stderr, "[HP_PROF] ksw_extend qlen %-8s %8lld Mcyc %10lld calls\n", bn[k], sum[48 + 2 * k] / 1000000, sum[49 + 2 * k]); }
         for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }

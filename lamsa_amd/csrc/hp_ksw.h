@@ -435,6 +435,9 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 24, tg0_);
+#ifdef HP_PROF
+    if (qlen <= 62) HP_TADD(cx, 62, tg0_);
+#endif
     return score;
 }
 
@@ -612,6 +615,9 @@ HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
+#ifdef HP_PROF
+    if (qlen <= 62) HP_TADD(cx, 60, te0_);
+#endif
     return er;
 }
 

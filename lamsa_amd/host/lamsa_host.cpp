@@ -425,6 +425,50 @@ void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index 
     }
 }
 
+// ------------------------------------------------------------------ seeding front end
+// split_seed (src/lamsa_aln.c:223-303) + lamsa_gem (:1179-1193, gem/gem_map.sh): the read file is cut into overlapping
+// seeds (<reads>.seed, names "<read>_<i>:<offset>"; <reads>.seed.info as the reference writes it) and the GEM mapper is
+// run on them with the reference's arguments; its output <reads>.seed.gem.map is what run_aln reads.  The mapper and
+// the <ref>.gem index belong to the reference's bundle (`lamsa index`); nothing of them is part of this repository.
+int run_seeding(const Options &opt, const lamsa_hp_para &P)
+{
+    FastxReader fx;
+    if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
+    const std::string seed_f = opt.reads + ".seed", info_f = opt.reads + ".seed.info";
+    FILE *sf = fopen(seed_f.c_str(), "w"), *inf = fopen(info_f.c_str(), "w");
+    if (!sf || !inf) { fprintf(stderr, "[lamsa_aln] Can't open seed file %s\n", sf ? info_f.c_str() : seed_f.c_str()); if (sf) fclose(sf); if (inf) fclose(inf); return 1; }
+    fprintf(stderr, "[lamsa_aln] Generating seed ... ");
+    Read rd; std::string o;
+    while (fx.next(rd)) {
+        const int L = (int)rd.seq.size(), seed_all = seeds_of(P, L);
+        o.clear();
+        for (int i = 0; i < seed_all; ++i) {
+            o += ">"; o += rd.name; o += "_"; o += std::to_string(i); o += ":"; o += std::to_string(i * P.seed_step); o += "\n";
+            o.append(rd.seq, (size_t)i * P.seed_step, (size_t)P.seed_len); o += "\n";
+        }
+        fwrite(o.data(), 1, o.size(), sf);
+        fprintf(inf, "%s %d %d %d\n", rd.name.c_str(), seed_all, L - P.seed_len - (seed_all - 1) * P.seed_step, L);
+    }
+    fclose(sf); fclose(inf);
+    fprintf(stderr, "done!\n");
+    const int t = P.read_type;
+    const float ed = opt.ed_rate >= 0 ? opt.ed_rate : (t == 1 ? 0.3f : (t == 2 ? 0.25f : 0.04f));
+    const float mis = opt.mis_rate >= 0 ? opt.mis_rate : (t == 2 ? 0.06f : 0.04f);
+    const float mat = opt.mat_rate >= 0 ? opt.mat_rate : (t == 1 ? 0.7f : (t == 2 ? 0.6f : 0.80f));
+    const std::string mapper = opt.gem_dir + "/gem-mapper", idx = opt.ref_prefix + ".gem", outp = seed_f + ".gem";
+    FILE *probe = fopen(mapper.c_str(), "r");
+    if (!probe) { fprintf(stderr, "[lamsa_aln] GEM mapper not found at %s (it ships with the reference; give its directory with --gem-dir, or run with -N on an existing %s.gem.map)\n", mapper.c_str(), seed_f.c_str()); return 1; }
+    fclose(probe);
+    char num[256];
+    snprintf(num, sizeof num, " -m %f -e %f --min-matched-bases %f --max-big-indel-length 3 -d %d -D 0 -T %d %s", mis, ed, mat, P.per_aln_m, opt.n_thread > 0 ? opt.n_thread : 1,
+             opt.fastest ? "--fast-mapping=0" : "--fast-mapping");
+    const std::string cmd = "'" + mapper + "' -I '" + idx + "' -i '" + seed_f + "' -o '" + outp + "'" + num + " 2>> '" + outp + ".log'";
+    fprintf(stderr, "[lamsa_aln] Executing gem-mapper ... \n");
+    if (system(cmd.c_str()) != 0) { fprintf(stderr, "[lamsa_aln] Seeding undone, gem-mapper exit abnormally.\n"); return 1; }
+    fprintf(stderr, "[lamsa_aln] gem-mapper done!\n");
+    return 0;
+}
+
 // ------------------------------------------------------------------ chunk loop
 int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats)
 {

@@ -51,12 +51,18 @@ void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P);
 struct Options {
     std::string ref_prefix, reads, seed_result;
     int supp_soft = 0, comm = 0, device = 0, n_thread = 1;
+    // seeding front end (lamsa_aln_c, src/lamsa_aln.c:1224-1275): -N reuses <reads>.seed.gem.map, otherwise the read file is
+    // cut into seeds and the GEM mapper of the reference's bundle is run on them
+    int no_seed_aln = 0, fastest = 0;
+    float ed_rate = -1, mis_rate = -1, mat_rate = -1;     // -e, -x; defaults per read type (src/lamsa_aln.h:26-70)
+    std::string gem_dir;                                  // directory holding gem-mapper (default: <directory of this binary>/gem)
     int chunk_reads = 16384; int64_t chunk_bases = 256ll << 20;     // reads per GPU batch (the reference's CHUNK_READ_N is 128 per thread pool)
 };
 struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0; };
 
 void sam_header(std::string &o, const Index &ix, const std::string &pg);
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);
+int run_seeding(const Options &opt, const lamsa_hp_para &P);
 int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats);
 
 }  // namespace lamsa

@@ -1,9 +1,10 @@
 // main.cpp -- `lamsa aln` on the MI355X hot path: same command line, scoring options and SAM output as the
 // reference's `lamsa aln` (src/main.c:29-44, src/lamsa_aln.c:1424-1538), including its quirks: `-g` also sets
 // soft clipping (missing break, :1509-1510); `-C` gates QUAL instead of appending the comment (:1037).
-// Differences, all stated at run time: seeding is never started from here (the GEM map <reads>.seed.gem.map
-// must exist: the reference's -N, and -I, are implied); stage (4) (BWT rescue) is not built, so results equal
-// the reference's with `-R 0`; `lamsa index` is left to the reference.
+// Seeding works as in the reference: unless -N (or --seed-result FILE) is given, the reads are cut into seeds and the
+// GEM mapper of the reference's bundle is run on them (--gem-dir DIR, default <directory of this binary>/gem; the
+// <ref>.gem index comes from the reference's `lamsa index`).  Differences, all stated at run time: stage (4) (BWT
+// rescue) is not built, so results equal the reference's with `-R 0`; `lamsa index` is left to the reference.
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +18,8 @@ static int usage()
 {
     fprintf(stderr, "\nUsage:   lamsa aln [options] <ref.fa> <read.fa/fq>\n\n"
                     "         options of the reference's `lamsa aln` (-t -l -i -p -V -v -s -R -k -f -m -M -O -E -w -b -e -d -x -T -r -g -S -C -o -N -I);\n"
-                    "         additionally --device INT (GPU ordinal), --seed-result FILE (GEM map, default <read>.seed.gem.map), --batch INT (reads per GPU batch)\n\n");
+                    "         additionally --device INT (GPU ordinal), --seed-result FILE (GEM map to use instead of seeding), --gem-dir DIR (where gem-mapper lives),\n"
+                    "         --batch INT (reads per GPU batch)\n\n");
     return 1;
 }
 
@@ -37,7 +39,7 @@ int main(int argc, char *argv[])
         {"max-skel",1,0,'s'},{"max-reg",1,0,'R'},{"bwt-kmer",1,0,'k'},{"fastest",0,0,'f'},{"ed-rate",1,0,'e'},{"diff-rate",1,0,'d'},
         {"mis-rate",1,0,'x'},{"read-type",1,0,'T'},{"match-sc",1,0,'m'},{"mis-pen",1,0,'M'},{"open-pen",1,0,'O'},{"ext-pen",1,0,'E'},
         {"band-width",1,0,'w'},{"end-bonus",1,0,'b'},{"max-out",1,0,'r'},{"gap-split",1,0,'g'},{"soft-clip",0,0,'S'},{"comment",0,0,'C'},
-        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"seed-result",1,0,1001},{"batch",1,0,1002},{0,0,0,0}};
+        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"gem-dir",1,0,1003},{"seed-result",1,0,1001},{"batch",1,0,1002},{0,0,0,0}};
     optind = 2;
     while ((c = getopt_long(argc, argv, "t:l:i:p:V:v:s:R:k:fm:M:O:E:w:b:e:d:x:T:r:g:SCo:hHNI", lopt, NULL)) >= 0) {
         switch (c) {
@@ -50,7 +52,7 @@ int main(int argc, char *argv[])
         case 's': P.ske_max = atoi(optarg); break;
         case 'R': P.bwt_max_len = atoi(optarg); break;
         case 'k': P.bwt_seed_len = atoi(optarg); break;
-        case 'f': break;
+        case 'f': opt.fastest = 1; break;
         case 'm': P.match = atoi(optarg); break;
         case 'M': P.mis = atoi(optarg); break;
         case 'O': P.ins_gapo = P.del_gapo = P.ins_ext_o = P.del_ext_o = (int)strtol(optarg, &p, 10);
@@ -65,7 +67,8 @@ int main(int argc, char *argv[])
                   break;
         case 'w': P.band_w = atoi(optarg); break;
         case 'b': P.end_bonus = atoi(optarg); break;
-        case 'e': case 'x': break;                                  // GEM seeding rates: not used on this path
+        case 'e': opt.ed_rate = (float)atof(optarg); break;         // GEM seeding rates (host side only)
+        case 'x': opt.mis_rate = (float)atof(optarg); break;
         case 'd': P.id_rate = (float)atof(optarg); break;
         case 'T': if (!strcmp(optarg, "pacbio")) P.read_type = 1; else if (!strcmp(optarg, "ont2d")) P.read_type = 2;
                   else { fprintf(stderr, "[lamsa_aln] Unkown parameter: %s\n", optarg); return usage(); } break;
@@ -75,8 +78,10 @@ int main(int argc, char *argv[])
         case 'S': opt.supp_soft = 1; break;
         case 'C': opt.comm = 1; break;
         case 'o': out = fopen(optarg, "w"); if (!out) { fprintf(stderr, "[lamsa_aln] Can not open output file: %s.\n", optarg); return 1; } break;
-        case 'N': case 'I': break;
+        case 'N': opt.no_seed_aln = 1; break;
+        case 'I': break;                                            // seed info is recomputed from the read lengths either way
         case 1000: opt.device = atoi(optarg); break;
+        case 1003: opt.gem_dir = optarg; break;
         case 1001: opt.seed_result = optarg; break;
         case 1002: opt.chunk_reads = atoi(optarg) > 0 ? atoi(optarg) : opt.chunk_reads; break;
         default: return usage();
@@ -86,6 +91,12 @@ int main(int argc, char *argv[])
     if (argc - optind != 2) return usage();
     opt.ref_prefix = argv[optind]; opt.reads = argv[optind + 1];
     if (P.bwt_max_len != 0) fprintf(stderr, "[lamsa_aln] note: stage 4 (BWT rescue of uncovered gaps <= -R %d bp) is not part of this build; output equals the reference's with -R 0\n", P.bwt_max_len);
+    if (opt.gem_dir.empty()) {                                       // get_bin_dir, src/lamsa_aln.c: <directory of the executable>/gem
+        std::string self = argv[0];
+        const size_t sl = self.rfind('/');
+        opt.gem_dir = (sl == std::string::npos ? std::string(".") : self.substr(0, sl)) + "/gem";
+    }
+    if (!opt.no_seed_aln && opt.seed_result.empty()) { const int src = lamsa::run_seeding(opt, P); if (src) return src; }
     lamsa::Stats st;
     fprintf(stderr, "[lamsa_aln] Mapping reads to genome ...\n");
     int rc = lamsa::run_aln(opt, P, out, pg, &st);

@@ -21,7 +21,7 @@ def cli():
 @pytest.mark.parametrize("name", G.SCENARIOS)
 def test_sam_identical_to_reference(cli, name, tmp_path):
     ref, reads, args, gold = G.stage_scenario(name, str(tmp_path))
-    p = subprocess.run([cli, "aln", "-R", "0"] + args + [ref, reads], capture_output=True, text=True)
+    p = subprocess.run([cli, "aln", "-N", "-R", "0"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "@PG\tID:lamsa" in p.stdout
     assert G.strip_pg(p.stdout) == G.strip_pg(gold)
@@ -35,7 +35,7 @@ def test_output_file_small_batches_and_gz_reads(cli, tmp_path):
         g.write(f.read())
     shutil.move(reads + ".seed.gem.map", gz + ".seed.gem.map")
     out = str(tmp_path / "out.sam")
-    p = subprocess.run([cli, "aln", "-R", "0", "--batch", "3", "-o", out] + args + [ref, gz], capture_output=True, text=True)
+    p = subprocess.run([cli, "aln", "-N", "-R", "0", "--batch", "3", "-o", out] + args + [ref, gz], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(open(out).read()) == G.strip_pg(gold)
 
@@ -48,5 +48,9 @@ def test_error_paths(cli, tmp_path):
     assert subprocess.run([cli, "aln", "-v", "1.5", ref, reads], capture_output=True).returncode == 1
     assert subprocess.run([cli, "aln", str(tmp_path / "nope.fa"), reads], capture_output=True).returncode != 0
     os.remove(reads + ".seed.gem.map")                                                                 # no seeding results: must say so, not run
-    p = subprocess.run([cli, "aln", ref, reads], capture_output=True, text=True)
+    p = subprocess.run([cli, "aln", "-N", ref, reads], capture_output=True, text=True)
     assert p.returncode != 0 and "gem" in p.stderr.lower()
+    p = subprocess.run([cli, "aln", "--gem-dir", str(tmp_path / "nowhere"), ref, reads], capture_output=True, text=True)    # seeding wanted, no mapper there
+    assert p.returncode != 0 and "gem mapper not found" in p.stderr.lower()
+    seeds = open(reads + ".seed").read().split("\n")                                                     # but the seeds were cut as the reference cuts them
+    assert seeds[0].endswith("_0:0") and len(seeds[1]) == 50 and seeds[2].endswith("_1:100")

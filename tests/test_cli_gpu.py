@@ -16,14 +16,14 @@ pytestmark = pytest.mark.gpu
 def test_sam_identical_to_reference(name, tmp_path):
     assert os.path.exists(BIN), "lamsa_amd/bin/lamsa is not built (python -c 'import __graft_entry__ as g; g.build()')"
     ref, reads, args, gold = G.stage_scenario(name, str(tmp_path))
-    p = subprocess.run([BIN, "aln", "-R", "0"] + args + [ref, reads], capture_output=True, text=True)
+    p = subprocess.run([BIN, "aln", "-N", "-R", "0"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(gold)
 
 
 def test_small_batches(tmp_path):
     ref, reads, args, gold = G.stage_scenario("c2_pacbio", str(tmp_path))
-    p = subprocess.run([BIN, "aln", "-R", "0", "--batch", "4"] + args + [ref, reads], capture_output=True, text=True)
+    p = subprocess.run([BIN, "aln", "-N", "-R", "0", "--batch", "4"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(gold)
 
@@ -46,7 +46,7 @@ def test_end_to_end_files_at_scale(tmp_path):
     want = subprocess.run([os.path.join(ROOT, "oracle", "lamsa_oracle"), "aln", "-T", "ont2d", "-t", "16", "-R", "0", d + "/ref.fa", d + "/reads.fa"],
                           capture_output=True, text=True)
     assert want.returncode == 0, want.stderr[-2000:]
-    got = subprocess.run([BIN, "aln", "-T", "ont2d", "-R", "0", "--batch", "300", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+    got = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "--batch", "300", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
     assert got.returncode == 0, got.stderr[-2000:]
     a, b = G.strip_pg(got.stdout), G.strip_pg(want.stdout)
     assert len(a.splitlines()) >= 1024 + 6

@@ -49,7 +49,7 @@ def main():
         else:
             simdata.write_fasta(rd, reads, width=70)
         want = subprocess.run([LAMSA, "aln"] + args + ["-t", "1", "-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
-        got = subprocess.run([binary, "aln"] + args + ["-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
+        got = subprocess.run([binary, "aln", "-N"] + args + ["-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
         same = G.strip_pg(got) == G.strip_pg(want)
         print("%-8s %s  %d lines" % (name, "identical" if same else "DIFFERENT", len(want.splitlines())))
         if not same:
@@ -57,6 +57,18 @@ def main():
             for a, b in zip(G.strip_pg(got).splitlines(), G.strip_pg(want).splitlines()):
                 if a != b:
                     print("  got : " + a[:400]); print("  want: " + b[:400]); break
+    # the seeding front end itself: our binary cuts the seeds and runs the bundled GEM mapper (container only)
+    gem_dir = os.path.join(os.path.dirname(LAMSA), "gem")
+    if os.path.exists(os.path.join(gem_dir, "gem-mapper")):
+        rd = os.path.join(tmp, "ont.fa")
+        want = subprocess.run([LAMSA, "aln", "-T", "ont2d", "-t", "1", "-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
+        for f in (rd + ".seed", rd + ".seed.gem.map", rd + ".seed.info"):
+            if os.path.exists(f):
+                os.remove(f)
+        got = subprocess.run([binary, "aln", "-T", "ont2d", "-R", "0", "--gem-dir", gem_dir, ref, rd], check=True, capture_output=True, text=True).stdout
+        same = G.strip_pg(got) == G.strip_pg(want)
+        print("%-8s %s  (seeds cut and GEM run by our binary)" % ("seeding", "identical" if same else "DIFFERENT"))
+        bad += 0 if same else 1
     print("tmp:", tmp)
     return 1 if bad else 0
 
