@@ -50,17 +50,32 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
     bool have = false;
 #define HP_BT_PUSH(w_) do { const int v_ = (w_); if (have && (pend & 0xf) == (v_ & 0xf)) pend += (v_ >> 4) << 4; \
         else { if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; } pend = v_; have = true; } } while (0)
+    const int zstride = HP_ZSTRIDE(n_col);
+    // one cell of the matrix as the reference's byte; 255 = never written (outside the window or the band)
+#define HP_BT_CELL(ii, kk, cell_) do { const int off_ = (ii) > w ? (ii) - w : 0; cell_ = 255; \
+        if ((kk) >= off_ && (kk) - off_ < n_col) { \
+            if (lz) { const int c_ = (kk) - off_, nib_ = (lz[(ii) * zstride + (c_ >> 1)] >> ((c_ & 1) << 2)) & 0xf; \
+                      cell_ = nib_ == 0xf ? 255 : ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)); } \
+            else { const int zc_ = gz[(long)(ii) * n_col + ((kk) - off_)]; \
+                   if (grb) { const hp_v2i be_ = grb[(ii)]; cell_ = ((kk) >= be_.x && (kk) < be_.y) ? zc_ : 255; } else cell_ = zc_; } } } while (0)
     while (i >= 0 && k >= 0) {
-        const int off = i > w ? i - w : 0;
-        int cell = 255;
-        if (k >= off && k - off < n_col) {
-            if (lz) {                                                       // 4 bits per cell, rows padded to whole dwords
-                const int c = k - off, nib = (lz[i * HP_ZSTRIDE(n_col) + (c >> 1)] >> ((c & 1) << 2)) & 0xf;
-                cell = nib == 0xf ? 255 : ((nib & 3) | ((nib & 4) ? 1 << 2 : 0) | ((nib & 8) ? 2 << 4 : 0));
-            } else {
-                const int zc = gz[(long)i * n_col + (k - off)];
-                if (grb) { const hp_v2i be = grb[i]; cell = (k >= be.x && k < be.y) ? zc : 255; } else cell = zc;
+        int cell;
+        if (which == 0) {
+            // In state H the walk follows the diagonal for as long as the cells say "came from M": the 64 lanes look at the
+            // next 64 diagonal cells at once and the whole run is pushed in one step.
+            wv::Lane<int> cl, okl;
+            WAVE_FOR(l) {
+                const int ii = i - l, kk = k - l;
+                int c = 255;
+                if (ii >= 0 && kk >= 0) HP_BT_CELL(ii, kk, c);
+                cl[l] = c; okl[l] = ii >= 0 && kk >= 0 && (c & 3) == 0;
             }
+            const unsigned long long mk = wv::ballot(okl);
+            const int run = mk == ~0ull ? 64 : __builtin_ctzll(~mk);
+            if (run > 0) { HP_BT_PUSH(run << 4 | C_M); i -= run; k -= run; continue; }
+            cell = wv::bcast(cl, 0);
+        } else {
+            HP_BT_CELL(i, k, cell);
         }
         which = cell >> (which << 1) & 3;
         if (which == 0) { HP_BT_PUSH(1 << 4 | C_M); --i; --k; }
@@ -71,6 +86,7 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
     if (k >= 0) HP_BT_PUSH((k + 1) << 4 | C_I);
     if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; }
 #undef HP_BT_PUSH
+#undef HP_BT_CELL
     wv::sync();
     for (int b0 = 0; b0 < n / 2; b0 += 64) {                               // _invert_cigar, lane-parallel
         WAVE_FOR(l) { const int a = b0 + l; if (a < n / 2) { const cig_t x = oc[a], y = oc[n - 1 - a]; oc[a] = y; oc[n - 1 - a] = x; } }
