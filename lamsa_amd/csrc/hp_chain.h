@@ -794,6 +794,36 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
     *rlo = lo; *rhi = hi;
 }
 
+// The driver loop of branch tracking (:1356-1361, :961-966): seeds from last to first, hits of a seed in ascending
+// order, every hit that is (still) a leaf of the pass starts a track.  The leaf test of a seed's hits is done by the
+// lanes when the seed is reached: tracking a hit only changes hits of earlier seeds (its ancestors) and sons whose own
+// tracks are complete, never another hit of the same seed that has not been visited yet.
+HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_flag, NScore &ns)
+{
+    const HP_G NodeS *ns_ = (const HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_in_de = (const HP_G int32_t *)r.n_in_de;
+    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+    const int64_t hb = r.hb;
+    for (int i0 = last_slot; i0 >= first_slot; i0 -= 63) {
+        // hit offsets of up to 63 seeds (i0-62 .. i0) and the end of the last one, one per lane
+        wv::Lane<int> ho;
+        WAVE_FOR(l) { const int x = i0 - 62 + l; ho[l] = (x >= 0 && x <= r.seed_out) ? (int)(g_hoff[x] - hb) : 0; }
+        for (int i = i0; i >= first_slot && i > i0 - 63; --i) {
+            const int h0 = wv::bcast(ho, i - (i0 - 62)), h1 = wv::bcast(ho, i + 1 - (i0 - 62));
+            for (int b = h0; b < h1; b += 64) {
+                wv::Lane<int> leaf;
+                WAVE_FOR(l) {
+                    const int k = b + l;
+                    int v = 0;
+                    if (k < h1) { int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0; }
+                    leaf[l] = v;
+                }
+                for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) branch_track(r, b + __builtin_ctzll(m), ns);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- frag_mini_dp_line with the whole pass in registers
 // Most mini-DP passes involve few hits: either the seed range between the two anchors is short, or (pass from START)
 // only the hits that can reach the right anchor matter (reach_run).  Up to HP_MS_SETS x 64 such hits are loaded once,
@@ -1481,9 +1511,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     NScore ns;
     if (!ns_alloc(r.cx, ns, H + 1, 0)) return false;
     ns.min_score_thd = 2;
-    for (int i = seed_out - 1; i >= 0; --i)                                                       // :1356-1361
-        for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
-            if (r.nd[k].dp_flag == MIN_FLAG && r.n_in_de[k] == 0) branch_track(r, k, ns);
+    track_leaves(r, 0, seed_out - 1, MIN_FLAG, ns);                                                 // :1356-1361
 
     HP_CSTAMP(8);
     const int o_l = ns.node_n;
@@ -1572,9 +1600,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
     NScore ns;
     if (!ns_alloc(r.cx, ns, hoff(r, end + 1) - hoff(r, start) + 1, 0)) return 0;
     ns.min_score_thd = 0;
-    for (int i = end; i >= start; --i)
-        for (int k = hoff(r, i), e = hoff(r, i + 1); k < e; ++k)
-            if (r.nd[k].dp_flag == dp_flag && r.n_in_de[k] == 0) branch_track(r, k, ns);
+    track_leaves(r, start, end, dp_flag, ns);
     int l_i = 0, next_start = 0, score = 0, NM = 0;
     for (;;) {
         int rr = ns_pop(ns, &score, &NM);
