@@ -1482,7 +1482,15 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     const int seed_out = r.seed_out, H = r.H;
     F.n = 0; F.nfrag = 0;
     int min_n = P->first_loci_thd, min_exist = 0, min_num = 0;
-    for (int i = 0; i < seed_out; ++i) if (mapn(r, i) <= min_n) { min_exist = 1; ++min_num; }    // :1315-1323
+    {                                                                                             // :1315-1323, 64 seeds per step
+        const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+        for (int i0 = 0; i0 < seed_out; i0 += 64) {
+            wv::Lane<int> few;
+            WAVE_FOR(l) { const int i = i0 + l; few[l] = i < seed_out && (int)(g_hoff[i + 1] - g_hoff[i]) <= min_n; }
+            min_num += __builtin_popcountll(wv::ballot(few));
+        }
+        min_exist = min_num > 0;
+    }
     const bool all_min = (!min_exist || min_num * 3 < seed_out);                                 // :1324-1331
 #ifdef HP_PROF
     long long tq_ = wv::clock(); if (r.prof) r.prof[56] += tq_ - tc_;
