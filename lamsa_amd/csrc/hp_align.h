@@ -146,15 +146,20 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
         r.n_from = nm; r.n_in_de = nm + c; r.n_son_n = nm + 2 * c; r.n_first = nm + 3 * c;
         r.n_last = nm + 4 * c; r.n_next = nm + 5 * c; r.n_max_score = nm + 6 * c; r.n_max_NM = nm + 7 * c; r.n_max_node = nm + 8 * c;
         r.n_node_n = nm + 9 * c; r.n_seed = nm + 10 * c;
-        for (int s = 0; s < r.seed_out; ++s) {                  // slot of every hit
-            const int b = hoff(r, s), e = hoff(r, s + 1);
-            const int sidv = r.seed_id[s];
-            for (int k0 = b; k0 < e; k0 += 64) {
+        {   // one hit per lane: its seed slot by binary search in the read's hit offsets (a few hundred entries,
+            // cache-resident), then the packed 32-byte record
+            const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+            const HP_G int32_t *g_sid = (const HP_G int32_t *)r.seed_id;
+            const int64_t hb = r.hb;
+            for (int k0 = 0; k0 < H; k0 += 64) {
                 WAVE_FOR(l) {
                     const int k = k0 + l;
-                    if (k < e) {
+                    if (k < H) {
+                        int lo = 0, hi = r.seed_out;                 // largest slot s with hit_off[s] - hb <= k
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)(g_hoff[mid] - hb) <= k) lo = mid; else hi = mid; }
+                        const int s = lo, b = (int)(g_hoff[s] - hb);
                         r.n_seed[k] = s;
-                        NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)sidv;
+                        NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)g_sid[s];
                         q.strand = r.h_strand[k]; q.len_dif8 = (int8_t)r.h_len_dif[k]; q.pad_ = 0;
                         q.dp_flag = 0; q.son_flag = F_INIT; q.match_flag = 0; q.score = 0; q.NM = 0;
                         r.nd[k] = q;
