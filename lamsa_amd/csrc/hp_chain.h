@@ -1422,40 +1422,67 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
     F.line_score = m; F.left_bound = m + (line_n + 1); F.right_bound = m + 2 * (line_n + 1); F.frag_off = m + 3 * (line_n + 1);
     F.fr_seed_off = m + 4 * (line_n + 1); F.fr_seed = F.fr_seed_off + (tot + 2);
     const lamsa_hp_para *P = r.cx.P;
+    // Both passes below walk a line node by node with a decision that depends on the previous one, so they stay
+    // sequential; what they read about a node is fetched 64 nodes at a time by the lanes and handed out by readlane.
+    const HP_G NodeS *gns = (const HP_G NodeS *)r.nd;
     if (P->aln_mode & 1) {                              // line_filter_overlap, :568-594
         for (int _i = 0; _i < line_n; ++_i) {
             const int li = L.rank[_i];
             int32_t *ni = L.pool + L.start[li]; const int ll = L.len[li];
-            int last_i = 0;
-            for (int j = 1; j < ll - 1; ++j) {
-                const int c = ni[j], p = ni[last_i];
-                const int st = r.h_strand[c];
-                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.nd[c].match_flag != F_INSERT) ni[j] = -1;
-                else last_i = j;
+            HP_G int32_t *gni = (HP_G int32_t *)ni;
+            int last_i = 0, st_p = 0, ld_p = 0; long long pos_p = 0;
+            for (int j0 = 0; j0 < ll; j0 += 64) {
+                wv::Lane<int> plo, phi, ldl, stl, mfl;
+                WAVE_FOR(l) {
+                    const int j = j0 + l;
+                    int a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+                    if (j < ll) { const int c = gni[j]; hp_load16(gns + c, a); hp_load16((const HP_G char *)(gns + c) + 16, b); }
+                    plo[l] = a[0]; phi[l] = a[1]; stl[l] = (int)(int8_t)((b[0] >> 16) & 0xff); ldl[l] = (int)(int8_t)((b[0] >> 24) & 0xff); mfl[l] = (b[1] >> 16) & 0xff;
+                }
+                const int cnt = ll - j0 < 64 ? ll - j0 : 64;
+                for (int q = 0; q < cnt; ++q) {
+                    const int j = j0 + q;
+                    const long long pos_c = (long long)(((unsigned long long)(unsigned)wv::bcast(phi, q) << 32) | (unsigned)wv::bcast(plo, q));
+                    const int st = wv::bcast(stl, q), ld_c = wv::bcast(ldl, q), mf_c = wv::bcast(mfl, q);
+                    if (j == 0) { pos_p = pos_c; ld_p = ld_c; st_p = st; continue; }
+                    const bool ovl = (long long)(P->seed_len + (st == 1 ? ld_p : ld_c)) > (long long)st * (pos_c - pos_p) && mf_c != F_INSERT;
+                    if (j < ll - 1) {
+                        if (ovl) gni[j] = -1; else { last_i = j; pos_p = pos_c; ld_p = ld_c; st_p = st; }
+                    } else if (ll - 1 != last_i && ovl) gni[last_i] = -1;             // the last node stays, the one before it goes (:586-592)
+                }
             }
-            if (ll - 1 != last_i) {
-                const int c = ni[ll - 1], p = ni[last_i];
-                const int st = r.h_strand[c];
-                if (P->seed_len + (st == 1 ? r.h_len_dif[p] : r.h_len_dif[c]) > st * (r.h_pos[c] - r.h_pos[p]) && r.nd[c].match_flag != F_INSERT) ni[last_i] = -1;
-            }
+            (void)st_p;
         }
+        wv::sync();
     }
     int nf = 0, ns = 0;
     for (int _l = 0; _l < line_n; ++_l) {
         const int li = L.rank[_l];
         const int32_t *ln = L.pool + L.start[li]; const int ll = L.len[li];
+        const HP_G int32_t *gln = (const HP_G int32_t *)ln;
         F.frag_off[_l] = nf;
-        int pre = ln[ll - 1], cur;
-        F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre;              // FRAG_END: a new fragment opens with its last seed
         F.right_bound[_l] = r.seed_all + 1;
-        for (int i = ll - 1; i > 0; --i) {
-            cur = pre;
-            if (ln[i - 1] < 0) continue;
-            pre = ln[i - 1];
-            const int mf = r.nd[cur].match_flag;
-            if (mf == F_INSERT || mf == F_DELETE || mf == F_MISMATCH || mf == F_LONG_MISMATCH) { ++nf; F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre; }
-            else if (mf == F_MATCH) F.fr_seed[ns++] = pre;
-            else { r.cx.status |= ST_REFEXIT; return false; }          // "[frag dp path] Error: Unknown flag", :1223
+        int pre = -1, mf_pre = 0;
+        // nodes from the last one backwards; lane q of a block holds node j1 - q
+        for (int j1 = ll - 1; j1 >= 0; j1 -= 64) {
+            wv::Lane<int> idl, mfl;
+            WAVE_FOR(l) {
+                const int j = j1 - l;
+                int id = -1, mf = 0;
+                if (j >= 0) { id = gln[j]; if (id >= 0) { int b[4]; hp_load16((const HP_G char *)(gns + id) + 16, b); mf = (b[1] >> 16) & 0xff; } }
+                idl[l] = id; mfl[l] = mf;
+            }
+            const int cnt = j1 + 1 < 64 ? j1 + 1 : 64;
+            for (int q = 0; q < cnt; ++q) {
+                const int id = wv::bcast(idl, q);
+                if (j1 - q == ll - 1) { pre = id; mf_pre = wv::bcast(mfl, q); F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre; continue; }   // FRAG_END: a new fragment opens with its last seed
+                if (id < 0) continue;                                      // dropped by the overlap filter
+                const int mf = mf_pre;                                     // edge class of the node after this one (`cur`)
+                pre = id; mf_pre = wv::bcast(mfl, q);
+                if (mf == F_INSERT || mf == F_DELETE || mf == F_MISMATCH || mf == F_LONG_MISMATCH) { ++nf; F.fr_seed_off[nf] = ns; F.fr_seed[ns++] = pre; }
+                else if (mf == F_MATCH) F.fr_seed[ns++] = pre;
+                else { r.cx.status |= ST_REFEXIT; return false; }          // "[frag dp path] Error: Unknown flag", :1223
+            }
         }
         ++nf;
         F.left_bound[_l] = 0;
