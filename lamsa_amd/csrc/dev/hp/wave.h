@@ -115,6 +115,9 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     x.v = dpp<0x138>(ident, v);                        // shift the inclusive scan right by one lane
 }
 
+// every lane receives the value of the lane below it; lane 0 receives `fill`
+HP_INL void shr1(Lane<int> &x, int fill) { x.v = dpp<0x138>(fill, x.v); }
+
 // exclusive prefix sum over lanes (lane 0 receives 0)
 HP_INL void scan_add_excl(Lane<int> &x) {
     int v = x.v;

@@ -451,10 +451,225 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 24, tg0_);
+    return score;
+}
+
+// =====================================================================================================
+// Register-resident rows for short queries (at most 62 bases: most junction jobs).  Column index j of the reference's
+// eh[] array lives in lane j: eh[j].h and eh[j].e are two registers, the query base of column j a third.  A row
+// reads its own lane (eh[j].h holds H(i-1,j-1)), the new H values move one lane up with a DPP shift, and lanes outside
+// [beg, end] simply keep their registers -- the reference's stale cells.  Only the direction matrix touches memory.
+// =====================================================================================================
+#define HP_REG_QMAX 62
+
+HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
+                            int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
+{
+    HP_T0(tg0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);
+    o_del = wv::uni(o_del); e_del = wv::uni(e_del); o_ins = wv::uni(o_ins); e_ins = wv::uni(e_ins);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
+    const size_t mark = arena_mark(cx.tmp);
+    const bool zl = HP_ZFITS(n_col, tlen);
+    uint8_t *z = (out && !zl) ? (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1) : nullptr;
+    if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
+    HP_L uint8_t *LZ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS) + HP_LDS_CELLS;
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    const int sc_match = wv::uni(cx.P->match), sc_mis = -wv::uni(cx.P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    wv::Lane<int> Hs, Es, qb, tl;
+    WAVE_FOR(l) {
+        Hs[l] = l == 0 ? 0 : (l <= w ? -(o_ins + e_ins * l) : HP_NEG_INF);             // first row, :569-572
+        Es[l] = HP_NEG_INF;
+        qb[l] = l < qlen ? (int)gq[(long)l * qs] : 4;
+        tl[l] = 4;
+    }
+    for (int ib = 0; ib < tlen; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            const int beg = i > w ? i - w : 0;
+            const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+            if (out && zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
+            const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
+            wv::Lane<int> m, key, hcur;
+            WAVE_FOR(l) {
+                m[l] = Hs[l] + HP_SUB(ti, qb[l]);
+                key[l] = (l >= beg && l < end) ? m[l] - oe_ins + l * e_ins : HP_SCAN_IDENT;
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            WAVE_FOR(l) {
+                hcur[l] = 0;
+                if (l >= beg && l < end) {
+                    int f = HP_NEG_INF - (l - beg) * e_ins;                // F(i,beg) = -inf carried along the row
+                    if (l > beg) { const int g = key[l] - (l - 1) * e_ins; f = g > f ? g : f; }
+                    int mm = m[l], ee = Es[l], h, tt;
+                    int dir = mm >= ee ? 0 : 1; h = mm >= ee ? mm : ee;    // ties: M over E   :598-599
+                    dir = h >= f ? dir : 2;     h = h >= f ? h : f;        //       then over F :600-601
+                    tt = mm - oe_del; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;              // :603-607
+                    tt = mm - oe_ins; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4;                             // :608-611 (f itself is not needed again: the scan redoes it)
+                    Es[l] = ee;
+                    hcur[l] = h;
+                    if (out) { if (zl) z_put(LZ, i, n_col, l - beg, dir); else gz[(long)i * n_col + (l - beg)] = (uint8_t)dir; }
+                }
+            }
+            wv::shr1(hcur, 0);                                             // eh[j+1].h = H(i,j)
+            WAVE_FOR(l) {
+                if (l == beg) Hs[l] = h1_init; else if (l > beg && l <= end) Hs[l] = hcur[l];
+                if (l == end) Es[l] = HP_NEG_INF;                          // :632
+            }
+        }
+    }
+    const int score = wv::bcast(Hs, qlen);
+    if (out) {
+        const int i = tlen - 1;
+        const int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;           // :638
+        wv::sync();
+        HP_T0(tb0_);
+        dp_backtrack(cx, zl ? LZ : nullptr, z, nullptr, n_col, w, i, k, *out);
+        HP_TADD(cx, 28, tb0_);
+    }
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 24, tg0_);
 #ifdef HP_PROF
-    if (qlen <= 62) HP_TADD(cx, 62, tg0_);
+    HP_TADD(cx, 62, tg0_);
 #endif
     return score;
+}
+
+HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
+{
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
+    HP_T0(te0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
+    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const size_t mark = arena_mark(cx.tmp);
+    const bool zl = HP_ZFITS(n_col, tlen);
+    uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
+    int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
+    HP_L uint8_t *LZ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS) + HP_LDS_CELLS;
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
+    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+    wv::Lane<int> Hs, Es, qb, tl;
+    WAVE_FOR(l) {                                                          // first row, :692-694
+        Hs[l] = l == 0 ? h0 : (l == 1 ? h1v : ((l <= qlen && h1v - (l - 2) * e_ins > e_ins) ? h1v - (l - 1) * e_ins : 0));
+        Es[l] = 0;
+        qb[l] = l < qlen ? (int)gq[(long)l * qs] : 4;
+        tl[l] = 4;
+    }
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            const int d_beg = i > w ? i - w : 0;
+            if (beg < i - w) beg = i - w;                                  // :718-720
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
+            else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
+            int h1_init;
+            if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+            else h1_init = 0;
+            wv::Lane<int> m, key, hcur;
+            WAVE_FOR(l) {
+                const int hm = Hs[l];
+                const int M = hm ? hm + HP_SUB(ti, qb[l]) : 0;             // :737
+                int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+                m[l] = M;
+                key[l] = (l >= beg && l < end) ? tt + l * e_ins : HP_SCAN_IDENT;
+            }
+            wv::scan_max_excl(key, HP_SCAN_IDENT);
+            WAVE_FOR(l) {
+                hcur[l] = -1;
+                if (l >= beg && l < end) {
+                    int f = 0 - (l - beg) * e_ins;                         // F(i,beg) = 0 carried along the row
+                    if (l > beg) { const int g = key[l] - (l - 1) * e_ins; f = g > f ? g : f; }
+                    int M = m[l], ee = Es[l], h, tt;
+                    int dir = M > ee ? 0 : 1; h = M > ee ? M : ee;          // ties: E over M   :738-739
+                    dir = h > f ? dir : 2;    h = h > f ? h : f;            //       F over both :740-741
+                    tt = M - oe_del; tt = tt > 0 ? tt : 0; ee -= e_del;
+                    if (ee > tt) dir |= 1 << 2; else ee = tt;               // :745-750
+                    tt = M - oe_ins; tt = tt > 0 ? tt : 0; f -= e_ins;
+                    if (f > tt) dir |= 2 << 4;                              // :751-755
+                    Es[l] = ee;
+                    hcur[l] = h;
+                    if (zl) z_put(LZ, i, n_col, l - d_beg, dir); else gz[(long)i * n_col + (l - d_beg)] = (uint8_t)dir;
+                }
+            }
+            // row maximum, last j among equals (:743-744)
+            int mrow = 0, mj = -1;
+            {
+                const int hmax = wv::reduce_max(hcur);
+                if (hmax >= 0) {
+                    wv::Lane<int> eq;
+                    WAVE_FOR(l) eq[l] = hcur[l] == hmax;
+                    mrow = hmax; mj = 63 - __builtin_clzll(wv::ballot(eq));
+                }
+            }
+            const int h_last = beg < end ? wv::bcast(hcur, end - 1) : h1_init;   // H(i,end-1), or the first-column value when the row is empty
+            WAVE_FOR(l) { if (hcur[l] < 0) hcur[l] = 0; }
+            wv::shr1(hcur, 0);                                             // eh[j+1].h = H(i,j)
+            wv::Lane<int> nz;
+            WAVE_FOR(l) {
+                if (beg < end) { if (l == beg) Hs[l] = h1_init; else if (l > beg && l <= end) Hs[l] = hcur[l]; }
+                else if (l == end) Hs[l] = h1_init;                        // eh[end].h = h1 when the row is empty (:758)
+                if (l == end) Es[l] = 0;                                   // :758
+                nz[l] = l >= beg && l <= end && (Hs[l] != 0 || Es[l] != 0);
+            }
+            const int jj = beg < end ? end : beg;                          // loop variable j after the row
+            if (jj == qlen) {                                              // :759-762
+                max_ie = gscore > h_last ? max_ie : i;
+                gscore = gscore > h_last ? gscore : h_last;
+            }
+            if (mrow == 0) { stop_rows = true; break; }                    // :763
+            if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+            else if (zdrop > 0) {                                          // :767-773
+                if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
+                else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
+            }
+            // shrink the band for the next row, :775-778
+            {
+                const unsigned long long nzm = wv::ballot(nz);
+                const unsigned long long lowm = nzm & (end < 64 ? ((1ull << end) - 1) : ~0ull);      // non-zero indices in [beg, end)
+                const int nb = lowm ? __builtin_ctzll(lowm) : end;
+                const unsigned long long upm = nzm & ~((1ull << nb) - 1);                             // non-zero indices in [nb, end]
+                const int jl = upm ? 63 - __builtin_clzll(upm) : nb - 1;
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+            }
+        }
+    }
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
+#ifdef HP_PROF
+    HP_TADD(cx, 60, te0_);
+#endif
+    return er;
 }
 
 // ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
@@ -464,6 +679,7 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     if (out) out->n = 0;
     if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
     { const int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }             // :549
+    if (qlen <= HP_REG_QMAX) return ksw_global_reg(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
     if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_global_lds(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
     return ksw_global_wide(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
 }
@@ -631,9 +847,6 @@ HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
-#ifdef HP_PROF
-    if (qlen <= 62) HP_TADD(cx, 60, te0_);
-#endif
     return er;
 }
 
@@ -655,7 +868,8 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }
-    const ExtRes er = 2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out);
+    const ExtRes er = qlen <= HP_REG_QMAX ? ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out)
+                    : (2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out));
     if (qle) *qle = er.qle;
     if (tle) *tle = er.tle;
     return er.score;

@@ -57,6 +57,7 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     }
 }
 
+HP_INL void shr1(Lane<int> &x, int fill) { for (int l = 63; l > 0; --l) x.v[l] = x.v[l - 1]; x.v[0] = fill; }
 HP_INL void scan_add_excl(Lane<int> &x) {
     int run = 0;
     for (int l = 0; l < 64; ++l) { const int cur = x.v[l]; x.v[l] = run; run += cur; }
