@@ -155,6 +155,25 @@ int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_
 int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch);
 int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
 
+/* The streaming form, for the chunk loop of lamsa_aln_core (src/lamsa_aln.c:1140-1170): the reference overlaps nothing
+ * (read chunk -> threads -> join -> print); here up to two chunks are in flight per handle.
+ *   submit   validates the batch, copies it to the device on the copy stream -- while the kernel of the previously
+ *            submitted batch is still running -- and queues its kernel behind that one.  It returns when the copy is
+ *            done (the caller's arrays may be reused) without waiting for any kernel.  LAMSA_HP_EINVAL when two
+ *            batches are already in flight.
+ *   collect  waits for the OLDEST submitted batch, runs its second pass if a read needs one and fetches the results
+ *            (callee-owned, valid until the next collect / run on this handle).  lamsa_hp_last_kernel_ms() then
+ *            refers to that batch.  LAMSA_HP_EINVAL when nothing is in flight.
+ * Loop of a streaming caller:  submit(B0); for i = 1..: prepare B_i; submit(B_i); collect(R_{i-1}); write R_{i-1}.
+ * lamsa_hp_upload_batch / run_uploaded / align_batch must not be called while a submitted batch is in flight. */
+int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch);
+int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res);
+
+/* Page-locked host memory for the arrays of a lamsa_hp_batch: copies from it run at the full PCIe rate and need no
+ * staging pass through the runtime's bounce buffers.  Optional -- ordinary memory works everywhere. */
+void *lamsa_hp_host_alloc(size_t bytes);
+void  lamsa_hp_host_free(void *p);
+
 /* Wall time in milliseconds of the kernel(s) of the most recent call on this handle,
  * measured with HIP events on the stream the kernels ran on; n-th kernel of that call. */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);

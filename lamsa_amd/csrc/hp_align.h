@@ -3,6 +3,7 @@
 // worker lamsa_main_aln (src/lamsa_aln.c:857-871), minus stage (4)/(5)/(6) which stay on the host.
 #pragma once
 #include "hp_fill.h"
+#include "hp_sort.h"
 
 namespace hp {
 
@@ -121,7 +122,6 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     r.hb = r.hit_off[0];
     r.H = (int)(r.hit_off[r.seed_out] - r.hb);
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
-    r.srt = in.h_sort + r.hb; r.rnk = in.h_rank + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
     r.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
@@ -133,6 +133,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     o.w = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)out_cap);
     r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
     int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 11 * (size_t)(H + 1));
+    int32_t *sidx = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)(H + 1));       // the sort index of the hits (hp_sort.h)
     r.nd = (NodeS *)arena_alloc(cx, sizeof(NodeS) * (size_t)(H + 1));
     const int reg_cap = 256 * a.scale;
     Regs G; G.n = 0; G.m = 0;
@@ -141,8 +142,15 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     G.r_beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 6 * (size_t)(reg_cap + 2));
     G.r_end = G.r_beg + (reg_cap + 2); G.r_bs = G.r_end + (reg_cap + 2); G.r_bn = G.r_bs + (reg_cap + 2); G.r_es = G.r_bn + (reg_cap + 2); G.r_en = G.r_es + (reg_cap + 2);
     int n0_pos = 1, n1_pos = 2;
-    if (o.w && r.rc_read && nm && r.nd && G.beg && G.rb && G.r_beg) {
+    const size_t sort_mark = arena_mark(cx.tmp);
+    uint64_t *sort_work = (uint64_t *)arena_alloc(cx, sizeof(uint64_t) * (size_t)(H + 1));      // released once the index is built
+    if (o.w && r.rc_read && nm && sidx && sort_work && r.nd && G.beg && G.rb && G.r_beg) {
         const int c = H + 1;
+        { HP_T0(t_sort_);
+        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
+        HP_TADD(cx, 46, t_sort_); }
+        arena_release(cx.tmp, sort_mark);
+        r.srt = sidx; r.rnk = sidx + c;
         r.n_from = nm; r.n_in_de = nm + c; r.n_son_n = nm + 2 * c; r.n_first = nm + 3 * c;
         r.n_last = nm + 4 * c; r.n_next = nm + 5 * c; r.n_max_score = nm + 6 * c; r.n_max_NM = nm + 7 * c; r.n_max_node = nm + 8 * c;
         r.n_node_n = nm + 9 * c; r.n_seed = nm + 10 * c;

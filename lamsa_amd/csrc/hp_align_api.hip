@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <stdlib.h>
+#include <time.h>
 #include "hp_align.h"
 #include "hp_handle.h"
 #include "hp_hostprep.h"
@@ -40,17 +42,38 @@ struct OutDev {                   // result arrays of one launch: per-read offse
     int32_t *stream(int n) const { return (int32_t *)((char *)buf.p + hdr(n)); }
 };
 
-struct AlignState {
-    DevBuf bin, slab, misc, retry_list;
-    OutDev out1, out2;
-    // the resident batch
-    bool valid = false;
+struct HostBuf {                  // page-locked host memory for the result stream: device-to-host copies at the PCIe rate
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
+    DevBuf bin, misc; OutDev out1;
+    bool valid = false;           // a batch is resident
     int32_t n_reads = 0; int64_t n_bases = 0, n_cig = 0;
     BatchIn in; const int32_t *d_order = nullptr;
     std::vector<int32_t> order, h_len, h_H;
     int32_t max_L = 0, max_H = 0;
+    int32_t sort_pb = 40, sort_cb = 24;        // key field widths for the in-kernel sort of the hits (hp_sort.h)
+    hipEvent_t e0 = nullptr, e1 = nullptr;     // around the main-pass kernel, on the compute stream
+};
+
+struct AlignState {
+    Slot slot[2];                 // two batches: one computing, one being uploaded (lamsa_hp_submit_batch)
+    int fifo[2] = {0, 0}, n_fifo = 0;          // submitted and not yet collected, oldest first
+    DevBuf slab, retry_list;      // shared by all launches: they are ordered on the one compute stream
+    OutDev out2;
     // host copies of the results
-    std::vector<int32_t> stream, r_len, r_st, r_tb; std::vector<int64_t> r_off;
+    HostBuf stream; std::vector<int32_t> r_len, r_st, r_tb; std::vector<int64_t> r_off;
 };
 
 static std::map<lamsa_hp_handle *, AlignState *> g_states;     // per-handle state of the align entry points
@@ -65,26 +88,37 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     auto it = g_states.find(h);
     if (it == g_states.end()) return;
     AlignState *S = it->second;
-    S->bin.release(); S->slab.release(); S->misc.release(); S->retry_list.release(); S->out1.buf.release(); S->out2.buf.release();
+    if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.out1.buf.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
+    S->slab.release(); S->retry_list.release(); S->out2.buf.release(); S->stream.release();
     delete S;
     g_states.erase(it);
 }
 
+// grow a device buffer that a queued kernel may still be using: drain the compute stream first
+static int grow(lamsa_hp_handle *h, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return b.ensure(bytes);
+}
+
 static size_t slab_bytes_for(const lamsa_hp_para &P, int L, int H, int scale)
-{   // per-wave scratch: node arrays + line sets (~400 B/hit), result + CIGAR buffers (~128 B/base), and the
+{   // per-wave scratch: node arrays, sort index + line sets (~424 B/hit), result + CIGAR buffers (~128 B/base), and the
     // direction matrix of the largest extension: (2w+1) columns x (L + 2*hash_step) rows.  Reads that need more
     // flag LAMSA_HP_ST_OVERFLOW and are re-run by the retry pass with `scale` = 8.
     const size_t z = (2 * (size_t)P.band_w + 128) * ((size_t)L + 256);
-    return al256(((size_t)256 << 10) + (size_t)scale * 128 * (size_t)L + 400 * (size_t)H + z * (size_t)(scale > 1 ? 4 : 1));
+    return al256(((size_t)256 << 10) + (size_t)scale * 128 * (size_t)L + 424 * (size_t)H + z * (size_t)(scale > 1 ? 4 : 1));
 }
 
-extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B)
+// validate `B`, build its processing order and sort index, copy it into slot `T` on the copy stream
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
+
+static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 {
-    if (!h || !B || B->n_reads < 0) return LAMSA_HP_EINVAL;
-    if (!h->d_pac) { h->err = "handle was created without a reference"; return LAMSA_HP_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
-    AlignState *S = state_of(h);
     S->valid = false;
+    const double t_0 = now_s();
     const int n = B->n_reads;
     const int64_t n_slots = n ? B->seed_off[n] : 0, n_hits = n_slots ? B->hit_off[n_slots] : 0, n_bases = n ? B->read_off[n] : 0;
     // ---- validate everything the kernels index with, on the host, before anything is launched
@@ -92,7 +126,9 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
     {
         std::atomic<int> bad(0);                         // 1..6: which check failed (the first one reported wins)
+        std::atomic<long long> max_pos(0);
         hp_parallel_blocks(n, [&](int r0, int r1) {
+            long long mp = 0;
             for (int r = r0; r < r1 && !bad.load(std::memory_order_relaxed); ++r) {
                 const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
                 if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { bad = 1; return; }
@@ -105,17 +141,24 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
                 }
                 if (H > (1 << 22)) { bad = 4; return; }
                 for (int64_t i = B->read_off[r]; i < B->read_off[r + 1]; ++i) if (B->read_seq[i] > 4) { bad = 5; return; }
-                for (int64_t k = B->hit_off[B->seed_off[r]]; k < B->hit_off[B->seed_off[r + 1]]; ++k)
-                    if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) ||
+                for (int64_t k = B->hit_off[B->seed_off[r]]; k < B->hit_off[B->seed_off[r + 1]]; ++k) {
+                    mp = B->h_pos[k] > mp ? B->h_pos[k] : mp;
+                    if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) || B->h_pos[k] < 0 || B->h_pos[k] >= (1ll << 40) ||
                         B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig) { bad = 6; return; }
+                }
                 S->h_len[r] = (int32_t)L; S->h_H[r] = (int32_t)H;
             }
+            long long seen = max_pos.load();
+            while (mp > seen && !max_pos.compare_exchange_weak(seen, mp)) { }
         });
         static const char *why[] = {"", "read too long / too many seeds", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
                                     "too many hits in one read", "read base code > 4", "bad hit record"};
         if (bad) { h->err = why[bad.load()]; return LAMSA_HP_EINVAL; }
         for (int r = 0; r < n; ++r) { S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
+        auto bits = [](unsigned long long x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
+        S->sort_pb = bits((unsigned long long)max_pos.load()); S->sort_cb = bits((unsigned long long)(2 * (long long)h->n_seqs + 1));
     }
+    const double t_1 = now_s();
     // ---- processing order: costliest first (chaining ~ H^2/64 lane steps, extension ~ L * band)
     S->order.resize((size_t)n);
     for (int r = 0; r < n; ++r) S->order[r] = r;
@@ -130,13 +173,11 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     const size_t o_roff = place(8 * ((size_t)n + 1)), o_rseq = place((size_t)n_bases), o_sall = place(4 * (size_t)n), o_last = place(4 * (size_t)n),
                  o_soff = place(8 * ((size_t)n + 1)), o_sid = place(4 * (size_t)n_slots), o_hoff = place(8 * ((size_t)n_slots + 1)),
                  o_pos = place(8 * (size_t)n_hits), o_chr = place(4 * (size_t)n_hits), o_coff = place(4 * (size_t)n_hits), o_nm = place(2 * (size_t)n_hits),
-                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n),
-                 o_srt = place(4 * (size_t)n_hits), o_rnk = place(4 * (size_t)n_hits);
-    std::vector<int32_t> srt, rnk;
-    hp_build_sort_index(n, B->seed_off, B->hit_off, B->h_pos, B->h_chr, B->h_strand, srt, rnk);
+                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n);
+    const double t_3 = now_s();
     if (S->bin.ensure(off)) { h->err = "hipMalloc(batch)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)S->bin.p;
-    hipStream_t s = h->stream;
+    hipStream_t s = h->copy_stream;
     static const int64_t zero64 = 0;
 #define UP(o, src, bytes) do { if ((bytes) > 0) HIPCHK(h, hipMemcpyAsync(d + (o), (src), (bytes), hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL); } while (0)
     if (n) { UP(o_roff, B->read_off, 8 * ((size_t)n + 1)); UP(o_soff, B->seed_off, 8 * ((size_t)n + 1)); }
@@ -147,9 +188,9 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     UP(o_pos, B->h_pos, 8 * (size_t)n_hits); UP(o_chr, B->h_chr, 4 * (size_t)n_hits); UP(o_coff, B->h_cig_off, 4 * (size_t)n_hits);
     UP(o_nm, B->h_nm, 2 * (size_t)n_hits); UP(o_ld, B->h_len_dif, 2 * (size_t)n_hits); UP(o_st, B->h_strand, (size_t)n_hits); UP(o_cn, B->h_cig_n, (size_t)n_hits);
     UP(o_cig, B->cig, 4 * (size_t)B->n_cig); UP(o_ord, S->order.data(), 4 * (size_t)n);
-    UP(o_srt, srt.data(), 4 * (size_t)n_hits); UP(o_rnk, rnk.data(), 4 * (size_t)n_hits);
 #undef UP
     HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
+    if (g_trace) fprintf(stderr, "[lamsa_hp] upload: validate %.1f ms, order %.1f ms, copy %.1f ms (%.2f GB on the device)\n", 1e3 * (t_1 - t_0), 1e3 * (t_3 - t_1), 1e3 * (now_s() - t_3), off / 1e9);
     BatchIn &in = S->in;
     in.n_reads = n; in.read_off = (const int64_t *)(d + o_roff); in.read_seq = (const uint8_t *)(d + o_rseq);
     in.seed_all = (const int32_t *)(d + o_sall); in.last_len = (const int32_t *)(d + o_last); in.seed_off = (const int64_t *)(d + o_soff);
@@ -157,15 +198,16 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     in.h_chr = (const int32_t *)(d + o_chr); in.h_cig_off = (const int32_t *)(d + o_coff); in.h_nm = (const int16_t *)(d + o_nm);
     in.h_len_dif = (const int16_t *)(d + o_ld); in.h_strand = (const int8_t *)(d + o_st); in.h_cig_n = (const uint8_t *)(d + o_cn);
     in.cig = (const int32_t *)(d + o_cig);
-    in.h_sort = (const int32_t *)(d + o_srt); in.h_rank = (const int32_t *)(d + o_rnk);
     S->d_order = (const int32_t *)(d + o_ord);
     S->n_reads = n; S->n_bases = n_bases; S->n_cig = B->n_cig;
     S->valid = true;
     return LAMSA_HP_OK;
 }
 
-// one launch over `n_units` reads (order list on the device); results into `O`
-static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H, float *ms)
+// one launch over `n_units` reads of the batch in slot `T` (order list on the device); results into `O`.  The kernel
+// is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
+static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
+                        hipEvent_t e0, hipEvent_t e1, bool wait)
 {
     size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
     if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
@@ -174,28 +216,28 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
     int n_waves = h->n_cu * per_cu;
     if (n_waves > n_units) n_waves = n_units;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    if (S->slab.ensure(slab_per_wave * (size_t)n_waves) || S->misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
-    const int n = S->n_reads;
+    if (grow(h, S->slab, slab_per_wave * (size_t)n_waves) || T.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    const int n = T.n_reads;
     AlignArgs a;
     a.P = h->para;
     a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
-    a.in = S->in;
+    a.in = T.in;
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
-    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)S->misc.p + 64);
-    a.slab = (char *)S->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)S->misc.p;
-    a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr;
+    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)T.misc.p + 64);
+    a.slab = (char *)S->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)T.misc.p;
+    a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
 #ifdef HP_PROF
     static DevBuf profbuf;
     if (profbuf.ensure(sizeof(long long) * 64 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 64 * (size_t)n); a.prof = (long long *)profbuf.p; }
+    wait = true;
 #endif
     hipStream_t s = h->stream;
-    HIPCHK(h, hipMemsetAsync(S->misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipEventRecord(h->ev0, s), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipMemsetAsync(T.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
     HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipEventRecord(h->ev1, s), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
-    if (ms) hipEventElapsedTime(ms, h->ev0, h->ev1);
+    HIPCHK(h, hipEventRecord(e1, s), LAMSA_HP_EKERNEL);
+    if (wait) HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
 #ifdef HP_PROF
     if (a.prof) {
         std::vector<long long> pr((size_t)n * 64);
@@ -207,78 +249,124 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, OutDev &O, const int3
         fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
         fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles) targets %lld trips %lld init_Mcyc %lld\n", sum[11], sum[12], sum[13] / 1000000);
         fprintf(stderr, "[HP_PROF] update_range: calls %lld total %lld prefilter %lld prologue %lld (Mcyc) chunks %lld | mini_line calls %lld tail+walk %lld Mcyc | forced %lld\n", sum[19], sum[16] / 1000000, sum[17] / 1000000, sum[18] / 1000000, sum[22], sum[21], sum[20] / 1000000, sum[23]);
-        { const char *nm[] = {"ksw_global", "ksw_extend", "backtrack", "ref_fetch", "head_fix", "frag_extend", "split_mapping", "tail_fix", "res_split", "res_aux", "mini_line_regs", "(calls = fallbacks)"};
+        { const char *nm[] = {"ksw_global", "ksw_extend", "backtrack", "ref_fetch", "head_fix", "frag_extend", "split_mapping", "tail_fix", "res_split", "res_aux", "mini_line_regs", "sort index"};
           for (int k = 0; k < 12; ++k) fprintf(stderr, "[HP_PROF] %-16s %8lld Mcyc %10lld calls\n", nm[k], sum[24 + 2 * k] / 1000000, sum[25 + 2 * k]);
           fprintf(stderr, "[HP_PROF] direction-matrix bytes in HBM %lld (%lld jobs); hits passed through nodes_per_init %lld (%lld calls)\n", sum[52], sum[53], sum[54], sum[55]);
           fprintf(stderr, "[HP_PROF] chain_first start: seed loop %lld, node_set loop %lld, min_extend %lld Mcyc (%lld reads with a MIN pass)\n", sum[56] / 1000000, sum[57] / 1000000, sum[58] / 1000000, sum[59]);
           fprintf(stderr, "[HP_PROF] query <= 62: ksw_extend %lld Mcyc %lld calls, ksw_global %lld Mcyc %lld calls\n", sum[60] / 1000000, sum[61], sum[62] / 1000000, sum[63]);
           const char *bn[] = {"[bi_extend total]", "[bi_extend after left ext]", "17-32", "33-64", "65-128", "129-256", "257-512", ">512"};
           for (int k = 0; k < 2; ++k) fprintf(stderr, "[HP_PROF] ksw_extend qlen %-8s %8lld Mcyc %10lld calls\n", bn[k], sum[48 + 2 * k] / 1000000, sum[49 + 2 * k]); }
-        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, S->h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }
+        for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, T.h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }
     }
 #endif
     return LAMSA_HP_OK;
+}
+
+static int slot_events(lamsa_hp_handle *h, Slot &T)
+{
+    if (!T.e0) HIPCHK(h, hipEventCreate(&T.e0), LAMSA_HP_EKERNEL);
+    if (!T.e1) HIPCHK(h, hipEventCreate(&T.e1), LAMSA_HP_EKERNEL);
+    return LAMSA_HP_OK;
+}
+
+// queue the main pass of the batch in slot `T`: every read, costliest first
+static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T)
+{
+    int rc = slot_events(h, T);
+    if (rc) return rc;
+    const int n = T.n_reads;
+    if (n == 0) return LAMSA_HP_OK;
+    if (T.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
+    return launch_align(h, S, T, T.out1, T.d_order, n, 1, T.max_L, T.max_H, T.e0, T.e1, false);
+}
+
+#define DL(dst, src, bytes) HIPCHK(h, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->copy_stream), LAMSA_HP_EKERNEL)
+#define DLSYNC() HIPCHK(h, hipStreamSynchronize(h->copy_stream), LAMSA_HP_EKERNEL)
+
+// wait for the main pass of slot `T`, re-run the reads that overflowed, fetch the results
+static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_result *R)
+{
+    const int n = T.n_reads;
+    h->kernel_ms[0] = h->kernel_ms[1] = 0;
+    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
+    if (S->stream.ensure(64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
+    if (n == 0) {
+        if (R) { R->stream = (const int32_t *)S->stream.p; R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); }
+        return LAMSA_HP_OK;
+    }
+    const double t_0 = now_s();
+    HIPCHK(h, hipEventSynchronize(T.e1), LAMSA_HP_EKERNEL);
+    const double t_1 = now_s();
+    hipEventElapsedTime(&h->kernel_ms[0], T.e0, T.e1);
+    unsigned long long used1 = 0;
+    DL(&used1, (char *)T.misc.p + 64, 8);
+    DL(S->r_st.data(), T.out1.st(n), 4 * (size_t)n); DL(S->r_off.data(), T.out1.off(), 8 * (size_t)n);
+    DL(S->r_len.data(), T.out1.len(n), 4 * (size_t)n); DL(S->r_tb.data(), T.out1.tb(n), 4 * (size_t)n);
+    DLSYNC();
+    if ((int64_t)used1 > T.out1.stream_cap) used1 = (unsigned long long)T.out1.stream_cap;
+    // ---- retry pass: reads whose work buffers (or the stream arena) were too small -- outliers; 8x capacities.
+    // It is queued behind whatever the compute stream already holds (the next batch's main pass, when streaming).
+    std::vector<int32_t> again;
+    for (int r = 0; r < n; ++r) if ((S->r_st[r] & LAMSA_HP_ST_OVERFLOW) || S->r_off[r] < 0) again.push_back(r);
+    unsigned long long used2 = 0;
+    if (!again.empty()) {
+        int mL = 0, mH = 0; int64_t cap2 = 1024;
+        for (int r : again) { mL = std::max(mL, T.h_len[r]); mH = std::max(mH, T.h_H[r]); cap2 += 64 + 12LL * 8 * T.h_len[r]; }
+        if (grow(h, S->out2.buf, OutDev::hdr(n) + 4 * (size_t)cap2 + 256) || grow(h, S->retry_list, 4 * again.size())) { h->err = "hipMalloc(retry)"; return LAMSA_HP_ENOMEM; }
+        S->out2.stream_cap = cap2;
+        HIPCHK(h, hipMemcpyAsync(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice, h->stream), LAMSA_HP_EKERNEL);
+        int rc = launch_align(h, S, T, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, h->ev0, h->ev1, true);
+        if (rc) return rc;
+        hipEventElapsedTime(&h->kernel_ms[1], h->ev0, h->ev1);
+        std::vector<int64_t> off2((size_t)n); std::vector<int32_t> len2((size_t)n), st2((size_t)n), tb2((size_t)n);
+        DL(&used2, (char *)T.misc.p + 64, 8);
+        DL(st2.data(), S->out2.st(n), 4 * (size_t)n); DL(off2.data(), S->out2.off(), 8 * (size_t)n);
+        DL(len2.data(), S->out2.len(n), 4 * (size_t)n); DL(tb2.data(), S->out2.tb(n), 4 * (size_t)n);
+        DLSYNC();
+        if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
+        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
+    }
+    for (int r = 0; r < n; ++r) if (S->r_off[r] < 0) { S->r_off[r] = 0; S->r_len[r] = 0; S->r_st[r] |= LAMSA_HP_ST_OVERFLOW; }
+    if (!R) return LAMSA_HP_OK;
+    if (S->stream.ensure(4 * (size_t)(used1 + used2) + 64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
+    int32_t *hs = (int32_t *)S->stream.p;
+    if (used1) DL(hs, T.out1.stream(n), 4 * (size_t)used1);
+    if (used2) DL(hs + used1, S->out2.stream(n), 4 * (size_t)used2);
+    DLSYNC();
+    if (g_trace) fprintf(stderr, "[lamsa_hp] collect: waited %.1f ms for the kernel (%.1f ms), results %.1f ms (%.2f GB)\n", 1e3 * (t_1 - t_0), h->kernel_ms[0], 1e3 * (now_s() - t_1), 4e-9 * (double)(used1 + used2));
+    R->stream = hs; R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data();
+    return LAMSA_HP_OK;
+}
+#undef DL
+#undef DLSYNC
+
+static int check_batch_args(lamsa_hp_handle *h, const lamsa_hp_batch *B)
+{
+    if (!h || !B || B->n_reads < 0) return LAMSA_HP_EINVAL;
+    if (!h->d_pac) { h->err = "handle was created without a reference"; return LAMSA_HP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    return LAMSA_HP_OK;
+}
+
+extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B)
+{
+    int rc = check_batch_args(h, B);
+    if (rc) return rc;
+    AlignState *S = state_of(h);
+    if (S->n_fifo) { h->err = "submitted batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
+    return upload_into(h, &S->slot[0], B);
 }
 
 extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
 {
     if (!h) return LAMSA_HP_EINVAL;
     AlignState *S = state_of(h);
-    if (!S->valid) { h->err = "no batch uploaded"; return LAMSA_HP_EINVAL; }
+    if (S->n_fifo) { h->err = "submitted batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
+    if (!S->slot[0].valid) { h->err = "no batch uploaded"; return LAMSA_HP_EINVAL; }
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
-    const int n = S->n_reads;
-    h->kernel_ms[0] = h->kernel_ms[1] = 0;
-    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
-    if (n == 0) {
-        S->stream.assign(4, 0);
-        if (R) { R->stream = S->stream.data(); R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); }
-        return LAMSA_HP_OK;
-    }
-    // ---- main pass: every read, costliest first
-    if (S->out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * S->n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
-    int rc = launch_align(h, S, S->out1, S->d_order, n, 1, S->max_L, S->max_H, &h->kernel_ms[0]);
+    int rc = start_main(h, S, S->slot[0]);
     if (rc) return rc;
-    unsigned long long used1 = 0;
-    HIPCHK(h, hipMemcpy(&used1, (char *)S->misc.p + 64, 8, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    if ((int64_t)used1 > S->out1.stream_cap) used1 = (unsigned long long)S->out1.stream_cap;
-    HIPCHK(h, hipMemcpy(S->r_st.data(), S->out1.st(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipMemcpy(S->r_off.data(), S->out1.off(), 8 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipMemcpy(S->r_len.data(), S->out1.len(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipMemcpy(S->r_tb.data(), S->out1.tb(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    // ---- retry pass: reads whose work buffers (or the stream arena) were too small -- outliers; 8x capacities
-    std::vector<int32_t> again;
-    for (int r = 0; r < n; ++r) if ((S->r_st[r] & LAMSA_HP_ST_OVERFLOW) || S->r_off[r] < 0) again.push_back(r);
-    unsigned long long used2 = 0;
-    if (!again.empty()) {
-        int mL = 0, mH = 0; int64_t cap2 = 1024;
-        for (int r : again) { mL = std::max(mL, S->h_len[r]); mH = std::max(mH, S->h_H[r]); cap2 += 64 + 12LL * 8 * S->h_len[r]; }
-        if (S->out2.ensure(n, cap2) || S->retry_list.ensure(4 * again.size())) { h->err = "hipMalloc(retry)"; return LAMSA_HP_ENOMEM; }
-        HIPCHK(h, hipMemcpy(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
-        rc = launch_align(h, S, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, &h->kernel_ms[1]);
-        if (rc) return rc;
-        HIPCHK(h, hipMemcpy(&used2, (char *)S->misc.p + 64, 8, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
-        std::vector<int64_t> off2((size_t)n); std::vector<int32_t> len2((size_t)n), st2((size_t)n), tb2((size_t)n);
-        HIPCHK(h, hipMemcpy(st2.data(), S->out2.st(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        HIPCHK(h, hipMemcpy(off2.data(), S->out2.off(), 8 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        HIPCHK(h, hipMemcpy(len2.data(), S->out2.len(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        HIPCHK(h, hipMemcpy(tb2.data(), S->out2.tb(n), 4 * (size_t)n, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
-    }
-    for (int r = 0; r < n; ++r) if (S->r_off[r] < 0) { S->r_off[r] = 0; S->r_len[r] = 0; S->r_st[r] |= LAMSA_HP_ST_OVERFLOW; }
-    if (!R) return LAMSA_HP_OK;
-    S->stream.resize((size_t)(used1 + used2) + 4);
-    if (used1) HIPCHK(h, hipMemcpy(S->stream.data(), S->out1.stream(n), 4 * (size_t)used1, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    if (used2) HIPCHK(h, hipMemcpy(S->stream.data() + used1, S->out2.stream(n), 4 * (size_t)used2, hipMemcpyDeviceToHost), LAMSA_HP_EKERNEL);
-    R->stream = S->stream.data(); R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data();
-    return LAMSA_HP_OK;
-}
-
-extern "C" int lamsa_hp_set_scratch_limit(lamsa_hp_handle *h, size_t bytes)
-{
-    if (!h || (bytes && bytes < ((size_t)64 << 10))) return LAMSA_HP_EINVAL;
-    h->scratch_limit = bytes;
-    return LAMSA_HP_OK;
+    return finish_main(h, S, S->slot[0], R);
 }
 
 extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B, lamsa_hp_result *R)
@@ -286,4 +374,47 @@ extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B,
     int rc = lamsa_hp_upload_batch(h, B);
     if (rc) return rc;
     return lamsa_hp_run_uploaded(h, R);
+}
+
+extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B)
+{
+    int rc = check_batch_args(h, B);
+    if (rc) return rc;
+    AlignState *S = state_of(h);
+    if (S->n_fifo >= 2) { h->err = "two batches are already in flight: collect one first"; return LAMSA_HP_EINVAL; }
+    const int k = S->n_fifo == 1 ? 1 - S->fifo[0] : 0;         // the slot no queued kernel reads
+    rc = upload_into(h, &S->slot[k], B);                         // overlaps the kernel of the other slot
+    if (rc) return rc;
+    rc = start_main(h, S, S->slot[k]);
+    if (rc) { S->slot[k].valid = false; return rc; }
+    S->fifo[S->n_fifo++] = k;
+    return LAMSA_HP_OK;
+}
+
+extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *R)
+{
+    if (!h) return LAMSA_HP_EINVAL;
+    AlignState *S = state_of(h);
+    if (S->n_fifo == 0) { h->err = "no batch in flight"; return LAMSA_HP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    const int k = S->fifo[0];
+    S->fifo[0] = S->fifo[1]; --S->n_fifo;
+    const int rc = finish_main(h, S, S->slot[k], R);
+    S->slot[k].valid = false;
+    return rc;
+}
+
+extern "C" void *lamsa_hp_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void lamsa_hp_host_free(void *p) { if (p) hipHostFree(p); }
+
+extern "C" int lamsa_hp_set_scratch_limit(lamsa_hp_handle *h, size_t bytes)
+{
+    if (!h || (bytes && bytes < ((size_t)64 << 10))) return LAMSA_HP_EINVAL;
+    h->scratch_limit = bytes;
+    return LAMSA_HP_OK;
 }

@@ -33,8 +33,6 @@ struct BatchIn {
     const int8_t  *h_strand;     // +1 / -1
     const uint8_t *h_cig_n;
     const int32_t *cig;          // seed CIGAR words
-    const int32_t *h_sort;       // [n_hits] per read: local hit indices sorted by (contig, strand, position)  (hp_hostprep.h)
-    const int32_t *h_rank;       // [n_hits] inverse permutation
 };
 
 // Result stream of one read (int32 words), serialised by the wave that aligned it:
@@ -57,6 +55,7 @@ struct AlignArgs {
     BatchIn in;
     BatchOut out;
     char *slab; size_t slab_per_wave;
+    int32_t sort_pb, sort_cb;    // bits of the largest hit position / contig*2+strand code of the batch (hp_sort.h)
     int32_t *counter;            // dynamic read queue head
     const int32_t *order;        // processing order (costliest first) / retry list, or nullptr
     int32_t n_units;             // number of entries to process (n_reads, or the length of the retry list)

@@ -1204,7 +1204,7 @@ HP_INL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line
 #endif
     const int n = mini_line_regs(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
 #ifdef HP_PROF
-    if (r.prof) { r.prof[44] += wv::clock() - t0_; r.prof[45] += 1; if (n < 0) r.prof[47] += 1; }
+    if (r.prof) { r.prof[44] += wv::clock() - t0_; r.prof[45] += 1; }
 #endif
     return n >= 0 ? n : mini_line_mem(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
 }

@@ -519,14 +519,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (int32_t ch : B.h_chr) if (ch < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); c->ret = 1; break; }
         return c;
     };
-    std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, prepare);
-    while (ret == 0) {
-        std::unique_ptr<Chunk> cur = next.get();
-        if (cur->ret) { ret = cur->ret; break; }
-        if (cur->B.reads.empty()) break;
-        next = std::async(std::launch::async, prepare);      // overlaps with everything below
-        Batch &B = cur->B;
-        const int n = (int)B.reads.size();
+    auto submit = [&](Batch &B) -> int {
         lamsa_hp_batch hb;
         hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
         hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
@@ -536,11 +529,17 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_off = &zero32; hb.h_cig_n = &zero8; }
         if (!hb.cig) hb.cig = &zero32;
         if (!hb.read_seq) hb.read_seq = &zero8;
+        const int e = lamsa_hp_submit_batch(h, &hb);
+        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_submit_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
+        return 0;
+    };
+    // records -> MAPQ / XA -> SAM text, on all host threads; written in input order
+    auto collect_and_write = [&](Batch &B) -> int {
         lamsa_hp_result res;
-        rc = lamsa_hp_align_batch(h, &hb, &res);
-        if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_align_batch failed: %d %s\n", rc, lamsa_hp_last_error(h)); ret = 2; break; }
+        const int e = lamsa_hp_collect_batch(h, &res);
+        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
         kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
-        // ---- records -> MAPQ / XA -> SAM text, on all host threads; written in input order
+        const int n = (int)B.reads.size();
         std::vector<std::string> sams((size_t)threads);
         std::vector<long> bad_of((size_t)threads, 0);
         parallel_blocks(n, threads, [&](int t, int r0, int r1) {
@@ -557,6 +556,23 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (int t = 0; t < threads; ++t) { fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
+        return 0;
+    };
+    // Two chunks are in flight on the device (lamsa_hp_submit_batch): while the GPU aligns chunk i-1, chunk i is
+    // uploaded behind it, chunk i+1 is read and parsed, and -- once collected -- chunk i-1's SAM text is written.
+    std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, prepare);
+    std::unique_ptr<Chunk> flying;                           // submitted, not yet collected
+    for (;;) {
+        std::unique_ptr<Chunk> cur = next.get();
+        if (cur->ret) ret = cur->ret;
+        const bool have = ret == 0 && !cur->B.reads.empty();
+        if (have) {
+            next = std::async(std::launch::async, prepare);  // overlaps with everything below
+            ret = submit(cur->B);
+        }
+        if (flying) { const int e = collect_and_write(flying->B); if (e && !ret) ret = e; flying.reset(); }
+        if (!have || ret) break;
+        flying = std::move(cur);
     }
     if (next.valid()) next.wait();                       // the reader thread must be done before the files are closed
     lamsa_hp_destroy(h);

@@ -56,7 +56,8 @@ class HpResult(C.Structure):
 
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
            "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms", "lamsa_hp_set_scratch_limit",
-           "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded")
+           "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded",
+           "lamsa_hp_submit_batch", "lamsa_hp_collect_batch", "lamsa_hp_host_alloc", "lamsa_hp_host_free")
 
 _lib = None
 
@@ -87,6 +88,13 @@ def load_library(path=LIB_PATH):
         L.lamsa_hp_last_kernel_ms.restype = C.c_float
         L.lamsa_hp_set_scratch_limit.argtypes = [C.c_void_p, C.c_size_t]
         L.lamsa_hp_set_scratch_limit.restype = C.c_int
+        L.lamsa_hp_submit_batch.argtypes = [C.c_void_p, C.POINTER(HpBatch)]
+        L.lamsa_hp_submit_batch.restype = C.c_int
+        L.lamsa_hp_collect_batch.argtypes = [C.c_void_p, C.POINTER(HpResult)]
+        L.lamsa_hp_collect_batch.restype = C.c_int
+        L.lamsa_hp_host_alloc.argtypes = [C.c_size_t]
+        L.lamsa_hp_host_alloc.restype = C.c_void_p
+        L.lamsa_hp_host_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -234,3 +242,53 @@ class LamsaHp:
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
         return self._result(R, self._n_up)
+
+    # ---- streaming form: up to two batches in flight
+    def submit_batch(self, batch):
+        """Upload `batch` behind the running kernel and queue its kernel; returns once the copy is done."""
+        b = self._batch_struct(batch)
+        rc = self.L.lamsa_hp_submit_batch(self._h, C.byref(b))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_submit_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        self._n_fly = getattr(self, "_n_fly", []) + [batch.n_reads]
+
+    def collect_batch(self, raw=False):
+        """Results of the oldest submitted batch, as align_batch returns them (raw=True: numpy views, see run_uploaded)."""
+        R = HpResult()
+        rc = self.L.lamsa_hp_collect_batch(self._h, C.byref(R))
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_collect_batch: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        n = self._n_fly.pop(0)
+        if raw:
+            self.last_stream_words = int(R.stream_words)
+            return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
+                    np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
+        return self._result(R, n)
+
+
+def pinned_batch(batch):
+    """Copy of `batch` (any object with the lamsa_hp_batch arrays) whose arrays live in page-locked host memory
+    (lamsa_hp_host_alloc): uploads from it run at the PCIe rate.  Keep the returned object alive while it is in use;
+    `release()` frees the memory."""
+    L = load_library()
+
+    class Pinned:
+        pass
+    out = Pinned(); out._ptrs = []; out.n_reads = batch.n_reads
+    for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
+                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+        a = np.ascontiguousarray(getattr(batch, name))
+        p = L.lamsa_hp_host_alloc(max(a.nbytes, 1))
+        if not p:
+            raise RuntimeError("lamsa_hp_host_alloc(%d) failed" % a.nbytes)
+        out._ptrs.append(p)
+        v = np.ctypeslib.as_array((C.c_uint8 * max(a.nbytes, 1)).from_address(p))[:a.nbytes].view(a.dtype)
+        v[...] = a.reshape(-1)
+        setattr(out, name, v)
+
+    def release():
+        for p in out._ptrs:
+            L.lamsa_hp_host_free(p)
+        out._ptrs = []
+    out.release = release
+    return out

@@ -26,8 +26,51 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
 }
 
 // ---------------------------------------------------------------- whole per-read path, emulated
+#include <algorithm>
 #include "hp_align.h"
-#include "hp_hostprep.h"
+
+// key field widths of a batch, as the product's validation pass derives them
+static void emu_sort_widths(const BatchIn &in, int n_reads, int &pb, int &cb)
+{
+    const int64_t n_hits = n_reads ? in.hit_off[in.seed_off[n_reads]] : 0;
+    long long mp = 0, mc = 0;
+    for (int64_t k = 0; k < n_hits; ++k) { mp = in.h_pos[k] > mp ? in.h_pos[k] : mp; mc = in.h_chr[k] > mc ? in.h_chr[k] : mc; }
+    pb = bits_of((unsigned long long)mp); cb = bits_of((unsigned long long)(2 * mc + 1));
+}
+
+// the sort index of a whole batch through the device code (hp_sort.h) under the lane emulation
+static void emu_sort_index(const BatchIn &in, int n_reads, std::vector<int32_t> &srt, std::vector<int32_t> &rnk)
+{
+    const int64_t n_hits = n_reads ? in.hit_off[in.seed_off[n_reads]] : 0;
+    srt.assign((size_t)n_hits + 1, 0); rnk.assign((size_t)n_hits + 1, 0);
+    std::vector<uint64_t> keys((size_t)n_hits + 1, 0);
+    static uint64_t lw[HP_LDS_WORDS / 2];
+    int pb, cb; emu_sort_widths(in, n_reads, pb, cb);
+    for (int r = 0; r < n_reads; ++r) {
+        const int64_t hb = in.hit_off[in.seed_off[r]]; const int H = (int)(in.hit_off[in.seed_off[r + 1]] - hb);
+        sort_read_hits(in.h_pos + hb, in.h_chr + hb, in.h_strand + hb, H, srt.data() + hb, rnk.data() + hb, keys.data() + hb, lw, HP_LDS_WORDS / 2, pb, cb);
+    }
+}
+
+// checker: the same index by std::stable_sort; returns the number of entries that differ
+extern "C" int64_t emu_sort_check(int n_reads, const int64_t *seed_off, const int64_t *hit_off, const int64_t *h_pos, const int32_t *h_chr, const int8_t *h_strand)
+{
+    BatchIn in; memset(&in, 0, sizeof in);
+    in.n_reads = n_reads; in.seed_off = seed_off; in.hit_off = hit_off; in.h_pos = h_pos; in.h_chr = h_chr; in.h_strand = h_strand;
+    std::vector<int32_t> srt, rnk;
+    emu_sort_index(in, n_reads, srt, rnk);
+    int64_t bad = 0;
+    for (int r = 0; r < n_reads; ++r) {
+        const int64_t hb = hit_off[seed_off[r]], he = hit_off[seed_off[r + 1]];
+        const int H = (int)(he - hb);
+        std::vector<int> idx((size_t)H);
+        for (int k = 0; k < H; ++k) idx[k] = k;
+        auto key = [&](int k) { return ((uint64_t)((uint32_t)h_chr[hb + k] * 2u + (h_strand[hb + k] > 0 ? 1u : 0u)) << 40) | ((uint64_t)h_pos[hb + k] & ((1ull << 40) - 1)); };
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) < key(b); });
+        for (int i = 0; i < H; ++i) bad += (srt[hb + i] != idx[i]) + (rnk[hb + idx[i]] != i);
+    }
+    return bad;
+}
 
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
                                int32_t *stream, int64_t stream_cap, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status)
@@ -38,9 +81,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.in.n_reads = B->n_reads; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
     a.in.seed_off = B->seed_off; a.in.seed_id = B->seed_id; a.in.hit_off = B->hit_off; a.in.h_pos = B->h_pos; a.in.h_chr = B->h_chr;
     a.in.h_cig_off = B->h_cig_off; a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig;
-    std::vector<int32_t> srt, rnk;
-    hp_build_sort_index(B->n_reads, B->seed_off, B->hit_off, B->h_pos, B->h_chr, B->h_strand, srt, rnk);
-    a.in.h_sort = srt.data(); a.in.h_rank = rnk.data();
+    emu_sort_widths(a.in, B->n_reads, a.sort_pb, a.sort_cb);
     unsigned long long cursor = 0;
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;

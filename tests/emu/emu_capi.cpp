@@ -2,6 +2,8 @@
 // so that the host program (lamsa_amd/host/*.cpp) can be linked into tests/_build/lamsa_emu and its file IO, GEM
 // parsing, ranking and SAM writer tested without a GPU.  Never linked into the product (lamsa_amd/bin/lamsa links
 // liblamsa_hp.so and has no CPU path).
+#include <deque>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "hp_para.h"
@@ -12,6 +14,8 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
 struct lamsa_hp_handle {
     lamsa_hp_para P; lamsa_hp_ref ref; std::string err;
     std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off;
+    struct Done { std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off; };
+    std::deque<Done> fifo;                 // lamsa_hp_submit_batch computes at once; lamsa_hp_collect_batch hands the oldest out
 };
 
 extern "C" int lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para, const lamsa_hp_ref *ref, int)
@@ -50,3 +54,29 @@ extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B,
     res->read_status = h->status.data(); res->read_tbases = h->tb.data();
     return LAMSA_HP_OK;
 }
+
+// the streaming form: same two-deep queue discipline and error returns as the product
+extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B)
+{
+    if (h->fifo.size() >= 2) { h->err = "two batches are already in flight: collect one first"; return LAMSA_HP_EINVAL; }
+    lamsa_hp_result r;
+    const int rc = lamsa_hp_align_batch(h, B, &r);
+    if (rc) return rc;
+    h->fifo.emplace_back();
+    lamsa_hp_handle::Done &d = h->fifo.back();
+    d.stream.swap(h->stream); d.len.swap(h->len); d.status.swap(h->status); d.tb.swap(h->tb); d.off.swap(h->off);
+    return LAMSA_HP_OK;
+}
+extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
+{
+    if (h->fifo.empty()) { h->err = "no batch in flight"; return LAMSA_HP_EINVAL; }
+    lamsa_hp_handle::Done &d = h->fifo.front();
+    h->stream.swap(d.stream); h->len.swap(d.len); h->status.swap(d.status); h->tb.swap(d.tb); h->off.swap(d.off);
+    h->fifo.pop_front();
+    if (h->stream.empty()) h->stream.push_back(0);
+    res->stream = h->stream.data(); res->stream_words = 0; for (size_t r = 0; r + 1 < h->len.size(); ++r) res->stream_words += h->len[r];
+    res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data();
+    return LAMSA_HP_OK;
+}
+extern "C" void *lamsa_hp_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+extern "C" void lamsa_hp_host_free(void *p) { free(p); }

@@ -86,6 +86,57 @@ def test_hip_second_pass_after_scratch_overflow(tmp_path):
     h.close()
 
 
+def test_hip_streaming_submit_collect(tmp_path):
+    """lamsa_hp_submit_batch / lamsa_hp_collect_batch: chunks of different sizes two-deep in flight come back in
+    submission order with the streams of the one-call boundary; queue-discipline errors; page-locked input arrays;
+    a second pass needed while the next chunk is already queued."""
+    from lamsa_amd import hp
+    ref, reads, args, _ = goldenlib.stage_scenario("c3_ont", str(tmp_path))
+    rt, over = goldenlib.para_from_args(args)
+    lp = reflib.lo_para(rt, **over)
+    B = reflib.Batch(ref, reads, lp)
+    want = reflib.oracle_streams(B, lp)
+    n = B.n_reads
+    parts = [list(range(0, n // 2)), list(range(n // 2, n)), [], [n - 1, 0, 1], list(range(n))]
+    h = _handle(B, rt, over)
+    with pytest.raises(RuntimeError):
+        h.collect_batch()                                # nothing in flight
+    got = []
+    h.submit_batch(B.take(parts[0]))
+    for k in range(1, len(parts)):
+        h.submit_batch(B.take(parts[k]))
+        if k == 1:
+            with pytest.raises(RuntimeError):
+                h.submit_batch(B)                        # two already in flight
+            with pytest.raises(RuntimeError):
+                h.align_batch(B)                         # the one-call form is refused while chunks are in flight
+        got.append(h.collect_batch())
+    got.append(h.collect_batch())
+    for k, idx in enumerate(parts):
+        assert got[k][0] == [want[i] for i in idx], "chunk %d" % k
+        assert (got[k][1] == 0).all()
+    # the one-call form works again once the queue is empty
+    assert h.align_batch(B)[0] == want
+    # page-locked arrays
+    Bp = hp.pinned_batch(B)
+    h.submit_batch(Bp); h.submit_batch(Bp)
+    a = h.collect_batch()[0]; b = h.collect_batch()[0]
+    Bp.release()
+    assert a == want and b == want
+    # every read of the first chunk needs the second pass while the second chunk's kernel is already queued
+    h.set_scratch_limit(600 << 10)
+    h.submit_batch(B); h.submit_batch(B.take(parts[0]))
+    a, st = h.collect_batch()
+    assert h.last_kernel_ms(1) > 0 and a == want and (st == 0).all()
+    b, st = h.collect_batch()
+    assert b == [want[i] for i in parts[0]] and (st == 0).all()
+    h.close()
+    # a handle destroyed with a chunk still in flight
+    h = _handle(B, rt, over)
+    h.submit_batch(B)
+    h.close()
+
+
 def _records(stream):
     """(line, offset, chr, nstrand, score, NM, cigar words) of every record of one read's stream."""
     out, i = [], 3
