@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--reads", type=int, default=32768, help="reads per batch (= per step) and per GPU")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--stream-chunks", type=int, default=4, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
+                    "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="development only: run the N > 1 code path with the gloo backend and every rank on GPU 0 "
@@ -199,10 +201,12 @@ def main():
                 h.submit_batch(Bx); h.collect_batch(raw=True)
             h.collect_batch(raw=True)
             return k * a.reads / (time.perf_counter() - t0)
-        r_stream = streamed(B)
-        Bp = hp.pinned_batch(B)
-        r_stream_pinned = streamed(Bp)
-        Bp.release()
+        r_stream = r_stream_pinned = None
+        if a.stream_chunks > 1:
+            r_stream = round(streamed(B, a.stream_chunks), 2)
+            Bp = hp.pinned_batch(B)
+            r_stream_pinned = round(streamed(Bp, a.stream_chunks), 2)
+            Bp.release()
         cpu = None
         if a.cpu_seconds > 0 and world == 1:               # the CPU baseline is measured on rank 0 of the single-GPU run only
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
@@ -225,7 +229,7 @@ def main():
                                    "(GEM thresholds, <=200/seed): %.1f hits/seed, %.0f hits/read" % (a.workload, a.reads, wl["length"], ref.l_pac, ref.n_copies, hits.mean() if len(hits) else 0, B.n_hits / max(1, a.reads)),
                        "reads_per_step_per_gpu": a.reads, "read_len": wl["length"], "read_type": wl["read_type"], "parallelism": "reads sharded over %d GPU(s), no collectives" % a.gpus},
             "reads_not_ok": int(tot[3]), "pcie_inclusive_reads_per_s": round(a.reads / t_pcie, 2),
-            "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": round(r_stream, 2), "pinned_host_arrays": round(r_stream_pinned, 2), "chunks": 4},
+            "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": r_stream, "pinned_host_arrays": r_stream_pinned, "chunks": a.stream_chunks},
             "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -174,8 +174,9 @@ int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res);
 void *lamsa_hp_host_alloc(size_t bytes);
 void  lamsa_hp_host_free(void *p);
 
-/* Wall time in milliseconds of the kernel(s) of the most recent call on this handle,
- * measured with HIP events on the stream the kernels ran on; n-th kernel of that call. */
+/* Wall time in milliseconds of the kernel(s) of the most recent call on this handle (for the streaming form: of the
+ * batch just collected), measured with HIP events on the stream the kernels ran on; which = 0: the main pass,
+ * 1: the second pass over the reads that overflowed their scratch (0 when none did). */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
 
 /* Cap the per-wave scratch slab of the first pass at `bytes` (0 = size it from the batch, the default).  The slab
