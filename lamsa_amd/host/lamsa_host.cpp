@@ -13,6 +13,7 @@
 // the output equals the reference's with `-R 0`.
 #include "lamsa_host.h"
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
@@ -21,7 +22,15 @@
 #include <future>
 #include <memory>
 #include <thread>
+#include <time.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace lamsa {
 
@@ -53,14 +62,50 @@ bool load_index(const std::string &prefix, Index &ix, std::string &err)
     return true;
 }
 
+// A mapped input file is touched page by page by a helper thread that runs ahead of the reader, so that the reader
+// itself does not take the page faults (they cost more than finding the line ends).
+struct Prefault {
+    std::thread th; std::atomic<bool> stop{false};
+    void start(const char *p, size_t n) {
+        th = std::thread([this, p, n]() { unsigned sink = 0; for (size_t i = 0; i < n && !stop.load(std::memory_order_relaxed); i += 4096) sink += (unsigned char)((const volatile char *)p)[i]; (void)sink; });
+    }
+    void finish() { stop = true; if (th.joinable()) th.join(); }
+};
+
 // ------------------------------------------------------------------ FASTA / FASTQ (+gz)
-struct FastxReader::Impl { gzFile f = nullptr; std::string line; bool have = false; };
+struct FastxReader::Impl {
+    gzFile f = nullptr; std::string line; bool have = false;
+    const char *m = nullptr; size_t mn = 0, mpos = 0;       // an uncompressed regular file is mapped instead of read through zlib
+    Prefault pf;
+};
 FastxReader::FastxReader() : p(new Impl) {}
-FastxReader::~FastxReader() { if (p->f) gzclose(p->f); delete p; }
-bool FastxReader::open(const std::string &path) { p->f = gzopen(path.c_str(), "r"); return p->f != nullptr; }
+FastxReader::~FastxReader() { p->pf.finish(); if (p->f) gzclose(p->f); if (p->m) munmap((void *)p->m, p->mn); delete p; }
+bool FastxReader::open(const std::string &path)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd >= 0) {
+        struct stat st; unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); p->m = (const char *)m; p->mn = (size_t)st.st_size; ::close(fd); p->pf.start(p->m, p->mn); return true; }
+        }
+        ::close(fd);
+    }
+    p->f = gzopen(path.c_str(), "r");
+    return p->f != nullptr;
+}
 static bool next_line(FastxReader::Impl *p)
 {
     if (p->have) { p->have = false; return true; }
+    if (p->m) {
+        if (p->mpos >= p->mn) return false;
+        const char *a = p->m + p->mpos, *nl = (const char *)memchr(a, '\n', p->mn - p->mpos);
+        const char *e = nl ? nl : p->m + p->mn;
+        p->mpos = (size_t)(e - p->m) + (nl ? 1 : 0);
+        while (e > a && (e[-1] == '\r' || e[-1] == '\n')) --e;
+        p->line.assign(a, (size_t)(e - a));
+        return true;
+    }
     p->line.clear();
     char buf[1 << 16];
     bool any = false;
@@ -84,7 +129,11 @@ bool FastxReader::next(Read &r)
     while (next_line(p)) {
         const char c0 = p->line.empty() ? 0 : p->line[0];
         if (c0 == '>' || c0 == '+' || c0 == '@') { if (c0 != '+') p->have = true; break; }
-        for (char c : p->line) if (isgraph((unsigned char)c)) r.seq.push_back(c);
+        const size_t k0 = r.seq.size();                                   // kseq keeps the isgraph() characters of a sequence line
+        r.seq.append(p->line);
+        unsigned dirty = 0;                                               // isgraph() in the C locale: 33..126
+        { const char *d = r.seq.data(); const size_t k1 = r.seq.size(); for (size_t k = k0; k < k1; ++k) dirty |= (unsigned)((unsigned char)(d[k] - 33) >= 94); }
+        if (dirty) r.seq.erase(std::remove_if(r.seq.begin() + (long)k0, r.seq.end(), [](char c) { return (unsigned char)(c - 33) >= 94; }), r.seq.end());
     }
     if (fastq && !p->have) {
         while (r.qual.size() < r.seq.size() && next_line(p)) r.qual += p->line;
@@ -95,34 +144,41 @@ bool FastxReader::next(Read &r)
 }
 
 // ------------------------------------------------------------------ GEM map line -> hits
-static inline void cig_push1(std::vector<int32_t> &c, size_t base, int32_t w)
+template <class V> static inline void cig_push1(V &c, size_t base, int32_t w)
 {   // _push_cigar1, src/frag_check.h:153 (restricted to the CIGAR that starts at `base`)
     if ((w >> 4) == 0) return;
     if (c.size() > base && (c.back() & 0xf) == (w & 0xf)) { c.back() += (w >> 4) << 4; return; }
     c.push_back(w);
 }
 
-// one hit "chr:strand:pos:gigar" appended to the batch; md2cigar, src/gem_parse.c:74-112
+// one hit "chr:strand:pos:gigar" appended to the batch; md2cigar, src/gem_parse.c:74-112.  The text is a view into the
+// mapped file: every scan is bounded by the token's end.
 static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
 {
-    const char *e = tok + len, *c1 = (const char *)memchr(tok, ':', len);
-    if (!c1) return;
-    const std::string chr(tok, c1);
+    const char *e = tok + len, *c1 = tok;
+    while (c1 < e && *c1 != ':') ++c1;
+    if (c1 >= e) return;
     const char strand = c1 + 1 < e ? c1[1] : '+';
-    const char *c2 = c1 + 2 < e ? (const char *)memchr(c1 + 2, ':', (size_t)(e - c1 - 2)) : nullptr;
-    if (!c2) return;
-    const char *c3 = (const char *)memchr(c2 + 1, ':', (size_t)(e - c2 - 1));
-    if (!c3) c3 = e;
-    const long long pos = atoll(std::string(c2 + 1, c3).c_str());
-    const char *md = c3 < e ? c3 + 1 : e;
-    const char *mdend = (const char *)memchr(md, ':', (size_t)(e - md));
-    if (!mdend) mdend = e;
+    const char *c2 = c1 + 2;
+    while (c2 < e && *c2 != ':') ++c2;
+    if (c2 >= e) return;
+    long long pos = 0;                                                     // atoll on the field
+    const char *c3 = c2 + 1;
+    { bool neg = false; if (c3 < e && (*c3 == '-' || *c3 == '+')) { neg = *c3 == '-'; ++c3; } for (; c3 < e && *c3 >= '0' && *c3 <= '9'; ++c3) pos = pos * 10 + (*c3 - '0'); if (neg) pos = -pos; }
+    while (c3 < e && *c3 != ':') ++c3;
+    const char *md = c3 < e ? c3 + 1 : e, *mdend = md;
+    while (mdend < e && *mdend != ':') ++mdend;
     const size_t base = B.cig.size();
     int nm = 0, bd = 0, bi = 0;
     for (const char *q = md; q < mdend;) {
         if (*q == '>') {
-            const int n = atoi(q + 1);
-            const char *s = q + 1; while (s < mdend && *s != '+' && *s != '-') ++s;
+            int n = 0;                                                     // atoi(q + 1)
+            const char *s = q + 1;
+            bool neg = false; if (s < mdend && (*s == '-' || *s == '+')) { neg = *s == '-'; ++s; }
+            const char *d0 = s;
+            for (; s < mdend && *s >= '0' && *s <= '9'; ++s) n = n * 10 + (*s - '0');
+            if (neg) { n = -n; s = d0 - 1; }                               // ">-3": atoi takes the sign, the scan below stops at it
+            while (s < mdend && *s != '+' && *s != '-') ++s;
             if (s < mdend && *s == '+') { bd += n; cig_push1(B.cig, base, (n << 4) | 2); } else { bi += n; cig_push1(B.cig, base, (n << 4) | 1); }
             nm += n;
             int d = 1; for (int t = n; t >= 10; t /= 10) ++d;
@@ -130,8 +186,9 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
         } else {
             int m = 0, mm = 0, run = 0; bool in_run = false;
             for (; q < mdend && *q != '>'; ++q) {
-                if (*q >= 'A' && *q <= 'T') { ++mm; if (in_run) { m += run; run = 0; in_run = false; } }
-                else if (isdigit((unsigned char)*q)) { run = in_run ? run * 10 + (*q - '0') : (*q - '0'); in_run = true; }
+                const char ch = *q;
+                if (ch >= 'A' && ch <= 'T') { ++mm; if (in_run) { m += run; run = 0; in_run = false; } }
+                else if (ch >= '0' && ch <= '9') { run = in_run ? run * 10 + (ch - '0') : (ch - '0'); in_run = true; }
                 else if (in_run) { m += run; run = 0; in_run = false; }
             }
             if (in_run) m += run;
@@ -140,21 +197,28 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
         }
     }
     if (strand == '-') std::reverse(B.cig.begin() + (long)base, B.cig.end());      // _invert_cigar, src/gem_parse.c:267
-    auto it = ix.name_to_id.find(chr);
-    B.h_pos.push_back(pos); B.h_chr.push_back(it == ix.name_to_id.end() ? -1 : it->second); B.h_strand.push_back(strand == '+' ? 1 : -1);
+    // contig name -> id (map_cal_msg's strcmp scan, src/lamsa_aln.c:767); consecutive hits mostly share the contig
+    static thread_local std::string last_name; static thread_local int last_id = 0; static thread_local const Index *last_ix = nullptr;
+    const size_t nl = (size_t)(c1 - tok);
+    if (last_ix != &ix || last_name.size() != nl || memcmp(last_name.data(), tok, nl) != 0) {
+        last_name.assign(tok, nl); last_ix = &ix;
+        auto it = ix.name_to_id.find(last_name);
+        last_id = it == ix.name_to_id.end() ? -1 : it->second;
+    }
+    B.h_pos.push_back(pos); B.h_chr.push_back(last_id); B.h_strand.push_back(strand == '+' ? 1 : -1);
     B.h_nm.push_back((int16_t)nm); B.h_len_dif.push_back((int16_t)(bd - bi)); B.h_cig_off.push_back((int32_t)base);
     B.h_cig_n.push_back((uint8_t)std::min<size_t>(255, B.cig.size() - base));
 }
 
 // all hits of one seed; more than max_n hits: the seed keeps its slot but loses all hits (src/gem_parse.c:243-246)
-static void parse_gem_hits(Batch &B, const Index &ix, const char *s, int max_n)
+static void parse_gem_hits(Batch &B, const Index &ix, const char *s, const char *end, int max_n)
 {
     const size_t h0 = B.h_pos.size(), c0 = B.cig.size();
     int n = 0;
-    for (const char *p = s; *p;) {
-        while (*p == ',') ++p;
-        if (!*p) break;
-        const char *e = p; while (*e && *e != ',') ++e;
+    for (const char *p = s; p < end;) {
+        while (p < end && *p == ',') ++p;
+        if (p >= end) break;
+        const char *e = (const char *)memchr(p, ',', (size_t)(end - p)); if (!e) e = end;
         if (n >= max_n) {
             B.h_pos.resize(h0); B.h_chr.resize(h0); B.h_strand.resize(h0); B.h_nm.resize(h0); B.h_len_dif.resize(h0); B.h_cig_off.resize(h0); B.h_cig_n.resize(h0); B.cig.resize(c0);
             return;
@@ -178,74 +242,88 @@ static const uint8_t *nt4_table()
 }
 
 // one read + its seed_all GEM map lines -> batch (lamsa_read_seq, src/lamsa_aln.c:927-956; split_seed :252-253,281).
-// `lines`: the read's seed_all map lines, NUL-separated.
-static void append_read_lines(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, const char *lines, int seed_all)
+// [lines, lines_end): the read's seed_all map lines as they are in the file, each ending in '\n'.
+static void append_read_lines(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, const char *lines, const char *lines_end, int seed_all)
 {
     const int L = (int)rd.seq.size();
     const uint8_t *t4 = nt4_table();
-    for (char c : rd.seq) B.read_seq.push_back(t4[(unsigned char)c]);
+    const size_t b0 = B.read_seq.size();
+    B.read_seq.resize(b0 + (size_t)L);
+    for (int i = 0; i < L; ++i) B.read_seq[b0 + (size_t)i] = t4[(unsigned char)rd.seq[(size_t)i]];
     B.read_off.push_back((int64_t)B.read_seq.size());
     B.seed_all.push_back(seed_all); B.last_len.push_back(L - P.seed_len - (seed_all - 1) * P.seed_step);
     const char *line = lines;
-    for (int sd = 0; sd < seed_all; ++sd, line += strlen(line) + 1) {
-        int ct = 0; size_t k;
-        for (k = 0; line[k]; ++k) if (line[k] == '\t') { if (ct == 3) break; ct++; }
-        if (!line[k] || line[k + 1] == '-') continue;                   // no map line content: the seed gets no slot
-        B.seed_id.push_back(sd + 1);
-        parse_gem_hits(B, ix, line + k + 1, P.per_aln_m);
-        B.hit_off.push_back((int64_t)B.h_pos.size());
+    for (int sd = 0; sd < seed_all && line < lines_end; ++sd) {
+        const char *eol = (const char *)memchr(line, '\n', (size_t)(lines_end - line));
+        if (!eol) eol = lines_end;
+        const char *q = line; int ct = 0;
+        for (; q < eol; ++q) if (*q == '\t') { if (ct == 3) break; ct++; }
+        if (q < eol && q + 1 < eol && q[1] != '-') {                    // otherwise no map content: the seed gets no slot
+            const char *he = eol; if (he > q + 1 && he[-1] == '\r') --he;
+            B.seed_id.push_back(sd + 1);
+            parse_gem_hits(B, ix, q + 1, he, P.per_aln_m);
+            B.hit_off.push_back((int64_t)B.h_pos.size());
+        }
+        line = eol + 1;
     }
     B.seed_off.push_back((int64_t)B.seed_id.size());
 }
 
 static int seeds_of(const lamsa_hp_para &P, int L) { return L < P.seed_len ? 0 : 1 + (L - P.seed_len) / P.seed_step; }
 
-// the read's map lines from the file into `raw` (NUL-separated)
-static bool read_map_lines(FILE *mapf, int seed_all, std::string &raw, std::string &err)
-{
-    static thread_local std::vector<char> line(65536);
-    raw.clear();
-    for (int sd = 0; sd < seed_all; ++sd) {
-        if (!fgets(line.data(), (int)line.size(), mapf)) { err = "seeds' GEM map result does not match the reads"; return false; }
-        size_t ll = strlen(line.data()); if (ll && line[ll - 1] == '\n') line[--ll] = 0;
-        raw.append(line.data(), ll + 1);
+// the seed-result file, mapped (or, where that fails, read) into memory: lines are handed out as spans, never copied
+struct MapText {
+    const char *p = nullptr; size_t n = 0, pos = 0; bool mapped = false; std::vector<char> owned; Prefault pf;
+    bool open(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            n = (size_t)st.st_size;
+            if (n == 0) { ::close(fd); p = ""; return true; }
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { madvise(m, n, MADV_SEQUENTIAL); p = (const char *)m; mapped = true; ::close(fd); pf.start(p, n); return true; }
+        }
+        char buf[1 << 16]; ssize_t got;                                    // a pipe or a file system without mmap
+        while ((got = ::read(fd, buf, sizeof buf)) > 0) owned.insert(owned.end(), buf, buf + got);
+        ::close(fd);
+        p = owned.data(); n = owned.size();
+        return true;
     }
-    return true;
-}
-
-bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err)
-{
-    const int seed_all = seeds_of(P, (int)rd.seq.size());
-    std::string raw;
-    if (!read_map_lines(mapf, seed_all, raw, err)) return false;
-    append_read_lines(B, ix, P, rd, raw.c_str(), seed_all);
-    B.reads.push_back(rd);
-    return true;
-}
-
-// concatenate per-thread partial batches (offsets become absolute)
-static void merge_batches(Batch &B, std::vector<Batch> &parts)
-{
-    for (Batch &p : parts) {
-        const int64_t b0 = (int64_t)B.read_seq.size(), s0 = (int64_t)B.seed_id.size(), h0 = (int64_t)B.h_pos.size(), c0 = (int64_t)B.cig.size();
-        for (size_t i = 1; i < p.read_off.size(); ++i) B.read_off.push_back(p.read_off[i] + b0);
-        for (size_t i = 1; i < p.seed_off.size(); ++i) B.seed_off.push_back(p.seed_off[i] + s0);
-        for (size_t i = 1; i < p.hit_off.size(); ++i) B.hit_off.push_back(p.hit_off[i] + h0);
-        B.read_seq.insert(B.read_seq.end(), p.read_seq.begin(), p.read_seq.end());
-        B.seed_all.insert(B.seed_all.end(), p.seed_all.begin(), p.seed_all.end());
-        B.last_len.insert(B.last_len.end(), p.last_len.begin(), p.last_len.end());
-        B.seed_id.insert(B.seed_id.end(), p.seed_id.begin(), p.seed_id.end());
-        B.h_pos.insert(B.h_pos.end(), p.h_pos.begin(), p.h_pos.end());
-        B.h_chr.insert(B.h_chr.end(), p.h_chr.begin(), p.h_chr.end());
-        B.h_strand.insert(B.h_strand.end(), p.h_strand.begin(), p.h_strand.end());
-        B.h_nm.insert(B.h_nm.end(), p.h_nm.begin(), p.h_nm.end());
-        B.h_len_dif.insert(B.h_len_dif.end(), p.h_len_dif.begin(), p.h_len_dif.end());
-        B.h_cig_n.insert(B.h_cig_n.end(), p.h_cig_n.begin(), p.h_cig_n.end());
-        for (int32_t o : p.h_cig_off) B.h_cig_off.push_back((int32_t)(o + c0));
-        B.cig.insert(B.cig.end(), p.cig.begin(), p.cig.end());
-        p.clear();
+    ~MapText() { pf.finish(); if (mapped) munmap((void *)p, n); }
+    // the next `lines` lines as [a, b); false when the file ends first
+    bool take(int lines, const char *&a, const char *&b) {
+        a = p + pos;
+        int left = lines;
+#if defined(__x86_64__)
+        static const bool avx2 = __builtin_cpu_supports("avx2");
+        if (avx2) pos = skip_lines_avx2(p, pos, n, left);
+#endif
+        for (; left > 0; --left) {
+            if (pos >= n) return false;
+            const char *nl = (const char *)memchr(p + pos, '\n', n - pos);
+            pos = nl ? (size_t)(nl - p) + 1 : n;
+        }
+        b = p + pos;
+        return true;
     }
-}
+#if defined(__x86_64__)
+    // advance over whole 32-byte blocks while they hold fewer newlines than are still wanted; `left` is updated.  The
+    // lines are ~200 bytes, so counting newlines a block at a time beats one memchr call per line.
+    __attribute__((target("avx2"))) static size_t skip_lines_avx2(const char *p, size_t pos, size_t n, int &left) {
+        const __m256i nl = _mm256_set1_epi8('\n');
+        while (left > 0 && pos + 32 <= n) {
+            const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + pos)), nl));
+            const int c = __builtin_popcount(m);
+            if (c < left) { left -= c; pos += 32; continue; }
+            unsigned mm = m;                                               // the left-th newline is inside this block
+            for (int i = 1; i < left; ++i) mm &= mm - 1;
+            pos += (size_t)__builtin_ctz(mm) + 1; left = 0;
+        }
+        return pos;
+    }
+#endif
+};
 
 template <class F> static void parallel_blocks(int n, int threads, F fn)
 {
@@ -253,6 +331,48 @@ template <class F> static void parallel_blocks(int n, int threads, F fn)
     std::vector<std::thread> th;
     const int per = (n + threads - 1) / threads;
     for (int t = 0; t < threads; ++t) { const int a = t * per, b = std::min(n, a + per); if (a < b) th.emplace_back([=]() { fn(t, a, b); }); }
+    for (auto &x : th) x.join();
+}
+
+// concatenate per-thread partial batches (offsets become absolute); every thread copies its own part
+static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
+{
+    const size_t np = parts.size();
+    std::vector<size_t> r0(np + 1, 0), b0(np + 1, 0), s0(np + 1, 0), h0(np + 1, 0), c0(np + 1, 0);
+    for (size_t i = 0; i < np; ++i) {
+        const Batch &p = parts[i];
+        r0[i + 1] = r0[i] + p.seed_all.size(); b0[i + 1] = b0[i] + p.read_seq.size(); s0[i + 1] = s0[i] + p.seed_id.size();
+        h0[i + 1] = h0[i] + p.h_pos.size(); c0[i + 1] = c0[i] + p.cig.size();
+    }
+    B.read_off.resize(r0[np] + 1); B.seed_off.resize(r0[np] + 1); B.seed_all.resize(r0[np]); B.last_len.resize(r0[np]); B.read_seq.resize(b0[np]);
+    B.seed_id.resize(s0[np]); B.hit_off.resize(s0[np] + 1);
+    B.h_pos.resize(h0[np]); B.h_chr.resize(h0[np]); B.h_strand.resize(h0[np]); B.h_nm.resize(h0[np]); B.h_len_dif.resize(h0[np]); B.h_cig_n.resize(h0[np]); B.h_cig_off.resize(h0[np]);
+    B.cig.resize(c0[np]);
+    B.read_off[0] = 0; B.seed_off[0] = 0; B.hit_off[0] = 0;
+    auto copy_parts = [&](int i0, int i1) {
+        for (int i = i0; i < i1; ++i) {
+            Batch &p = parts[(size_t)i];
+            for (size_t k = 1; k < p.read_off.size(); ++k) B.read_off[r0[i] + k] = p.read_off[k] + (int64_t)b0[i];
+            for (size_t k = 1; k < p.seed_off.size(); ++k) B.seed_off[r0[i] + k] = p.seed_off[k] + (int64_t)s0[i];
+            for (size_t k = 1; k < p.hit_off.size(); ++k) B.hit_off[s0[i] + k] = p.hit_off[k] + (int64_t)h0[i];
+            std::copy(p.read_seq.begin(), p.read_seq.end(), B.read_seq.begin() + (long)b0[i]);
+            std::copy(p.seed_all.begin(), p.seed_all.end(), B.seed_all.begin() + (long)r0[i]);
+            std::copy(p.last_len.begin(), p.last_len.end(), B.last_len.begin() + (long)r0[i]);
+            std::copy(p.seed_id.begin(), p.seed_id.end(), B.seed_id.begin() + (long)s0[i]);
+            std::copy(p.h_pos.begin(), p.h_pos.end(), B.h_pos.begin() + (long)h0[i]);
+            std::copy(p.h_chr.begin(), p.h_chr.end(), B.h_chr.begin() + (long)h0[i]);
+            std::copy(p.h_strand.begin(), p.h_strand.end(), B.h_strand.begin() + (long)h0[i]);
+            std::copy(p.h_nm.begin(), p.h_nm.end(), B.h_nm.begin() + (long)h0[i]);
+            std::copy(p.h_len_dif.begin(), p.h_len_dif.end(), B.h_len_dif.begin() + (long)h0[i]);
+            std::copy(p.h_cig_n.begin(), p.h_cig_n.end(), B.h_cig_n.begin() + (long)h0[i]);
+            for (size_t k = 0; k < p.h_cig_off.size(); ++k) B.h_cig_off[h0[i] + k] = (int32_t)(p.h_cig_off[k] + (int64_t)c0[i]);
+            std::copy(p.cig.begin(), p.cig.end(), B.cig.begin() + (long)c0[i]);
+            p.clear();
+        }
+    };
+    if (threads < 2 || h0[np] < 4096) { copy_parts(0, (int)np); return; }
+    std::vector<std::thread> th;                             // one thread per part
+    for (size_t i = 0; i < np; ++i) if (!parts[i].seed_all.empty()) th.emplace_back(copy_parts, (int)i, (int)i + 1);
     for (auto &x : th) x.join();
 }
 
@@ -470,53 +590,76 @@ int run_seeding(const Options &opt, const lamsa_hp_para &P)
 }
 
 // ------------------------------------------------------------------ chunk loop
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
 int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats)
 {
+    const double t_begin = now_s();
+    double parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0;
     Index ix; std::string err;
     if (!load_index(opt.ref_prefix, ix, err)) { fprintf(stderr, "[lamsa_aln] %s\n", err.c_str()); return 1; }
     const std::string map_path = opt.seed_result.empty() ? opt.reads + ".seed.gem.map" : opt.seed_result;
-    FILE *mapf = fopen(map_path.c_str(), "r");
-    if (!mapf) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
+    MapText mapt;
+    if (!mapt.open(map_path)) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
     FastxReader fx;
-    if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); fclose(mapf); return 1; }
+    if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
     lamsa_hp_ref ref; ref.pac = ix.pac.data(); ref.l_pac = ix.l_pac; ref.n_seqs = (int32_t)ix.name.size(); ref.seq_offset = ix.off.data(); ref.seq_len = ix.len.data();
     lamsa_hp_handle *h = nullptr;
-    int rc = lamsa_hp_create(&h, &P, &ref, opt.device);
-    if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] no usable MI355X / HIP device (lamsa_hp_create: %d); this build has no CPU path\n", rc); fclose(mapf); return 2; }
+    int rc = opt.parse_only ? LAMSA_HP_OK : lamsa_hp_create(&h, &P, &ref, opt.device);
+    if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] no usable MI355X / HIP device (lamsa_hp_create: %d); this build has no CPU path\n", rc); return 2; }
+    const double load_s = now_s() - t_begin;
     std::string sam;
     sam_header(sam, ix, pg_line);
     fwrite(sam.data(), 1, sam.size(), out);
     long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
     const int threads = opt.n_thread > 0 ? opt.n_thread : 1;
     bool eof = false; int ret = 0;
-    // One chunk = reads + their hit records, ready for the GPU.  The next chunk is read and parsed (on all host
-    // threads) while the GPU works on the current one and while the previous one's SAM text is formatted.
-    struct Chunk { Batch B; int ret = 0; };
-    auto prepare = [&]() -> std::unique_ptr<Chunk> {
-        std::unique_ptr<Chunk> c(new Chunk);
+    // One chunk = reads + their hit records, ready for the GPU.  Four stages overlap: the sequential pass over the
+    // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
+    // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
+    // The chunk buffers are recycled.
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; };
+    Chunk pool[5]; int n_scanned = 0;
+    std::vector<Batch> parts((size_t)threads);              // per-thread partial batches of the parse, recycled too
+    const bool trace = getenv("LAMSA_TRACE") != nullptr;
+    auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
+        Chunk *c = &pool[n_scanned++ % 5];
         Batch &B = c->B;
-        B.clear();
+        B.clear(); c->ret = 0; c->span.clear();
         if (eof) return c;
-        std::vector<std::string> raw;                   // the chunk's GEM map lines, per read
-        Read rd; std::string e;
+        const double t0 = now_s();
+        Read rd;
         int64_t chunk_bases = 0;
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
             if (!fx.next(rd)) { eof = true; break; }
-            raw.emplace_back();
-            if (!read_map_lines(mapf, seeds_of(P, (int)rd.seq.size()), raw.back(), e)) { fprintf(stderr, "[lamsa_read_seq] %s\n", e.c_str()); c->ret = 1; return c; }
-            B.reads.push_back(rd);
+            const char *la, *lb;
+            if (!mapt.take(seeds_of(P, (int)rd.seq.size()), la, lb)) { fprintf(stderr, "[lamsa_read_seq] seeds' GEM map result does not match the reads\n"); c->ret = 1; eof = true; return c; }
+            c->span.emplace_back(la, lb);
             chunk_bases += (int64_t)rd.seq.size();
+            B.reads.emplace_back(); std::swap(B.reads.back(), rd);
         }
+        if (trace) fprintf(stderr, "[scan] %d reads in %.3f s\n", (int)B.reads.size(), now_s() - t0);
+        return c;
+    };
+    std::future<Chunk *> scanned = std::async(std::launch::async, scan);
+    auto prepare = [&]() -> Chunk * {
+        const double t0 = now_s();
+        Chunk *c = scanned.get();
+        scanned = std::async(std::launch::async, scan);      // the following chunk is cut while this one is parsed
+        Batch &B = c->B;
         const int n = (int)B.reads.size();
-        if (n == 0) return c;
+        if (n == 0 || c->ret) return c;
+        const double t1 = now_s();
         // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
-        std::vector<Batch> parts((size_t)threads);
         for (Batch &p : parts) p.clear();
         parallel_blocks(n, threads, [&](int t, int r0, int r1) {
-            for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], raw[(size_t)r].c_str(), seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
+            for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], c->span[(size_t)r].first, c->span[(size_t)r].second, seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
         });
-        merge_batches(B, parts);
+        const double t2 = now_s();
+        merge_batches(B, parts, threads);
+        if (trace) fprintf(stderr, "[prepare] waited %.3f s for the scan, parse %.3f, merge %.3f\n", t1 - t0, t2 - t1, now_s() - t2);
         for (int32_t ch : B.h_chr) if (ch < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); c->ret = 1; break; }
+        parse_s += now_s() - t0;                            // one prepare() runs at a time
         return c;
     };
     auto submit = [&](Batch &B) -> int {
@@ -529,14 +672,19 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_off = &zero32; hb.h_cig_n = &zero8; }
         if (!hb.cig) hb.cig = &zero32;
         if (!hb.read_seq) hb.read_seq = &zero8;
+        const double t0 = now_s();
         const int e = lamsa_hp_submit_batch(h, &hb);
+        submit_s += now_s() - t0;
         if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_submit_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
         return 0;
     };
     // records -> MAPQ / XA -> SAM text, on all host threads; written in input order
     auto collect_and_write = [&](Batch &B) -> int {
         lamsa_hp_result res;
+        const double t0 = now_s();
         const int e = lamsa_hp_collect_batch(h, &res);
+        const double t1 = now_s();
+        wait_s += t1 - t0;
         if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
         kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
         const int n = (int)B.reads.size();
@@ -556,28 +704,40 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (int t = 0; t < threads; ++t) { fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
+        sam_s += now_s() - t1;
         return 0;
     };
     // Two chunks are in flight on the device (lamsa_hp_submit_batch): while the GPU aligns chunk i-1, chunk i is
     // uploaded behind it, chunk i+1 is read and parsed, and -- once collected -- chunk i-1's SAM text is written.
-    std::future<std::unique_ptr<Chunk>> next = std::async(std::launch::async, prepare);
-    std::unique_ptr<Chunk> flying;                           // submitted, not yet collected
+    if (opt.parse_only) {
+        for (;;) {
+            Chunk *c = prepare();
+            if (c->ret || c->B.reads.empty()) { ret = c->ret; break; }
+            n_reads += (long)c->B.reads.size(); for (const Read &q : c->B.reads) n_bases += (long)q.seq.size();
+        }
+        if (scanned.valid()) scanned.wait();
+        if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; }
+        return ret;
+    }
+    std::future<Chunk *> next = std::async(std::launch::async, prepare);
+    Chunk *flying = nullptr;                                 // submitted, not yet collected
     for (;;) {
-        std::unique_ptr<Chunk> cur = next.get();
+        Chunk *cur = next.get();
         if (cur->ret) ret = cur->ret;
         const bool have = ret == 0 && !cur->B.reads.empty();
         if (have) {
             next = std::async(std::launch::async, prepare);  // overlaps with everything below
             ret = submit(cur->B);
         }
-        if (flying) { const int e = collect_and_write(flying->B); if (e && !ret) ret = e; flying.reset(); }
+        if (flying) { const int e = collect_and_write(flying->B); if (e && !ret) ret = e; flying = nullptr; }
         if (!have || ret) break;
-        flying = std::move(cur);
+        flying = cur;
     }
-    if (next.valid()) next.wait();                       // the reader thread must be done before the files are closed
+    if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
+    if (scanned.valid()) scanned.wait();
     lamsa_hp_destroy(h);
-    fclose(mapf);
-    if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms; }
+    if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
+                 stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; }
     return ret;
 }
 

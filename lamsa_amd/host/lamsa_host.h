@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/lamsa_hp.h"
@@ -29,16 +30,24 @@ class FastxReader {
     Impl *p;
 };
 
+// vector whose resize() leaves new elements uninitialised: the batch arrays are sized once per chunk and then filled
+// by all host threads, and a chunk's buffers are recycled, so nothing is ever zero-filled or page-faulted twice
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&... a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
 struct Batch {                       // the arrays of lamsa_hp_batch, host side
     std::vector<Read> reads;
-    std::vector<int64_t> read_off, seed_off, hit_off, h_pos;
-    std::vector<uint8_t> read_seq, h_cig_n;
-    std::vector<int32_t> seed_all, last_len, seed_id, h_chr, h_cig_off, cig;
-    std::vector<int16_t> h_nm, h_len_dif;
-    std::vector<int8_t> h_strand;
+    RawVec<int64_t> read_off, seed_off, hit_off, h_pos;
+    RawVec<uint8_t> read_seq, h_cig_n;
+    RawVec<int32_t> seed_all, last_len, seed_id, h_chr, h_cig_off, cig;
+    RawVec<int16_t> h_nm, h_len_dif;
+    RawVec<int8_t> h_strand;
     void clear();
 };
-bool append_read(Batch &B, const Index &ix, const lamsa_hp_para &P, const Read &rd, FILE *mapf, std::string &err);
 
 struct Rec { int64_t offset = 0; int chr = 0, nstrand = 0, score = 0, NM = 0, reg_beg = 0, reg_end = 0; std::vector<int32_t> cigar; };   // res_t
 struct XaRef { int st, li, ri; };
@@ -54,11 +63,13 @@ struct Options {
     // seeding front end (lamsa_aln_c, src/lamsa_aln.c:1224-1275): -N reuses <reads>.seed.gem.map, otherwise the read file is
     // cut into seeds and the GEM mapper of the reference's bundle is run on them
     int no_seed_aln = 0, fastest = 0;
+    int parse_only = 0;                                   // --parse-only: read and parse the inputs, no GPU work, no output (ingest timing)
     float ed_rate = -1, mis_rate = -1, mat_rate = -1;     // -e, -x; defaults per read type (src/lamsa_aln.h:26-70)
     std::string gem_dir;                                  // directory holding gem-mapper (default: <directory of this binary>/gem)
     int chunk_reads = 16384; int64_t chunk_bases = 256ll << 20;     // reads per GPU batch (the reference's CHUNK_READ_N is 128 per thread pool)
 };
-struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0; };
+struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
+               double wall_s = 0, load_s = 0, parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0; };   // where the chunk loop's time went
 
 void sam_header(std::string &o, const Index &ix, const std::string &pg);
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);

@@ -19,6 +19,7 @@ static int usage()
     fprintf(stderr, "\nUsage:   lamsa aln [options] <ref.fa> <read.fa/fq>\n\n"
                     "         options of the reference's `lamsa aln` (-t -l -i -p -V -v -s -R -k -f -m -M -O -E -w -b -e -d -x -T -r -g -S -C -o -N -I);\n"
                     "         additionally --device INT (GPU ordinal), --seed-result FILE (GEM map to use instead of seeding), --gem-dir DIR (where gem-mapper lives),\n"
+                    "         --parse-only (read and parse the inputs, print the ingest time; no GPU work, no output),\n"
                     "         --batch INT (reads per GPU batch)\n\n");
     return 1;
 }
@@ -39,7 +40,7 @@ int main(int argc, char *argv[])
         {"max-skel",1,0,'s'},{"max-reg",1,0,'R'},{"bwt-kmer",1,0,'k'},{"fastest",0,0,'f'},{"ed-rate",1,0,'e'},{"diff-rate",1,0,'d'},
         {"mis-rate",1,0,'x'},{"read-type",1,0,'T'},{"match-sc",1,0,'m'},{"mis-pen",1,0,'M'},{"open-pen",1,0,'O'},{"ext-pen",1,0,'E'},
         {"band-width",1,0,'w'},{"end-bonus",1,0,'b'},{"max-out",1,0,'r'},{"gap-split",1,0,'g'},{"soft-clip",0,0,'S'},{"comment",0,0,'C'},
-        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"gem-dir",1,0,1003},{"seed-result",1,0,1001},{"batch",1,0,1002},{0,0,0,0}};
+        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"gem-dir",1,0,1003},{"seed-result",1,0,1001},{"batch",1,0,1002},{"parse-only",0,0,1004},{0,0,0,0}};
     optind = 2;
     while ((c = getopt_long(argc, argv, "t:l:i:p:V:v:s:R:k:fm:M:O:E:w:b:e:d:x:T:r:g:SCo:hHNI", lopt, NULL)) >= 0) {
         switch (c) {
@@ -82,6 +83,7 @@ int main(int argc, char *argv[])
         case 'I': break;                                            // seed info is recomputed from the read lengths either way
         case 1000: opt.device = atoi(optarg); break;
         case 1003: opt.gem_dir = optarg; break;
+            case 1004: opt.parse_only = 1; break;
         case 1001: opt.seed_result = optarg; break;
         case 1002: opt.chunk_reads = atoi(optarg) > 0 ? atoi(optarg) : opt.chunk_reads; break;
         default: return usage();
@@ -101,6 +103,8 @@ int main(int argc, char *argv[])
     fprintf(stderr, "[lamsa_aln] Mapping reads to genome ...\n");
     int rc = lamsa::run_aln(opt, P, out, pg, &st);
     fprintf(stderr, "[lamsa_aln] Mapping done! %ld reads, %ld bases, GPU kernels %.1f ms%s\n", st.n_reads, st.n_bases, st.kernel_ms, st.n_bad ? " (some reads reported unmapped, see above)" : "");
+    fprintf(stderr, "[lamsa_aln] wall %.2f s: index load + device setup %.2f; in the chunk loop (overlapping): read + parse %.2f, check + upload %.2f, wait for the GPU %.2f, rank + SAM %.2f\n",
+            st.wall_s, st.load_s, st.parse_s, st.submit_s, st.wait_s, st.sam_s);
     if (out != stdout) fclose(out);
     return rc;
 }

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Time the product binary end to end on files (run on the GPU box): simulated reads + hits written as the files
+`lamsa aln -N` reads (FASTA, GEM map text, .pac/.ann), then `lamsa_amd/bin/lamsa aln -N ...` on them, page cache warm.
+Prints the binary's own stage accounting and reads/s.  usage: tools/cli_bench.py [n_reads] [read_len] [ref_bp] [reads per chunk]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import simbatch   # noqa: E402
+import simfiles   # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+ref_bp = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000_000
+threads = os.cpu_count() or 8
+d = tempfile.mkdtemp(prefix="clib_", dir=os.environ.get("TMPDIR", "/tmp"))
+t = time.time(); ref = simbatch.SimRef(ref_bp, n_contigs=24, seed=5, threads=min(threads, 16))
+B = simbatch.SimBatch(ref, n, L, "ont2d", seed=31, threads=min(threads, 16))
+simfiles.write_index(d + "/ref.fa", ref); simfiles.write_reads(d + "/reads.fa", B)
+print("files written in %.1f s: %d reads, %.0f hits/read, map %.1f MB" % (time.time() - t, n, B.n_hits / n, os.path.getsize(d + "/reads.fa.seed.gem.map") / 1e6), flush=True)
+batch = sys.argv[4] if len(sys.argv) > 4 else "2048"
+for rep, extra in enumerate((["--parse-only"], [], [])):
+    t = time.time()
+    p = subprocess.run([os.path.join(ROOT, "lamsa_amd", "bin", "lamsa"), "aln", "-N", "-T", "ont2d", "-R", "0", "--batch", batch, "-o", d + "/out.sam"] + extra + [d + "/ref.fa", d + "/reads.fa"],
+                       capture_output=True, text=True, env=dict(os.environ, LAMSA_TRACE="1"))
+    dt = time.time() - t
+    print("run %d %s: rc %d, %.2f s wall -> %.0f reads/s end to end" % (rep, " ".join(extra), p.returncode, dt, n / dt))
+    print("\n".join(l for l in p.stderr.splitlines() if "wall" in l or "Mapping done" in l or "failed" in l or "[prepare]" in l), flush=True)
+print("SAM %.1f MB" % (os.path.getsize(d + "/out.sam") / 1e6))
