@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ont10k", choices=sorted(WORKLOADS))
-    ap.add_argument("--reads", type=int, default=32768, help="reads per batch (= per step) and per GPU")
+    ap.add_argument("--reads", type=int, default=65536, help="reads per batch (= per step) and per GPU; the metric's configuration is 1 M reads over 8 GPUs = 125 k per GPU, "
+                    "and one batch holds at most 2^31 seed CIGAR words (~ 125 k reads of this kind)")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
     ap.add_argument("--stream-chunks", type=int, default=4, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "

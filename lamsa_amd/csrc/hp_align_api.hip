@@ -8,6 +8,7 @@
 #include <atomic>
 #include <map>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 #include "hp_align.h"
 #include "hp_handle.h"
@@ -31,33 +32,47 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
     }
 }
 
-struct OutDev {                   // result arrays of one launch: per-read offset / length / status + the stream arena
-    DevBuf buf; int64_t stream_cap = 0;
-    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n); }
-    int ensure(int n, int64_t cap) { stream_cap = cap; return buf.ensure(hdr(n) + 4 * (size_t)cap + 256); }
-    int64_t *off() const { return (int64_t *)buf.p; }
-    int32_t *len(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n)); }
-    int32_t *st(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n) + al256(4 * (size_t)n)); }
-    int32_t *tb(int n) const { return (int32_t *)((char *)buf.p + al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n)); }
-    int32_t *stream(int n) const { return (int32_t *)((char *)buf.p + hdr(n)); }
-};
-
-struct HostBuf {                  // page-locked host memory for the result stream: device-to-host copies at the PCIe rate
-    void *p = nullptr; size_t cap = 0;
+struct HostBuf {                  // page-locked host memory, mapped into the device's address space
+    void *p = nullptr, *dev = nullptr; size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) hipHostFree(p);
-        p = nullptr; cap = 0;
+        p = dev = nullptr; cap = 0;
         size_t want = bytes + bytes / 4 + 256;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+        if (hipHostMalloc(&p, want, hipHostMallocMapped) != hipSuccess) { p = nullptr; return -1; }
+        if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) { hipHostFree(p); p = nullptr; return -1; }
         cap = want;
         return 0;
     }
-    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) hipHostFree(p); p = dev = nullptr; cap = 0; }
+};
+
+// Result arrays of one launch.  The stream arena is in HBM and fetched with one large copy.  The per-read offset /
+// length / status / bases arrays (20 B per read) are written by the kernel straight into mapped host memory: a small
+// device-to-host copy is a runtime kernel launch that, measured, does not start while another batch's persistent
+// grid is running (a 0.6 GB copy took 10 ms beside it, five 0.5 MB ones 380 ms).
+struct OutDev {
+    DevBuf buf; HostBuf host; int64_t stream_cap = 0; int n_cap = 0;
+    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n); }
+    int ensure(int n, int64_t cap) { stream_cap = cap; n_cap = n; return buf.ensure(4 * (size_t)cap + 256) || host.ensure(hdr(n) + 256); }
+    // device-visible addresses (kernel arguments)
+    int64_t *off() const { return (int64_t *)host.dev; }
+    int32_t *len(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n)); }
+    int32_t *st(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n) + al256(4 * (size_t)n)); }
+    int32_t *tb(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n)); }
+    // the same arrays as the host sees them (valid once the launch has completed)
+    const int64_t *h_off() const { return (const int64_t *)host.p; }
+    const int32_t *h_len(int n) const { return (const int32_t *)((const char *)host.p + al256(8 * (size_t)n)); }
+    const int32_t *h_st(int n) const { return (const int32_t *)((const char *)host.p + al256(8 * (size_t)n) + al256(4 * (size_t)n)); }
+    const int32_t *h_tb(int n) const { return (const int32_t *)((const char *)host.p + al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n)); }
+    int32_t *stream(int) const { return (int32_t *)buf.p; }
+    void release() { buf.release(); host.release(); }
 };
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
-    DevBuf bin, misc; OutDev out1;
+    DevBuf bin, misc, slab; OutDev out1;
+    hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
+                                  // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
     int32_t n_reads = 0; int64_t n_bases = 0, n_cig = 0;
     BatchIn in; const int32_t *d_order = nullptr;
@@ -70,10 +85,11 @@ struct Slot {                     // one batch on the device: its inputs, the ou
 struct AlignState {
     Slot slot[2];                 // two batches: one computing, one being uploaded (lamsa_hp_submit_batch)
     int fifo[2] = {0, 0}, n_fifo = 0;          // submitted and not yet collected, oldest first
-    DevBuf slab, retry_list;      // shared by all launches: they are ordered on the one compute stream
+    DevBuf retry_list;            // second passes run one at a time (inside collect / run_uploaded)
     OutDev out2;
     // host copies of the results
-    HostBuf stream; std::vector<int32_t> r_len, r_st, r_tb; std::vector<int64_t> r_off;
+    HostBuf stream;               // page-locked: the result stream
+    std::vector<int32_t> r_len, r_st, r_tb; std::vector<int64_t> r_off;
 };
 
 static std::map<lamsa_hp_handle *, AlignState *> g_states;     // per-handle state of the align entry points
@@ -89,17 +105,18 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     if (it == g_states.end()) return;
     AlignState *S = it->second;
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.out1.buf.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
-    S->slab.release(); S->retry_list.release(); S->out2.buf.release(); S->stream.release();
+    if (h->stream_b) hipStreamSynchronize(h->stream_b);
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
+    S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
     g_states.erase(it);
 }
 
-// grow a device buffer that a queued kernel may still be using: drain the compute stream first
+// grow a device buffer that a queued kernel may still be using: drain both compute streams first
 static int grow(lamsa_hp_handle *h, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return 0;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipStreamSynchronize(h->stream_b) != hipSuccess) return -1;
     return b.ensure(bytes);
 }
 
@@ -124,6 +141,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     // ---- validate everything the kernels index with, on the host, before anything is launched
     S->h_len.assign((size_t)n, 0); S->h_H.assign((size_t)n, 0); S->max_L = 0; S->max_H = 0;
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
+    if (B->n_cig < 0 || B->n_cig > 0x7fffffffll) { h->err = "more than 2^31-1 seed CIGAR words in one batch (h_cig_off is 32-bit): split the batch"; return LAMSA_HP_EINVAL; }
     {
         std::atomic<int> bad(0);                         // 1..6: which check failed (the first one reported wins)
         std::atomic<long long> max_pos(0);
@@ -207,16 +225,17 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 // one launch over `n_units` reads of the batch in slot `T` (order list on the device); results into `O`.  The kernel
 // is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
 static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
-                        hipEvent_t e0, hipEvent_t e1, bool wait)
+                        hipEvent_t e0, hipEvent_t e1, bool wait, int spare_waves = 0)
 {
     size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
     if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     int n_waves = h->n_cu * per_cu;
+    if (n_waves > 4 * spare_waves) n_waves -= spare_waves;      // streaming: wave slots left free for the runtime's copy kernels (see start_main)
     if (n_waves > n_units) n_waves = n_units;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    if (grow(h, S->slab, slab_per_wave * (size_t)n_waves) || T.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    if (grow(h, T.slab, slab_per_wave * (size_t)n_waves) || T.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     const int n = T.n_reads;
     AlignArgs a;
     a.P = h->para;
@@ -224,14 +243,14 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, c
     a.in = T.in;
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)T.misc.p + 64);
-    a.slab = (char *)S->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)T.misc.p;
+    a.slab = (char *)T.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)T.misc.p;
     a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
 #ifdef HP_PROF
     static DevBuf profbuf;
     if (profbuf.ensure(sizeof(long long) * 64 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 64 * (size_t)n); a.prof = (long long *)profbuf.p; }
     wait = true;
 #endif
-    hipStream_t s = h->stream;
+    hipStream_t s = T.cs;
     HIPCHK(h, hipMemsetAsync(T.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
@@ -242,6 +261,12 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, c
     if (a.prof) {
         std::vector<long long> pr((size_t)n * 64);
         hipMemcpy(pr.data(), a.prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost);
+        if (const char *dump = getenv("LAMSA_HP_PROF_DUMP")) {          // per read: H, L, then the 64 counters
+            if (FILE *fp = fopen(dump, "wb")) {
+                for (int r = 0; r < n; ++r) { long long hl[2] = {T.h_H[r], T.h_len[r]}; fwrite(hl, 8, 2, fp); fwrite(&pr[(size_t)r * 64], 8, 64, fp); }
+                fclose(fp);
+            }
+        }
         std::vector<int> idx((size_t)n); for (int i = 0; i < n; ++i) idx[i] = i;
         auto tot = [&](int r) { long long t = 0; for (int k = 0; k < 6; ++k) t += pr[(size_t)r * 64 + k]; return t; };
         std::sort(idx.begin(), idx.end(), [&](int x, int y) { return tot(x) > tot(y); });
@@ -264,20 +289,24 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, c
 
 static int slot_events(lamsa_hp_handle *h, Slot &T)
 {
+    T.cs = &T == &state_of(h)->slot[1] ? h->stream_b : h->stream;
     if (!T.e0) HIPCHK(h, hipEventCreate(&T.e0), LAMSA_HP_EKERNEL);
     if (!T.e1) HIPCHK(h, hipEventCreate(&T.e1), LAMSA_HP_EKERNEL);
     return LAMSA_HP_OK;
 }
 
 // queue the main pass of the batch in slot `T`: every read, costliest first
-static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T)
+// `streaming`: the persistent grid fills every wave slot of the device and holds it until the batch is done; the
+// runtime's device-to-host copies are kernels too and would wait for that.  When results of the previous batch are
+// fetched while this one runs, a few slots stay free so that those copies start at once (64 of 4 096: -1.6 % waves).
+static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, bool streaming = false)
 {
     int rc = slot_events(h, T);
     if (rc) return rc;
     const int n = T.n_reads;
     if (n == 0) return LAMSA_HP_OK;
     if (T.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
-    return launch_align(h, S, T, T.out1, T.d_order, n, 1, T.max_L, T.max_H, T.e0, T.e1, false);
+    return launch_align(h, S, T, T.out1, T.d_order, n, 1, T.max_L, T.max_H, T.e0, T.e1, false, streaming ? 64 : 0);
 }
 
 #define DL(dst, src, bytes) HIPCHK(h, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->copy_stream), LAMSA_HP_EKERNEL)
@@ -298,31 +327,29 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_resu
     HIPCHK(h, hipEventSynchronize(T.e1), LAMSA_HP_EKERNEL);
     const double t_1 = now_s();
     hipEventElapsedTime(&h->kernel_ms[0], T.e0, T.e1);
-    unsigned long long used1 = 0;
-    DL(&used1, (char *)T.misc.p + 64, 8);
-    DL(S->r_st.data(), T.out1.st(n), 4 * (size_t)n); DL(S->r_off.data(), T.out1.off(), 8 * (size_t)n);
-    DL(S->r_len.data(), T.out1.len(n), 4 * (size_t)n); DL(S->r_tb.data(), T.out1.tb(n), 4 * (size_t)n);
-    DLSYNC();
+    // the per-read arrays are in mapped host memory already (OutDev); the slot may be reused while the caller still
+    // reads the results, so they are copied out
+    memcpy(S->r_off.data(), T.out1.h_off(), 8 * (size_t)n); memcpy(S->r_len.data(), T.out1.h_len(n), 4 * (size_t)n);
+    memcpy(S->r_st.data(), T.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), T.out1.h_tb(n), 4 * (size_t)n);
+    unsigned long long used1 = 0;                        // the arena is handed out front to back: its fill is the largest end
+    for (int r = 0; r < n; ++r) if (S->r_off[r] >= 0 && (unsigned long long)(S->r_off[r] + S->r_len[r]) > used1) used1 = (unsigned long long)(S->r_off[r] + S->r_len[r]);
     if ((int64_t)used1 > T.out1.stream_cap) used1 = (unsigned long long)T.out1.stream_cap;
     // ---- retry pass: reads whose work buffers (or the stream arena) were too small -- outliers; 8x capacities.
-    // It is queued behind whatever the compute stream already holds (the next batch's main pass, when streaming).
+    // On this slot's own stream: it runs beside the other slot's main pass when streaming.
     std::vector<int32_t> again;
     for (int r = 0; r < n; ++r) if ((S->r_st[r] & LAMSA_HP_ST_OVERFLOW) || S->r_off[r] < 0) again.push_back(r);
     unsigned long long used2 = 0;
     if (!again.empty()) {
         int mL = 0, mH = 0; int64_t cap2 = 1024;
         for (int r : again) { mL = std::max(mL, T.h_len[r]); mH = std::max(mH, T.h_H[r]); cap2 += 64 + 12LL * 8 * T.h_len[r]; }
-        if (grow(h, S->out2.buf, OutDev::hdr(n) + 4 * (size_t)cap2 + 256) || grow(h, S->retry_list, 4 * again.size())) { h->err = "hipMalloc(retry)"; return LAMSA_HP_ENOMEM; }
+        if (grow(h, S->out2.buf, 4 * (size_t)cap2 + 256) || S->out2.host.ensure(OutDev::hdr(n) + 256) || grow(h, S->retry_list, 4 * again.size())) { h->err = "hipMalloc(retry)"; return LAMSA_HP_ENOMEM; }
         S->out2.stream_cap = cap2;
-        HIPCHK(h, hipMemcpyAsync(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice, h->stream), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice, T.cs), LAMSA_HP_EKERNEL);
         int rc = launch_align(h, S, T, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, h->ev0, h->ev1, true);
         if (rc) return rc;
         hipEventElapsedTime(&h->kernel_ms[1], h->ev0, h->ev1);
-        std::vector<int64_t> off2((size_t)n); std::vector<int32_t> len2((size_t)n), st2((size_t)n), tb2((size_t)n);
-        DL(&used2, (char *)T.misc.p + 64, 8);
-        DL(st2.data(), S->out2.st(n), 4 * (size_t)n); DL(off2.data(), S->out2.off(), 8 * (size_t)n);
-        DL(len2.data(), S->out2.len(n), 4 * (size_t)n); DL(tb2.data(), S->out2.tb(n), 4 * (size_t)n);
-        DLSYNC();
+        const int64_t *off2 = S->out2.h_off(); const int32_t *len2 = S->out2.h_len(n), *st2 = S->out2.h_st(n), *tb2 = S->out2.h_tb(n);
+        for (int r : again) if (off2[r] >= 0 && (unsigned long long)(off2[r] + len2[r]) > used2) used2 = (unsigned long long)(off2[r] + len2[r]);
         if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
         for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
     }
@@ -385,7 +412,7 @@ extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     const int k = S->n_fifo == 1 ? 1 - S->fifo[0] : 0;         // the slot no queued kernel reads
     rc = upload_into(h, &S->slot[k], B);                         // overlaps the kernel of the other slot
     if (rc) return rc;
-    rc = start_main(h, S, S->slot[k]);
+    rc = start_main(h, S, S->slot[k], true);
     if (rc) { S->slot[k].valid = false; return rc; }
     S->fifo[S->n_fifo++] = k;
     return LAMSA_HP_OK;

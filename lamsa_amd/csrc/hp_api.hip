@@ -42,7 +42,7 @@ extern "C" int lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para,
     h->device = device_id; h->para = *para;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return LAMSA_HP_ENODEV; }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return LAMSA_HP_ENODEV; }
     if (ref && ref->pac) {
         size_t pb = (size_t)(ref->l_pac / 4 + 1);
         h->l_pac = ref->l_pac; h->n_seqs = ref->n_seqs;
@@ -71,6 +71,7 @@ extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->stream_b) hipStreamDestroy(h->stream_b);
     delete h;
 }
 

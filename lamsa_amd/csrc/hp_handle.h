@@ -24,7 +24,8 @@ struct DevBuf {
 struct lamsa_hp_handle {
     int device = 0;
     lamsa_hp_para para;
-    hipStream_t stream = nullptr;          // compute: every kernel of this handle, in order
+    hipStream_t stream = nullptr;          // compute: the DP batches and the align kernels of batch slot 0, in order
+    hipStream_t stream_b = nullptr;        // compute: the align kernels of batch slot 1 (lamsa_hp_submit_batch alternates the slots)
     hipStream_t copy_stream = nullptr;     // batch uploads and result downloads, concurrent with the compute stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
