@@ -110,13 +110,14 @@ def job_rates(dt, totals, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ont10k", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=65536, help="reads per batch (= per step) and per GPU; the metric's configuration is 1 M reads over 8 GPUs = 125 k per GPU, "
                     "and one batch holds at most 2^31 seed CIGAR words (~ 125 k reads of this kind)")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--sequential", action="store_true", help="wait for every step before starting the next (default: consecutive steps are queued two deep)")
     ap.add_argument("--stream-chunks", type=int, default=4, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
                     "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
@@ -164,14 +165,32 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        h.run_uploaded(fetch=True, raw=True)
-    kernel_ms = []
+    def run_steps(k):
+        """k passes over the resident batch, results fetched into host memory every time.  Consecutive passes are queued
+        two deep (lamsa_hp_start_uploaded / finish_uploaded) like the kernels of consecutive training steps: the waves
+        of pass i+1 start on the SIMDs that the tail of pass i leaves idle.  --sequential waits for every pass instead."""
+        ms, raw = [], None
+        if a.sequential or k < 2:
+            for _ in range(k):
+                raw = h.run_uploaded(fetch=True, raw=True)      # kernels + download of the result streams into host memory
+                ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+            return ms, raw
+        h.start_uploaded()
+        for _ in range(k - 1):
+            h.start_uploaded()
+            raw = h.finish_uploaded(fetch=True, raw=True)
+            ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+        raw = h.finish_uploaded(fetch=True, raw=True)
+        ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+        return ms, raw
+
+    if not a.sequential:                                # set-up, untimed: both launch lanes allocate their scratch and output buffers
+        h.start_uploaded(); h.start_uploaded(); h.finish_uploaded(fetch=False); h.finish_uploaded(fetch=False)
+    if a.warmup:
+        run_steps(a.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        raw = h.run_uploaded(fetch=True, raw=True)          # kernels + download of the result streams into host memory
-        kernel_ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+    kernel_ms, raw = run_steps(a.steps)
     sync()
     dt = time.perf_counter() - t0
     stream, r_off, r_len, status = raw

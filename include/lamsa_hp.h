@@ -154,6 +154,10 @@ int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_
  * (res may be NULL: results stay on the device and are not fetched). */
 int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch);
 int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
+/* run_uploaded in two halves, two runs deep: start queues a run of the resident batch and returns; finish waits for
+ * the oldest run and fetches its results (res may be NULL).  The second run's waves start as the first one's drain. */
+int lamsa_hp_start_uploaded(lamsa_hp_handle *h);
+int lamsa_hp_finish_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
 
 /* The streaming form, for the chunk loop of lamsa_aln_core (src/lamsa_aln.c:1140-1170): the reference overlaps nothing
  * (read chunk -> threads -> join -> print); here up to two chunks are in flight per handle.

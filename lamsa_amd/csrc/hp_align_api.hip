@@ -27,10 +27,18 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
         int u = 0;
         if (wv::leader()) u = atomicAdd(a.counter, 1);
         u = wv::uni(u);
-        if (u >= a.n_units) break;          // every wave reaches this exit: the queue head only grows
+        if (u >= a.n_units) {               // every wave reaches this exit: the queue head only grows
+            // the queue is empty: from now on wave slots fall idle.  Tell the stream that holds the next launch back
+            // (hipStreamWaitValue32 in launch_align) so that its waves move in exactly now.
+            if (a.drained && wv::leader()) __hip_atomic_store(a.drained, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         align_read(a, a.order ? a.order[u] : u, slot, (HP_L int32_t *)lds);
     }
 }
+
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
 
 struct HostBuf {                  // page-locked host memory, mapped into the device's address space
     void *p = nullptr, *dev = nullptr; size_t cap = 0;
@@ -71,6 +79,8 @@ struct OutDev {
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
     DevBuf bin, misc, slab; OutDev out1;
+    uint32_t *sig = nullptr;      // signal memory: the generation of the last main pass of this slot whose read queue ran empty
+    uint32_t busy_gen = 0;        // generation of the main pass queued on this slot and not yet finished (0: none)
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
@@ -85,6 +95,8 @@ struct Slot {                     // one batch on the device: its inputs, the ou
 struct AlignState {
     Slot slot[2];                 // two batches: one computing, one being uploaded (lamsa_hp_submit_batch)
     int fifo[2] = {0, 0}, n_fifo = 0;          // submitted and not yet collected, oldest first
+    uint32_t gen = 0; int can_wait = -1;      // launch generations; whether the device has hipStreamWaitValue32
+    int res_fifo[2] = {0, 0}, n_res = 0;       // runs of the resident batch (slot 0) started and not yet finished: the lane each uses
     DevBuf retry_list;            // second passes run one at a time (inside collect / run_uploaded)
     OutDev out2;
     // host copies of the results
@@ -106,7 +118,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     AlignState *S = it->second;
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); if (T.sig) hipFree(T.sig); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
     g_states.erase(it);
@@ -129,8 +141,6 @@ static size_t slab_bytes_for(const lamsa_hp_para &P, int L, int H, int scale)
 }
 
 // validate `B`, build its processing order and sort index, copy it into slot `T` on the copy stream
-static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
-static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
 
 static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 {
@@ -222,9 +232,10 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     return LAMSA_HP_OK;
 }
 
-// one launch over `n_units` reads of the batch in slot `T` (order list on the device); results into `O`.  The kernel
+// one launch over `n_units` reads of the batch in slot `T` (order list on the device) with the launch resources
+// (scratch slab, queue head, stream, events) of slot `Ln`; results into `O`.  The kernel
 // is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
-static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
+static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
                         hipEvent_t e0, hipEvent_t e1, bool wait, int spare_waves = 0)
 {
     size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
@@ -235,23 +246,46 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, c
     if (n_waves > 4 * spare_waves) n_waves -= spare_waves;      // streaming: wave slots left free for the runtime's copy kernels (see start_main)
     if (n_waves > n_units) n_waves = n_units;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    if (grow(h, T.slab, slab_per_wave * (size_t)n_waves) || T.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     const int n = T.n_reads;
     AlignArgs a;
     a.P = h->para;
     a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
     a.in = T.in;
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
-    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)T.misc.p + 64);
-    a.slab = (char *)T.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)T.misc.p;
+    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64);
+    a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)Ln.misc.p;
     a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
+    a.drained = nullptr; a.gen = 0;
+    hipStream_t s = Ln.cs;
+    if (scale == 1) {
+        // Two main passes may be queued at a time, one per slot and stream.  Started together they would split the wave
+        // slots and run side by side at half occupancy each; instead the later one is held back until the read queue of
+        // the earlier one runs empty, so that it takes over the SIMDs exactly as the earlier one's tail leaves them.
+        if (S->can_wait < 0) {
+            int v = 0; S->can_wait = hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, h->device) == hipSuccess && v ? 1 : 0;
+            if (g_trace) fprintf(stderr, "[lamsa_hp] hipStreamWaitValue32 %s\n", S->can_wait ? "available" : "not available: launches are not staggered");
+        }
+        if (S->can_wait && !Ln.sig) {
+            const hipError_t e = hipExtMallocWithFlags((void **)&Ln.sig, 8, hipMallocSignalMemory);      // signal memory comes in 8-byte pieces
+            if (e != hipSuccess) { Ln.sig = nullptr; S->can_wait = 0; if (g_trace) fprintf(stderr, "[lamsa_hp] no signal memory (%s): launches are not staggered\n", hipGetErrorString(e)); }
+            else hipMemset(Ln.sig, 0, 8);
+        }
+        (void)hipGetLastError();                             // a failed probe must not look like a failed launch below
+        Slot &other = &Ln == &S->slot[0] ? S->slot[1] : S->slot[0];
+        if (S->can_wait && other.busy_gen && other.sig) {
+            const double tw = now_s();
+            HIPCHK(h, hipStreamWaitValue32(s, other.sig, other.busy_gen, hipStreamWaitValueGte, 0xffffffffu), LAMSA_HP_EKERNEL);
+            if (g_trace) fprintf(stderr, "[lamsa_hp] launch held back behind generation %u (call took %.2f ms)\n", other.busy_gen, 1e3 * (now_s() - tw));
+        }
+        if (S->can_wait && Ln.sig) { a.drained = Ln.sig; a.gen = ++S->gen; Ln.busy_gen = a.gen; }
+    }
 #ifdef HP_PROF
     static DevBuf profbuf;
     if (profbuf.ensure(sizeof(long long) * 64 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 64 * (size_t)n); a.prof = (long long *)profbuf.p; }
     wait = true;
 #endif
-    hipStream_t s = T.cs;
-    HIPCHK(h, hipMemsetAsync(T.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
     HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
@@ -287,11 +321,11 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, OutDev &O, c
     return LAMSA_HP_OK;
 }
 
-static int slot_events(lamsa_hp_handle *h, Slot &T)
+static int slot_events(lamsa_hp_handle *h, Slot &Ln)
 {
-    T.cs = &T == &state_of(h)->slot[1] ? h->stream_b : h->stream;
-    if (!T.e0) HIPCHK(h, hipEventCreate(&T.e0), LAMSA_HP_EKERNEL);
-    if (!T.e1) HIPCHK(h, hipEventCreate(&T.e1), LAMSA_HP_EKERNEL);
+    Ln.cs = &Ln == &state_of(h)->slot[1] ? h->stream_b : h->stream;
+    if (!Ln.e0) HIPCHK(h, hipEventCreate(&Ln.e0), LAMSA_HP_EKERNEL);
+    if (!Ln.e1) HIPCHK(h, hipEventCreate(&Ln.e1), LAMSA_HP_EKERNEL);
     return LAMSA_HP_OK;
 }
 
@@ -299,21 +333,21 @@ static int slot_events(lamsa_hp_handle *h, Slot &T)
 // `streaming`: the persistent grid fills every wave slot of the device and holds it until the batch is done; the
 // runtime's device-to-host copies are kernels too and would wait for that.  When results of the previous batch are
 // fetched while this one runs, a few slots stay free so that those copies start at once (64 of 4 096: -1.6 % waves).
-static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, bool streaming = false)
+static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, bool streaming = false)
 {
-    int rc = slot_events(h, T);
+    int rc = slot_events(h, Ln);
     if (rc) return rc;
     const int n = T.n_reads;
     if (n == 0) return LAMSA_HP_OK;
-    if (T.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
-    return launch_align(h, S, T, T.out1, T.d_order, n, 1, T.max_L, T.max_H, T.e0, T.e1, false, streaming ? 64 : 0);
+    if (Ln.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
+    return launch_align(h, S, T, Ln, Ln.out1, T.d_order, n, 1, T.max_L, T.max_H, Ln.e0, Ln.e1, false, streaming ? 64 : 0);
 }
 
 #define DL(dst, src, bytes) HIPCHK(h, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->copy_stream), LAMSA_HP_EKERNEL)
 #define DLSYNC() HIPCHK(h, hipStreamSynchronize(h->copy_stream), LAMSA_HP_EKERNEL)
 
 // wait for the main pass of slot `T`, re-run the reads that overflowed, fetch the results
-static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_result *R)
+static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lamsa_hp_result *R)
 {
     const int n = T.n_reads;
     h->kernel_ms[0] = h->kernel_ms[1] = 0;
@@ -324,16 +358,17 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_resu
         return LAMSA_HP_OK;
     }
     const double t_0 = now_s();
-    HIPCHK(h, hipEventSynchronize(T.e1), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventSynchronize(Ln.e1), LAMSA_HP_EKERNEL);
+    Ln.busy_gen = 0;
     const double t_1 = now_s();
-    hipEventElapsedTime(&h->kernel_ms[0], T.e0, T.e1);
+    hipEventElapsedTime(&h->kernel_ms[0], Ln.e0, Ln.e1);
     // the per-read arrays are in mapped host memory already (OutDev); the slot may be reused while the caller still
     // reads the results, so they are copied out
-    memcpy(S->r_off.data(), T.out1.h_off(), 8 * (size_t)n); memcpy(S->r_len.data(), T.out1.h_len(n), 4 * (size_t)n);
-    memcpy(S->r_st.data(), T.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), T.out1.h_tb(n), 4 * (size_t)n);
+    memcpy(S->r_off.data(), Ln.out1.h_off(), 8 * (size_t)n); memcpy(S->r_len.data(), Ln.out1.h_len(n), 4 * (size_t)n);
+    memcpy(S->r_st.data(), Ln.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), Ln.out1.h_tb(n), 4 * (size_t)n);
     unsigned long long used1 = 0;                        // the arena is handed out front to back: its fill is the largest end
     for (int r = 0; r < n; ++r) if (S->r_off[r] >= 0 && (unsigned long long)(S->r_off[r] + S->r_len[r]) > used1) used1 = (unsigned long long)(S->r_off[r] + S->r_len[r]);
-    if ((int64_t)used1 > T.out1.stream_cap) used1 = (unsigned long long)T.out1.stream_cap;
+    if ((int64_t)used1 > Ln.out1.stream_cap) used1 = (unsigned long long)Ln.out1.stream_cap;
     // ---- retry pass: reads whose work buffers (or the stream arena) were too small -- outliers; 8x capacities.
     // On this slot's own stream: it runs beside the other slot's main pass when streaming.
     std::vector<int32_t> again;
@@ -344,8 +379,8 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_resu
         for (int r : again) { mL = std::max(mL, T.h_len[r]); mH = std::max(mH, T.h_H[r]); cap2 += 64 + 12LL * 8 * T.h_len[r]; }
         if (grow(h, S->out2.buf, 4 * (size_t)cap2 + 256) || S->out2.host.ensure(OutDev::hdr(n) + 256) || grow(h, S->retry_list, 4 * again.size())) { h->err = "hipMalloc(retry)"; return LAMSA_HP_ENOMEM; }
         S->out2.stream_cap = cap2;
-        HIPCHK(h, hipMemcpyAsync(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice, T.cs), LAMSA_HP_EKERNEL);
-        int rc = launch_align(h, S, T, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, h->ev0, h->ev1, true);
+        HIPCHK(h, hipMemcpyAsync(S->retry_list.p, again.data(), 4 * again.size(), hipMemcpyHostToDevice, Ln.cs), LAMSA_HP_EKERNEL);
+        int rc = launch_align(h, S, T, Ln, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, h->ev0, h->ev1, true);
         if (rc) return rc;
         hipEventElapsedTime(&h->kernel_ms[1], h->ev0, h->ev1);
         const int64_t *off2 = S->out2.h_off(); const int32_t *len2 = S->out2.h_len(n), *st2 = S->out2.h_st(n), *tb2 = S->out2.h_tb(n);
@@ -357,7 +392,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, lamsa_hp_resu
     if (!R) return LAMSA_HP_OK;
     if (S->stream.ensure(4 * (size_t)(used1 + used2) + 64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
     int32_t *hs = (int32_t *)S->stream.p;
-    if (used1) DL(hs, T.out1.stream(n), 4 * (size_t)used1);
+    if (used1) DL(hs, Ln.out1.stream(n), 4 * (size_t)used1);
     if (used2) DL(hs + used1, S->out2.stream(n), 4 * (size_t)used2);
     DLSYNC();
     if (g_trace) fprintf(stderr, "[lamsa_hp] collect: waited %.1f ms for the kernel (%.1f ms), results %.1f ms (%.2f GB)\n", 1e3 * (t_1 - t_0), h->kernel_ms[0], 1e3 * (now_s() - t_1), 4e-9 * (double)(used1 + used2));
@@ -380,7 +415,7 @@ extern "C" int lamsa_hp_upload_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     int rc = check_batch_args(h, B);
     if (rc) return rc;
     AlignState *S = state_of(h);
-    if (S->n_fifo) { h->err = "submitted batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
+    if (S->n_fifo || S->n_res) { h->err = "batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
     return upload_into(h, &S->slot[0], B);
 }
 
@@ -391,9 +426,38 @@ extern "C" int lamsa_hp_run_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
     if (S->n_fifo) { h->err = "submitted batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
     if (!S->slot[0].valid) { h->err = "no batch uploaded"; return LAMSA_HP_EINVAL; }
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
-    int rc = start_main(h, S, S->slot[0]);
+    if (S->n_res) { h->err = "runs of the resident batch are in flight: finish them first"; return LAMSA_HP_EINVAL; }
+    int rc = start_main(h, S, S->slot[0], S->slot[0]);
     if (rc) return rc;
-    return finish_main(h, S, S->slot[0], R);
+    return finish_main(h, S, S->slot[0], S->slot[0], R);
+}
+
+// Runs of the resident batch, two deep: a run uses the inputs of slot 0 and the launch resources of either slot.
+extern "C" int lamsa_hp_start_uploaded(lamsa_hp_handle *h)
+{
+    if (!h) return LAMSA_HP_EINVAL;
+    AlignState *S = state_of(h);
+    if (S->n_fifo) { h->err = "submitted batches are in flight: collect them first"; return LAMSA_HP_EINVAL; }
+    if (!S->slot[0].valid) { h->err = "no batch uploaded"; return LAMSA_HP_EINVAL; }
+    if (S->n_res >= 2) { h->err = "two runs are already in flight: finish one first"; return LAMSA_HP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    const int k = S->n_res == 1 ? 1 - S->res_fifo[0] : 0;
+    S->slot[1].valid = false;                                  // its buffers serve as a lane now
+    const int rc = start_main(h, S, S->slot[0], S->slot[k]);
+    if (rc) return rc;
+    S->res_fifo[S->n_res++] = k;
+    return LAMSA_HP_OK;
+}
+
+extern "C" int lamsa_hp_finish_uploaded(lamsa_hp_handle *h, lamsa_hp_result *R)
+{
+    if (!h) return LAMSA_HP_EINVAL;
+    AlignState *S = state_of(h);
+    if (S->n_res == 0) { h->err = "no run in flight"; return LAMSA_HP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    const int k = S->res_fifo[0];
+    S->res_fifo[0] = S->res_fifo[1]; --S->n_res;
+    return finish_main(h, S, S->slot[0], S->slot[k], R);
 }
 
 extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B, lamsa_hp_result *R)
@@ -408,11 +472,12 @@ extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     int rc = check_batch_args(h, B);
     if (rc) return rc;
     AlignState *S = state_of(h);
+    if (S->n_res) { h->err = "runs of the resident batch are in flight: finish them first"; return LAMSA_HP_EINVAL; }
     if (S->n_fifo >= 2) { h->err = "two batches are already in flight: collect one first"; return LAMSA_HP_EINVAL; }
     const int k = S->n_fifo == 1 ? 1 - S->fifo[0] : 0;         // the slot no queued kernel reads
     rc = upload_into(h, &S->slot[k], B);                         // overlaps the kernel of the other slot
     if (rc) return rc;
-    rc = start_main(h, S, S->slot[k], true);
+    rc = start_main(h, S, S->slot[k], S->slot[k], true);
     if (rc) { S->slot[k].valid = false; return rc; }
     S->fifo[S->n_fifo++] = k;
     return LAMSA_HP_OK;
@@ -426,7 +491,7 @@ extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *R)
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
     const int k = S->fifo[0];
     S->fifo[0] = S->fifo[1]; --S->n_fifo;
-    const int rc = finish_main(h, S, S->slot[k], R);
+    const int rc = finish_main(h, S, S->slot[k], S->slot[k], R);
     S->slot[k].valid = false;
     return rc;
 }

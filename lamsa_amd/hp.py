@@ -57,7 +57,8 @@ class HpResult(C.Structure):
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
            "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms", "lamsa_hp_set_scratch_limit",
            "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded",
-           "lamsa_hp_submit_batch", "lamsa_hp_collect_batch", "lamsa_hp_host_alloc", "lamsa_hp_host_free")
+           "lamsa_hp_submit_batch", "lamsa_hp_collect_batch", "lamsa_hp_host_alloc", "lamsa_hp_host_free",
+           "lamsa_hp_start_uploaded", "lamsa_hp_finish_uploaded")
 
 _lib = None
 
@@ -95,6 +96,10 @@ def load_library(path=LIB_PATH):
         L.lamsa_hp_host_alloc.argtypes = [C.c_size_t]
         L.lamsa_hp_host_alloc.restype = C.c_void_p
         L.lamsa_hp_host_free.argtypes = [C.c_void_p]
+        L.lamsa_hp_start_uploaded.argtypes = [C.c_void_p]
+        L.lamsa_hp_start_uploaded.restype = C.c_int
+        L.lamsa_hp_finish_uploaded.argtypes = [C.c_void_p, C.POINTER(HpResult)]
+        L.lamsa_hp_finish_uploaded.restype = C.c_int
         _lib = L
     return _lib
 
@@ -242,6 +247,28 @@ class LamsaHp:
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
         return self._result(R, self._n_up)
+
+    def start_uploaded(self):
+        """Queue a run of the resident batch (two may be in flight)."""
+        rc = self.L.lamsa_hp_start_uploaded(self._h)
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_start_uploaded: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+
+    def finish_uploaded(self, fetch=True, raw=False):
+        """Wait for the oldest run of the resident batch; results as run_uploaded returns them."""
+        R = HpResult()
+        rc = self.L.lamsa_hp_finish_uploaded(self._h, C.byref(R) if fetch else None)
+        if rc != 0:
+            raise RuntimeError("lamsa_hp_finish_uploaded: %d %s" % (rc, self.L.lamsa_hp_last_error(self._h).decode()))
+        if not fetch:
+            return None
+        n = self._n_up
+        if raw:
+            self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
+            self.last_stream_words = int(R.stream_words)
+            return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
+                    np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
+        return self._result(R, n)
 
     # ---- streaming form: up to two batches in flight
     def submit_batch(self, batch):

@@ -130,6 +130,21 @@ def test_hip_streaming_submit_collect(tmp_path):
     assert h.last_kernel_ms(1) > 0 and a == want and (st == 0).all()
     b, st = h.collect_batch()
     assert b == [want[i] for i in parts[0]] and (st == 0).all()
+    # runs of a resident batch, two deep
+    h.set_scratch_limit(0)
+    h.upload_batch(B)
+    h.start_uploaded(); h.start_uploaded()
+    with pytest.raises(RuntimeError):
+        h.start_uploaded()                               # two already in flight
+    with pytest.raises(RuntimeError):
+        h.submit_batch(B)                                # not while resident runs are in flight
+    a = h.finish_uploaded()[0]
+    h.start_uploaded()
+    b = h.finish_uploaded()[0]; c = h.finish_uploaded()[0]
+    assert a == want and b == want and c == want
+    with pytest.raises(RuntimeError):
+        h.finish_uploaded()
+    assert h.run_uploaded()[0] == want
     h.close()
     # a handle destroyed with a chunk still in flight
     h = _handle(B, rt, over)
