@@ -263,7 +263,9 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, Ou
         // slots and run side by side at half occupancy each; instead the later one is held back until the read queue of
         // the earlier one runs empty, so that it takes over the SIMDs exactly as the earlier one's tail leaves them.
         if (S->can_wait < 0) {
-            int v = 0; S->can_wait = hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, h->device) == hipSuccess && v ? 1 : 0;
+            // LAMSA_HP_NO_STAGGER=1 switches the hold-back off: tools that serialise kernel dispatches (rocprofv3 --pmc) would
+            // run the waiting stream operation before the launch it waits for and never return
+            int v = 0; S->can_wait = !getenv("LAMSA_HP_NO_STAGGER") && hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, h->device) == hipSuccess && v ? 1 : 0;
             if (g_trace) fprintf(stderr, "[lamsa_hp] hipStreamWaitValue32 %s\n", S->can_wait ? "available" : "not available: launches are not staggered");
         }
         if (S->can_wait && !Ln.sig) {
