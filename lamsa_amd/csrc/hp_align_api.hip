@@ -236,14 +236,13 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 // (scratch slab, queue head, stream, events) of slot `Ln`; results into `O`.  The kernel
 // is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
 static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
-                        hipEvent_t e0, hipEvent_t e1, bool wait, int spare_waves = 0)
+                        hipEvent_t e0, hipEvent_t e1, bool wait)
 {
     size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
     if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     int n_waves = h->n_cu * per_cu;
-    if (n_waves > 4 * spare_waves) n_waves -= spare_waves;      // streaming: wave slots left free for the runtime's copy kernels (see start_main)
     if (n_waves > n_units) n_waves = n_units;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
     if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
@@ -332,17 +331,14 @@ static int slot_events(lamsa_hp_handle *h, Slot &Ln)
 }
 
 // queue the main pass of the batch in slot `T`: every read, costliest first
-// `streaming`: the persistent grid fills every wave slot of the device and holds it until the batch is done; the
-// runtime's device-to-host copies are kernels too and would wait for that.  When results of the previous batch are
-// fetched while this one runs, a few slots stay free so that those copies start at once (64 of 4 096: -1.6 % waves).
-static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, bool streaming = false)
+static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln)
 {
     int rc = slot_events(h, Ln);
     if (rc) return rc;
     const int n = T.n_reads;
     if (n == 0) return LAMSA_HP_OK;
     if (Ln.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
-    return launch_align(h, S, T, Ln, Ln.out1, T.d_order, n, 1, T.max_L, T.max_H, Ln.e0, Ln.e1, false, streaming ? 64 : 0);
+    return launch_align(h, S, T, Ln, Ln.out1, T.d_order, n, 1, T.max_L, T.max_H, Ln.e0, Ln.e1, false);
 }
 
 #define DL(dst, src, bytes) HIPCHK(h, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->copy_stream), LAMSA_HP_EKERNEL)
@@ -479,7 +475,7 @@ extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     const int k = S->n_fifo == 1 ? 1 - S->fifo[0] : 0;         // the slot no queued kernel reads
     rc = upload_into(h, &S->slot[k], B);                         // overlaps the kernel of the other slot
     if (rc) return rc;
-    rc = start_main(h, S, S->slot[k], S->slot[k], true);
+    rc = start_main(h, S, S->slot[k], S->slot[k]);
     if (rc) { S->slot[k].valid = false; return rc; }
     S->fifo[S->n_fifo++] = k;
     return LAMSA_HP_OK;
