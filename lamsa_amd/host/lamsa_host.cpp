@@ -589,6 +589,44 @@ int run_seeding(const Options &opt, const lamsa_hp_para &P)
     return 0;
 }
 
+// ------------------------------------------------------------------ binary hit stream
+// The arrays of lamsa_hp_batch, chunk after chunk, as they go to the GPU: a re-run on the same reads (other scoring /
+// filtering options) maps the file and uploads straight from the page cache -- no seeding, no text, no parse.  Native
+// byte order; the header pins the options that shape the arrays (-T, -l, -i, -p).
+namespace {
+const char HITS_MAGIC[8] = {'L', 'A', 'M', 'S', 'A', 'H', 'P', '1'};
+struct HitsHeader { char magic[8]; int32_t read_type, seed_len, seed_step, per_aln_m; int64_t reserved[2]; };
+struct HitsChunkHeader { int64_t n_reads, n_bases, n_slots, n_hits, n_cig, bytes; };      // bytes: of the arrays that follow (each padded to 64)
+inline size_t pad64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct HitsWriter {
+    FILE *fp = nullptr;
+    bool open(const std::string &path, const lamsa_hp_para &P) {
+        fp = fopen(path.c_str(), "wb");
+        if (!fp) return false;
+        HitsHeader h; memset(&h, 0, sizeof h); memcpy(h.magic, HITS_MAGIC, 8);
+        h.read_type = P.read_type; h.seed_len = P.seed_len; h.seed_step = P.seed_step; h.per_aln_m = P.per_aln_m;
+        return fwrite(&h, sizeof h, 1, fp) == 1;
+    }
+    template <class V> bool put(const V &v, size_t n) {
+        static const char zeros[64] = {0};
+        const size_t bytes = n * sizeof(v[0]);
+        if (bytes && fwrite(v.data(), 1, bytes, fp) != bytes) return false;
+        const size_t padn = pad64(bytes) - bytes;
+        return padn == 0 || fwrite(zeros, 1, padn, fp) == padn;
+    }
+    bool write(const lamsa::Batch &B) {
+        const size_t n = B.reads.size(), nb = B.read_seq.size(), ns = B.seed_id.size(), nh = B.h_pos.size(), nc = B.cig.size();
+        HitsChunkHeader c; c.n_reads = (int64_t)n; c.n_bases = (int64_t)nb; c.n_slots = (int64_t)ns; c.n_hits = (int64_t)nh; c.n_cig = (int64_t)nc;
+        c.bytes = (int64_t)(pad64(8 * (n + 1)) * 2 + pad64(nb) + pad64(4 * n) * 2 + pad64(4 * ns) + pad64(8 * (ns + 1)) + pad64(8 * nh) + pad64(4 * nh) * 2 + pad64(nh) * 2 + pad64(2 * nh) * 2 + pad64(4 * nc));
+        if (fwrite(&c, sizeof c, 1, fp) != 1) return false;
+        return put(B.read_off, n + 1) && put(B.read_seq, nb) && put(B.seed_all, n) && put(B.last_len, n) && put(B.seed_off, n + 1) && put(B.seed_id, ns) && put(B.hit_off, ns + 1) &&
+               put(B.h_pos, nh) && put(B.h_chr, nh) && put(B.h_strand, nh) && put(B.h_nm, nh) && put(B.h_len_dif, nh) && put(B.h_cig_off, nh) && put(B.h_cig_n, nh) && put(B.cig, nc);
+    }
+    void close() { if (fp) fclose(fp); fp = nullptr; }
+};
+}  // namespace
+
 // ------------------------------------------------------------------ chunk loop
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -599,8 +637,17 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     Index ix; std::string err;
     if (!load_index(opt.ref_prefix, ix, err)) { fprintf(stderr, "[lamsa_aln] %s\n", err.c_str()); return 1; }
     const std::string map_path = opt.seed_result.empty() ? opt.reads + ".seed.gem.map" : opt.seed_result;
-    MapText mapt;
-    if (!mapt.open(map_path)) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
+    MapText mapt, hitsf;                                // GEM map text, or (--hits) the binary hit stream written by --save-hits
+    const bool from_hits = !opt.hits.empty();
+    if (from_hits) {
+        HitsHeader hh;
+        if (!hitsf.open(opt.hits) || hitsf.n < sizeof hh) { fprintf(stderr, "[lamsa_aln] Can't open hit stream %s\n", opt.hits.c_str()); return 1; }
+        memcpy(&hh, hitsf.p, sizeof hh);
+        if (memcmp(hh.magic, HITS_MAGIC, 8) != 0 || hh.read_type != P.read_type || hh.seed_len != P.seed_len || hh.seed_step != P.seed_step || hh.per_aln_m != P.per_aln_m) {
+            fprintf(stderr, "[lamsa_aln] %s is not a hit stream written with these seeding options (-T, -l, -i, -p)\n", opt.hits.c_str()); return 1;
+        }
+        hitsf.pos = sizeof hh;
+    } else if (!mapt.open(map_path)) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
     FastxReader fx;
     if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
     lamsa_hp_ref ref; ref.pac = ix.pac.data(); ref.l_pac = ix.l_pac; ref.n_seqs = (int32_t)ix.name.size(); ref.seq_offset = ix.off.data(); ref.seq_len = ix.len.data();
@@ -618,18 +665,43 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
     // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
     // The chunk buffers are recycled.
-    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; };
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; };
+    HitsWriter saver;
+    if (!opt.save_hits.empty() && !from_hits && !saver.open(opt.save_hits, P)) { fprintf(stderr, "[lamsa_aln] Can't write hit stream %s\n", opt.save_hits.c_str()); return 1; }
     Chunk pool[5]; int n_scanned = 0;
     std::vector<Batch> parts((size_t)threads);              // per-thread partial batches of the parse, recycled too
     const bool trace = getenv("LAMSA_TRACE") != nullptr;
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
         Chunk *c = &pool[n_scanned++ % 5];
         Batch &B = c->B;
-        B.clear(); c->ret = 0; c->span.clear();
+        B.clear(); c->ret = 0; c->span.clear(); c->mapped = false;
         if (eof) return c;
         const double t0 = now_s();
         Read rd;
         int64_t chunk_bases = 0;
+        if (from_hits) {                                    // the chunk as it was stored: its arrays are views into the mapped stream
+            if (hitsf.pos + sizeof(HitsChunkHeader) > hitsf.n) { eof = true; if (fx.next(rd)) { fprintf(stderr, "[lamsa_read_seq] the hit stream ends before the reads\n"); c->ret = 1; } return c; }
+            HitsChunkHeader ch; memcpy(&ch, hitsf.p + hitsf.pos, sizeof ch);
+            const char *a = hitsf.p + hitsf.pos + sizeof ch;
+            if (ch.n_reads <= 0 || ch.bytes < 0 || hitsf.pos + sizeof ch + (size_t)ch.bytes > hitsf.n) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
+            const size_t n = (size_t)ch.n_reads, nb = (size_t)ch.n_bases, ns = (size_t)ch.n_slots, nh = (size_t)ch.n_hits, nc = (size_t)ch.n_cig;
+            lamsa_hp_batch &hb = c->hb;
+            auto take = [&](size_t bytes) { const char *q = a; a += pad64(bytes); return q; };
+            hb.n_reads = (int32_t)n; hb.n_cig = (int64_t)nc;
+            hb.read_off = (const int64_t *)take(8 * (n + 1)); hb.read_seq = (const uint8_t *)take(nb); hb.seed_all = (const int32_t *)take(4 * n); hb.last_len = (const int32_t *)take(4 * n);
+            hb.seed_off = (const int64_t *)take(8 * (n + 1)); hb.seed_id = (const int32_t *)take(4 * ns); hb.hit_off = (const int64_t *)take(8 * (ns + 1));
+            hb.h_pos = (const int64_t *)take(8 * nh); hb.h_chr = (const int32_t *)take(4 * nh); hb.h_strand = (const int8_t *)take(nh); hb.h_nm = (const int16_t *)take(2 * nh);
+            hb.h_len_dif = (const int16_t *)take(2 * nh); hb.h_cig_off = (const int32_t *)take(4 * nh); hb.h_cig_n = (const uint8_t *)take(nh); hb.cig = (const int32_t *)take(4 * nc);
+            if ((size_t)(a - (hitsf.p + hitsf.pos + sizeof ch)) != (size_t)ch.bytes) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
+            hitsf.pos += sizeof ch + (size_t)ch.bytes;
+            for (size_t r = 0; r < n; ++r) {
+                if (!fx.next(rd) || (int64_t)rd.seq.size() != hb.read_off[r + 1] - hb.read_off[r]) { fprintf(stderr, "[lamsa_read_seq] the hit stream does not match the reads\n"); c->ret = 1; eof = true; return c; }
+                B.reads.emplace_back(); std::swap(B.reads.back(), rd);
+            }
+            c->mapped = true;
+            if (trace) fprintf(stderr, "[scan] %d reads of the hit stream in %.3f s\n", (int)n, now_s() - t0);
+            return c;
+        }
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
             if (!fx.next(rd)) { eof = true; break; }
             const char *la, *lb;
@@ -649,6 +721,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         Batch &B = c->B;
         const int n = (int)B.reads.size();
         if (n == 0 || c->ret) return c;
+        if (c->mapped) { parse_s += now_s() - t0; return c; }
         const double t1 = now_s();
         // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
         for (Batch &p : parts) p.clear();
@@ -659,11 +732,15 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         merge_batches(B, parts, threads);
         if (trace) fprintf(stderr, "[prepare] waited %.3f s for the scan, parse %.3f, merge %.3f\n", t1 - t0, t2 - t1, now_s() - t2);
         for (int32_t ch : B.h_chr) if (ch < 1) { fprintf(stderr, "[lamsa_aln] seed hit on a contig that is not in the index\n"); c->ret = 1; break; }
+        if (saver.fp && !c->ret && !saver.write(B)) { fprintf(stderr, "[lamsa_aln] writing %s failed\n", opt.save_hits.c_str()); c->ret = 1; }
         parse_s += now_s() - t0;                            // one prepare() runs at a time
         return c;
     };
-    auto submit = [&](Batch &B) -> int {
+    auto submit = [&](Chunk &ck) -> int {
+        Batch &B = ck.B;
         lamsa_hp_batch hb;
+        if (ck.mapped) hb = ck.hb;
+        else {
         hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
         hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
         hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_off = B.h_cig_off.data(); hb.h_cig_n = B.h_cig_n.data(); hb.cig = B.cig.data(); hb.n_cig = (int64_t)B.cig.size();
@@ -672,6 +749,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_off = &zero32; hb.h_cig_n = &zero8; }
         if (!hb.cig) hb.cig = &zero32;
         if (!hb.read_seq) hb.read_seq = &zero8;
+        }
         const double t0 = now_s();
         const int e = lamsa_hp_submit_batch(h, &hb);
         submit_s += now_s() - t0;
@@ -716,6 +794,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             n_reads += (long)c->B.reads.size(); for (const Read &q : c->B.reads) n_bases += (long)q.seq.size();
         }
         if (scanned.valid()) scanned.wait();
+        saver.close();
         if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; }
         return ret;
     }
@@ -727,7 +806,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         const bool have = ret == 0 && !cur->B.reads.empty();
         if (have) {
             next = std::async(std::launch::async, prepare);  // overlaps with everything below
-            ret = submit(cur->B);
+            ret = submit(*cur);
         }
         if (flying) { const int e = collect_and_write(flying->B); if (e && !ret) ret = e; flying = nullptr; }
         if (!have || ret) break;
@@ -735,6 +814,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     }
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();
+    saver.close();
     lamsa_hp_destroy(h);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
                  stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; }

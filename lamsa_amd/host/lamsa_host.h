@@ -63,6 +63,7 @@ struct Options {
     // seeding front end (lamsa_aln_c, src/lamsa_aln.c:1224-1275): -N reuses <reads>.seed.gem.map, otherwise the read file is
     // cut into seeds and the GEM mapper of the reference's bundle is run on them
     int no_seed_aln = 0, fastest = 0;
+    std::string save_hits, hits;                          // --save-hits FILE: also write the parsed chunks as a binary hit stream; --hits FILE: read that instead of the GEM map text
     int parse_only = 0;                                   // --parse-only: read and parse the inputs, no GPU work, no output (ingest timing)
     float ed_rate = -1, mis_rate = -1, mat_rate = -1;     // -e, -x; defaults per read type (src/lamsa_aln.h:26-70)
     std::string gem_dir;                                  // directory holding gem-mapper (default: <directory of this binary>/gem)

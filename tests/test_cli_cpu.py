@@ -54,3 +54,23 @@ def test_error_paths(cli, tmp_path):
     assert p.returncode != 0 and "gem mapper not found" in p.stderr.lower()
     seeds = open(reads + ".seed").read().split("\n")                                                     # but the seeds were cut as the reference cuts them
     assert seeds[0].endswith("_0:0") and len(seeds[1]) == 50 and seeds[2].endswith("_1:100")
+
+
+def test_binary_hit_stream_round_trip(cli, tmp_path):
+    """--save-hits writes the parsed seed hits chunk by chunk; --hits replays them (no GEM text, no parse) -- same SAM;
+    a stream written with other seeding options, or for other reads, is refused."""
+    ref, reads, args, want = G.stage_scenario("c3_ont", str(tmp_path))
+    hits = str(tmp_path / "hits.bin")
+    p = subprocess.run([cli, "aln", "-N", "-R", "0", "--batch", "5", "--save-hits", hits] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(want)
+    os.remove(reads + ".seed.gem.map")                         # the replay must not need it
+    q = subprocess.run([cli, "aln", "-R", "0", "--hits", hits] + args + [ref, reads], capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr[-2000:]
+    assert G.strip_pg(q.stdout) == G.strip_pg(want)
+    bad = subprocess.run([cli, "aln", "-R", "0", "--hits", hits, "-T", "pacbio", ref, reads], capture_output=True, text=True)
+    assert bad.returncode != 0 and "hit stream" in bad.stderr
+    os.makedirs(str(tmp_path / "other"))
+    ref2, reads2, args2, _ = G.stage_scenario("c2_pacbio", str(tmp_path / "other"))
+    bad = subprocess.run([cli, "aln", "-R", "0", "--hits", hits] + args + [ref, reads2], capture_output=True, text=True)
+    assert bad.returncode != 0 and "hit stream" in bad.stderr

@@ -23,11 +23,11 @@ B = simbatch.SimBatch(ref, n, L, "ont2d", seed=31, threads=min(threads, 16))
 simfiles.write_index(d + "/ref.fa", ref); simfiles.write_reads(d + "/reads.fa", B)
 print("files written in %.1f s: %d reads, %.0f hits/read, map %.1f MB" % (time.time() - t, n, B.n_hits / n, os.path.getsize(d + "/reads.fa.seed.gem.map") / 1e6), flush=True)
 batch = sys.argv[4] if len(sys.argv) > 4 else "2048"
-for rep, extra in enumerate((["--parse-only"], [], [])):
+for rep, extra in enumerate((["--parse-only"], ["--save-hits", d + "/hits.bin"], [], ["--hits", d + "/hits.bin", "--parse-only"], ["--hits", d + "/hits.bin"], ["--hits", d + "/hits.bin"])):
     t = time.time()
     p = subprocess.run([os.path.join(ROOT, "lamsa_amd", "bin", "lamsa"), "aln", "-N", "-T", "ont2d", "-R", "0", "--batch", batch, "-o", d + "/out.sam"] + extra + [d + "/ref.fa", d + "/reads.fa"],
-                       capture_output=True, text=True, env=dict(os.environ, LAMSA_TRACE="1"))
+                       capture_output=True, text=True)
     dt = time.time() - t
     print("run %d %s: rc %d, %.2f s wall -> %.0f reads/s end to end" % (rep, " ".join(extra), p.returncode, dt, n / dt))
-    print("\n".join(l for l in p.stderr.splitlines() if "wall" in l or "Mapping done" in l or "failed" in l or "[prepare]" in l), flush=True)
+    print("\n".join(l for l in p.stderr.splitlines() if "wall" in l or "Mapping done" in l or "failed" in l), flush=True)
 print("SAM %.1f MB" % (os.path.getsize(d + "/out.sam") / 1e6))
