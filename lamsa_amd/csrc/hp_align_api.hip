@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -105,23 +106,29 @@ struct AlignState {
 };
 
 static std::map<lamsa_hp_handle *, AlignState *> g_states;     // per-handle state of the align entry points
+static std::mutex g_states_lock;                                // a handle is single-threaded, different handles may live on different threads
 static AlignState *state_of(lamsa_hp_handle *h)
 {
+    std::lock_guard<std::mutex> guard(g_states_lock);
     auto it = g_states.find(h);
     if (it != g_states.end()) return it->second;
     return g_states[h] = new AlignState();
 }
 extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
 {
-    auto it = g_states.find(h);
-    if (it == g_states.end()) return;
-    AlignState *S = it->second;
+    AlignState *S = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(g_states_lock);
+        auto it = g_states.find(h);
+        if (it == g_states.end()) return;
+        S = it->second;
+        g_states.erase(it);
+    }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
     for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); if (T.sig) hipFree(T.sig); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
-    g_states.erase(it);
 }
 
 // grow a device buffer that a queued kernel may still be using: drain both compute streams first
