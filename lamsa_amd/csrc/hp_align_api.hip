@@ -482,7 +482,9 @@ extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B
     const int k = S->n_fifo == 1 ? 1 - S->fifo[0] : 0;         // the slot no queued kernel reads
     rc = upload_into(h, &S->slot[k], B);                         // overlaps the kernel of the other slot
     if (rc) return rc;
+    const double t_s = now_s();
     rc = start_main(h, S, S->slot[k], S->slot[k]);
+    if (g_trace) fprintf(stderr, "[lamsa_hp] submit: launch queued in %.1f ms (scratch and output buffers are allocated on first use)\n", 1e3 * (now_s() - t_s));
     if (rc) { S->slot[k].valid = false; return rc; }
     S->fifo[S->n_fifo++] = k;
     return LAMSA_HP_OK;

@@ -500,6 +500,20 @@ void sam_header(std::string &o, const Index &ix, const std::string &pg)
 
 // aln_res_output, src/lamsa_aln.c:1001-1100.  (`-C` with a reverse-strand FASTQ read never terminates in the
 // reference, :1043; here QUAL is printed reversed -- the evident intent, documented divergence.)
+// decimal digits of v appended to o (the CIGAR of a 10 kbp noisy read has ~1 500 operations: no printf per operation)
+static inline void append_int(std::string &o, long long v)
+{
+    char buf[24]; int n = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) buf[n++] = '-';
+    while (n) o.push_back(buf[--n]);
+}
+static inline void append_cigar(std::string &o, const std::vector<int32_t> &cig, const char *ops)
+{
+    for (int32_t w : cig) { append_int(o, w >> 4); o.push_back(ops[w & 0xf]); }
+}
+
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt)
 {
     static const char OPS[] = "MIDNSHP=XB", OPS_HC[] = "MIDNHHP=XB";
@@ -515,23 +529,25 @@ void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index 
                 int flag = r.nstrand ? 0 : 0x10;
                 const bool soft = !prim || opt.supp_soft;
                 if (!soft) flag |= 0x800;
-                appendf(o, "%s\t%d\t%s\t%lld\t%d\t", rd.name.c_str(), flag, ix.name[(size_t)r.chr - 1].c_str(), (long long)r.offset, (int)la.mapQ);
-                for (int32_t w : r.cigar) appendf(o, "%d%c", w >> 4, (soft ? OPS : OPS_HC)[w & 0xf]);
+                o += rd.name; o.push_back('\t'); append_int(o, flag); o.push_back('\t'); o += ix.name[(size_t)r.chr - 1]; o.push_back('\t');
+                append_int(o, (long long)r.offset); o.push_back('\t'); append_int(o, (int)la.mapQ); o.push_back('\t');
+                append_cigar(o, r.cigar, soft ? OPS : OPS_HC);
                 o += "\t*\t0\t0\t";
                 const int b = soft ? 0 : r.reg_beg - 1, e = soft ? read_len : r.reg_end;
-                if (r.nstrand == 1) o.append(rd.seq, (size_t)b, (size_t)(e - b)); else for (int si = e - 1; si >= b; --si) o.push_back(comp_char(rd.seq[(size_t)si]));
+                if (r.nstrand == 1) o.append(rd.seq, (size_t)b, (size_t)(e - b));
+                else { const size_t k0 = o.size(); o.resize(k0 + (size_t)(e - b)); char *d = &o[k0]; for (int si = e - 1; si >= b; --si) *d++ = comp_char(rd.seq[(size_t)si]); }
                 o.push_back('\t');
                 if (with_qual) { if (r.nstrand == 1) o.append(rd.qual, (size_t)b, (size_t)(e - b)); else for (int si = e - 1; si >= b; --si) o.push_back(rd.qual[(size_t)si]); }
                 else o.push_back('*');
                 if (soft) prim = true;
-                appendf(o, "\tNM:i:%d\tAS:i:%d", r.NM, r.score);
+                o += "\tNM:i:"; append_int(o, r.NM); o += "\tAS:i:"; append_int(o, r.score);
                 if (j == 0 && !la.xa.empty()) {
                     o += "\tXA:Z:";
                     for (const XaRef &x : la.xa) {
                         const Rec &xr = R.stage[x.st][(size_t)x.li].rec[(size_t)x.ri];
-                        appendf(o, "%s,%c%lld,", ix.name[(size_t)xr.chr - 1].c_str(), "-+"[xr.nstrand], (long long)xr.offset);
-                        for (int32_t w : xr.cigar) appendf(o, "%d%c", w >> 4, OPS[w & 0xf]);
-                        appendf(o, ",%d;", xr.NM);
+                        o += ix.name[(size_t)xr.chr - 1]; o.push_back(','); o.push_back("-+"[xr.nstrand]); append_int(o, (long long)xr.offset); o.push_back(',');
+                        append_cigar(o, xr.cigar, OPS);
+                        o.push_back(','); append_int(o, xr.NM); o.push_back(';');
                     }
                 }
                 o.push_back('\n');
