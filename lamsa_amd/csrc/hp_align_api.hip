@@ -28,12 +28,7 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
         int u = 0;
         if (wv::leader()) u = atomicAdd(a.counter, 1);
         u = wv::uni(u);
-        if (u >= a.n_units) {               // every wave reaches this exit: the queue head only grows
-            // the queue is empty: from now on wave slots fall idle.  Tell the stream that holds the next launch back
-            // (hipStreamWaitValue32 in launch_align) so that its waves move in exactly now.
-            if (a.drained && wv::leader()) __hip_atomic_store(a.drained, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
+        if (u >= a.n_units) break;          // every wave reaches this exit: the queue head only grows
         align_read(a, a.order ? a.order[u] : u, slot, (HP_L int32_t *)lds);
     }
 }
@@ -80,8 +75,6 @@ struct OutDev {
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
     DevBuf bin, misc, slab; OutDev out1;
-    uint32_t *sig = nullptr;      // signal memory: the generation of the last main pass of this slot whose read queue ran empty
-    uint32_t busy_gen = 0;        // generation of the main pass queued on this slot and not yet finished (0: none)
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
@@ -96,7 +89,6 @@ struct Slot {                     // one batch on the device: its inputs, the ou
 struct AlignState {
     Slot slot[2];                 // two batches: one computing, one being uploaded (lamsa_hp_submit_batch)
     int fifo[2] = {0, 0}, n_fifo = 0;          // submitted and not yet collected, oldest first
-    uint32_t gen = 0; int can_wait = -1;      // launch generations; whether the device has hipStreamWaitValue32
     int res_fifo[2] = {0, 0}, n_res = 0;       // runs of the resident batch (slot 0) started and not yet finished: the lane each uses
     DevBuf retry_list;            // second passes run one at a time (inside collect / run_uploaded)
     OutDev out2;
@@ -126,7 +118,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); if (T.sig) hipFree(T.sig); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
 }
@@ -262,37 +254,12 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, Ou
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64);
     a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)Ln.misc.p;
     a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
-    a.drained = nullptr; a.gen = 0;
+    // Two main passes may be queued at a time, one per slot and stream.  The earlier one holds every wave slot until its
+    // read queue runs empty; the later one's workgroups are dispatched as those slots fall free, i.e. it takes over the
+    // SIMDs exactly as the earlier one's tail leaves them.  (Holding the later launch back explicitly, with
+    // hipStreamWaitValue32 on a flag the earlier kernel sets, measured the same and could hang under tools that
+    // serialise dispatches, so it is not done.)
     hipStream_t s = Ln.cs;
-    if (scale == 1) {
-        // Two main passes may be queued at a time, one per slot and stream.  Started together they would split the wave
-        // slots and run side by side at half occupancy each; instead the later one is held back until the read queue of
-        // the earlier one runs empty, so that it takes over the SIMDs exactly as the earlier one's tail leaves them.
-        if (S->can_wait < 0) {
-            // LAMSA_HP_NO_STAGGER=1 switches the hold-back off: tools that serialise kernel dispatches (rocprofv3 --pmc) would
-            // run the waiting stream operation before the launch it waits for and never return
-            int v = 0; S->can_wait = !getenv("LAMSA_HP_NO_STAGGER") && hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, h->device) == hipSuccess && v ? 1 : 0;
-            if (g_trace) fprintf(stderr, "[lamsa_hp] hipStreamWaitValue32 %s\n", S->can_wait ? "available" : "not available: launches are not staggered");
-        }
-        if (S->can_wait && !Ln.sig) {
-            const hipError_t e = hipExtMallocWithFlags((void **)&Ln.sig, 8, hipMallocSignalMemory);      // signal memory comes in 8-byte pieces
-            if (e != hipSuccess) { Ln.sig = nullptr; S->can_wait = 0; if (g_trace) fprintf(stderr, "[lamsa_hp] no signal memory (%s): launches are not staggered\n", hipGetErrorString(e)); }
-            else hipMemset(Ln.sig, 0, 8);
-        }
-        (void)hipGetLastError();                             // a failed probe must not look like a failed launch below
-        Slot &other = &Ln == &S->slot[0] ? S->slot[1] : S->slot[0];
-        if (S->can_wait && other.busy_gen && other.sig) {
-            const double tw = now_s();
-            HIPCHK(h, hipStreamWaitValue32(s, other.sig, other.busy_gen, hipStreamWaitValueGte, 0xffffffffu), LAMSA_HP_EKERNEL);
-            if (g_trace) fprintf(stderr, "[lamsa_hp] launch held back behind generation %u (call took %.2f ms)\n", other.busy_gen, 1e3 * (now_s() - tw));
-        }
-        if (S->can_wait && Ln.sig) { a.drained = Ln.sig; a.gen = ++S->gen; Ln.busy_gen = a.gen; }
-    }
-#ifdef HP_PROF
-    static DevBuf profbuf;
-    if (profbuf.ensure(sizeof(long long) * 64 * (size_t)n + 64) == 0) { hipMemset(profbuf.p, 0, sizeof(long long) * 64 * (size_t)n); a.prof = (long long *)profbuf.p; }
-    wait = true;
-#endif
     HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
@@ -364,7 +331,6 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
     }
     const double t_0 = now_s();
     HIPCHK(h, hipEventSynchronize(Ln.e1), LAMSA_HP_EKERNEL);
-    Ln.busy_gen = 0;
     const double t_1 = now_s();
     hipEventElapsedTime(&h->kernel_ms[0], Ln.e0, Ln.e1);
     // the per-read arrays are in mapped host memory already (OutDev); the slot may be reused while the caller still

@@ -55,7 +55,6 @@ struct AlignArgs {
     BatchIn in;
     BatchOut out;
     char *slab; size_t slab_per_wave;
-    uint32_t *drained; uint32_t gen;   // the first wave that finds the read queue empty stores `gen` there (nullptr: nobody listens)
     int32_t sort_pb, sort_cb;    // bits of the largest hit position / contig*2+strand code of the batch (hp_sort.h)
     int32_t *counter;            // dynamic read queue head
     const int32_t *order;        // processing order (costliest first) / retry list, or nullptr

@@ -86,7 +86,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;
     std::vector<char> slab(slab_bytes);
-    a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr; a.drained = nullptr; a.gen = 0;
+    a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
     static int32_t lds[HP_LDS_WORDS];
     for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0, lds);
     *n_words = (int64_t)cursor;
