@@ -12,6 +12,7 @@
 // (include/lamsa_hp.h).  Stage (4), the BWT rescue of short uncovered gaps (src/bwt_aln.c), is not built yet:
 // the output equals the reference's with `-R 0`.
 #include "lamsa_host.h"
+#include "rescue.h"
 #include <algorithm>
 #include <atomic>
 #include <cctype>
@@ -670,6 +671,14 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     lamsa_hp_handle *h = nullptr;
     int rc = opt.parse_only ? LAMSA_HP_OK : lamsa_hp_create(&h, &P, &ref, opt.device);
     if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] no usable MI355X / HIP device (lamsa_hp_create: %d); this build has no CPU path\n", rc); return 2; }
+    // stage (4): needs the reference's FM index files and a second handle for its DP batches (a handle is single-threaded)
+    FmIndex fm; lamsa_hp_handle *h_dp = nullptr; bool rescue = false; long n_rescue_jobs = 0;
+    if (P.bwt_max_len > 0 && !opt.parse_only) {
+        std::string e2;
+        if (!fm.load(opt.ref_prefix, e2)) fprintf(stderr, "[lamsa_aln] note: stage 4 (BWT rescue of uncovered regions <= -R %d bp) is skipped: %s; output equals the reference's with -R 0\n", P.bwt_max_len, e2.c_str());
+        else if (lamsa_hp_create(&h_dp, &P, nullptr, opt.device) != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] cannot create the stage-4 handle\n"); lamsa_hp_destroy(h); return 2; }
+        else rescue = true;
+    }
     const double load_s = now_s() - t_begin;
     std::string sam;
     sam_header(sam, ix, pg_line);
@@ -684,11 +693,11 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; };
     HitsWriter saver;
     if (!opt.save_hits.empty() && !from_hits && !saver.open(opt.save_hits, P)) { fprintf(stderr, "[lamsa_aln] Can't write hit stream %s\n", opt.save_hits.c_str()); return 1; }
-    Chunk pool[5]; int n_scanned = 0;
+    Chunk pool[6]; int n_scanned = 0;
     std::vector<Batch> parts((size_t)threads);              // per-thread partial batches of the parse, recycled too
     const bool trace = getenv("LAMSA_TRACE") != nullptr;
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
-        Chunk *c = &pool[n_scanned++ % 5];
+        Chunk *c = &pool[n_scanned++ % 6];
         Batch &B = c->B;
         B.clear(); c->ret = 0; c->span.clear(); c->mapped = false;
         if (eof) return c;
@@ -773,24 +782,65 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         return 0;
     };
     // records -> MAPQ / XA -> SAM text, on all host threads; written in input order
-    auto collect_and_write = [&](Batch &B) -> int {
-        lamsa_hp_result res;
-        const double t0 = now_s();
-        const int e = lamsa_hp_collect_batch(h, &res);
+    // Everything after the GPU for one chunk: result streams -> records, stage (4) (rescue.h: plan on the host threads,
+    // one DP batch on the GPU through the second handle, finish on the host threads), MAPQ / XA, SAM text in input order.
+    // It runs as a task of its own beside the next collect; `res` stays valid until the collect after that.
+    auto write_chunk = [&](Chunk *ck, lamsa_hp_result res) -> int {
         const double t1 = now_s();
-        wait_s += t1 - t0;
-        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
-        kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
+        Batch &B = ck->B;
         const int n = (int)B.reads.size();
-        std::vector<std::string> sams((size_t)threads);
+        const uint8_t *codes = ck->mapped ? ck->hb.read_seq : B.read_seq.data();
+        const int64_t *roff = ck->mapped ? ck->hb.read_off : B.read_off.data();
+        std::vector<ReadResult> RR((size_t)n);
+        std::vector<RescuePlan> plans(rescue ? (size_t)n : 0);
+        std::vector<RescueJobs> tj((size_t)threads);
+        std::vector<int> t_first((size_t)threads, 0), t_last((size_t)threads, 0);
         std::vector<long> bad_of((size_t)threads, 0);
         parallel_blocks(n, threads, [&](int t, int r0, int r1) {
-            ReadResult R;
-            std::string &o = sams[(size_t)t];
+            t_first[(size_t)t] = r0; t_last[(size_t)t] = r1;
             for (int r = r0; r < r1; ++r) {
+                ReadResult &R = RR[(size_t)r];
                 const int L = (int)B.reads[(size_t)r].seq.size();
                 parse_stream(res.stream + res.read_off[r], res.read_len[r], L, R);
-                if (R.status != 0) { ++bad_of[(size_t)t]; fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[(size_t)r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow"); }
+                if (rescue && R.status == 0) rescue_plan(R, codes + roff[r], L, ix, fm, P, plans[(size_t)r], tj[(size_t)t]);
+            }
+        });
+        // the DP jobs of all threads as one batch
+        std::vector<int64_t> base((size_t)threads + 1, 0);
+        for (int t = 0; t < threads; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)tj[(size_t)t].qlen.size();
+        lamsa_hp_dp_out dpo; memset(&dpo, 0, sizeof dpo);
+        if (base[(size_t)threads] > 0) {
+            RescueJobs all;
+            for (int t = 0; t < threads; ++t) {
+                const RescueJobs &j = tj[(size_t)t];
+                const int64_t s0 = (int64_t)all.seq.size();
+                all.seq.insert(all.seq.end(), j.seq.begin(), j.seq.end());
+                for (size_t k = 0; k < j.qlen.size(); ++k) { all.q_off.push_back(j.q_off[k] + s0); all.t_off.push_back(j.t_off[k] + s0); }
+                all.qlen.insert(all.qlen.end(), j.qlen.begin(), j.qlen.end()); all.tlen.insert(all.tlen.end(), j.tlen.begin(), j.tlen.end());
+                all.kind.insert(all.kind.end(), j.kind.begin(), j.kind.end()); all.w.insert(all.w.end(), j.w.begin(), j.w.end()); all.h0.insert(all.h0.end(), j.h0.begin(), j.h0.end());
+            }
+            all.seq.resize(all.seq.size() + 16, 0);
+            lamsa_hp_dp_jobs dj;
+            dj.n_jobs = (int32_t)all.qlen.size(); dj.seq = all.seq.data(); dj.seq_bytes = (int64_t)all.seq.size(); dj.q_off = all.q_off.data(); dj.qlen = all.qlen.data();
+            dj.t_off = all.t_off.data(); dj.tlen = all.tlen.data(); dj.kind = all.kind.data(); dj.w = all.w.data(); dj.h0 = all.h0.data();
+            const int e = lamsa_hp_dp_batch(h_dp, &dj, &dpo);
+            if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_dp_batch (stage 4) failed: %d %s\n", e, lamsa_hp_last_error(h_dp)); return 2; }
+            for (int32_t k = 0; k < dj.n_jobs; ++k) if (dpo.status[k] != 0) { fprintf(stderr, "[lamsa_aln] a stage-4 DP job overflowed its work buffer\n"); return 2; }
+            n_rescue_jobs += dj.n_jobs;
+        }
+        std::vector<std::string> sams((size_t)threads);
+        parallel_blocks(n, threads, [&](int t, int, int) {
+            std::string &o = sams[(size_t)t];
+            DpResults dp; dp.score = dpo.score; dp.qle = dpo.qle; dp.tle = dpo.tle; dp.cig_off = dpo.cig_off; dp.cigar = dpo.cigar; dp.base = base[(size_t)t];
+            for (int r = t_first[(size_t)t]; r < t_last[(size_t)t]; ++r) {
+                ReadResult &R = RR[(size_t)r];
+                const int L = (int)B.reads[(size_t)r].seq.size();
+                if (rescue && R.status == 0 && !plans[(size_t)r].lines.empty()) rescue_finish(R, codes + roff[r], L, ix, P, plans[(size_t)r], dp);
+                if (R.status != 0) {
+                    ++bad_of[(size_t)t];
+                    fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[(size_t)r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow");
+                    for (int st = 0; st < 3; ++st) R.stage[st].clear();
+                }
                 rank_results(R, L, P);
                 write_sam(o, R, B.reads[(size_t)r], ix, opt);
             }
@@ -799,6 +849,18 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
         sam_s += now_s() - t1;
+        return 0;
+    };
+    std::future<int> writer;                                 // the write_chunk task of the chunk collected last
+    auto collect_and_write = [&](Chunk *ck) -> int {
+        if (writer.valid()) { const int e = writer.get(); if (e) return e; }      // its result buffers are about to be reused
+        lamsa_hp_result res;
+        const double t0 = now_s();
+        const int e = lamsa_hp_collect_batch(h, &res);
+        wait_s += now_s() - t0;
+        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
+        kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
+        writer = std::async(std::launch::async, write_chunk, ck, res);
         return 0;
     };
     // Two chunks are in flight on the device (lamsa_hp_submit_batch): while the GPU aligns chunk i-1, chunk i is
@@ -824,14 +886,16 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             next = std::async(std::launch::async, prepare);  // overlaps with everything below
             ret = submit(*cur);
         }
-        if (flying) { const int e = collect_and_write(flying->B); if (e && !ret) ret = e; flying = nullptr; }
+        if (flying) { const int e = collect_and_write(flying); if (e && !ret) ret = e; flying = nullptr; }
         if (!have || ret) break;
         flying = cur;
     }
+    if (writer.valid()) { const int e = writer.get(); if (e && !ret) ret = e; }
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();
     saver.close();
     lamsa_hp_destroy(h);
+    if (h_dp) lamsa_hp_destroy(h_dp);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
                  stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; }
     return ret;

@@ -96,7 +96,6 @@ int main(int argc, char *argv[])
     lamsa_hp_para_finish(&P);
     if (argc - optind != 2) return usage();
     opt.ref_prefix = argv[optind]; opt.reads = argv[optind + 1];
-    if (P.bwt_max_len != 0) fprintf(stderr, "[lamsa_aln] note: stage 4 (BWT rescue of uncovered gaps <= -R %d bp) is not part of this build; output equals the reference's with -R 0\n", P.bwt_max_len);
     if (opt.gem_dir.empty()) {                                       // get_bin_dir, src/lamsa_aln.c: <directory of the executable>/gem
         std::string self = argv[0];
         const size_t sl = self.rfind('/');

@@ -4,6 +4,7 @@
 // liblamsa_hp.so and has no CPU path).
 #include <deque>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 #include "hp_para.h"
@@ -11,8 +12,15 @@
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
                                int32_t *stream, int64_t stream_cap, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status);
 
+extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
+                            const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,
+                            const int32_t *kind, const int32_t *w, const int32_t *h0,
+                            int32_t *score, int32_t *qle, int32_t *tle, int32_t *status,
+                            int32_t *cig_n, const int64_t *cig_cap_off, int32_t *cig, size_t slab_bytes);
+
 struct lamsa_hp_handle {
     lamsa_hp_para P; lamsa_hp_ref ref; std::string err;
+    std::vector<int32_t> d_score, d_qle, d_tle, d_status, d_cig; std::vector<int64_t> d_off;      // lamsa_hp_dp_batch results
     std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off;
     struct Done { std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off; };
     std::deque<Done> fifo;                 // lamsa_hp_submit_batch computes at once; lamsa_hp_collect_batch hands the oldest out
@@ -20,7 +28,9 @@ struct lamsa_hp_handle {
 
 extern "C" int lamsa_hp_create(lamsa_hp_handle **out, const lamsa_hp_para *para, const lamsa_hp_ref *ref, int)
 {
-    lamsa_hp_handle *h = new lamsa_hp_handle; h->P = *para; h->ref = *ref; *out = h; return LAMSA_HP_OK;
+    lamsa_hp_handle *h = new lamsa_hp_handle; h->P = *para;
+    if (ref) h->ref = *ref; else memset(&h->ref, 0, sizeof h->ref);
+    *out = h; return LAMSA_HP_OK;
 }
 extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h) { delete h; }
 extern "C" const char *lamsa_hp_last_error(const lamsa_hp_handle *h) { return h ? h->err.c_str() : "null handle"; }
@@ -59,12 +69,17 @@ extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B,
 extern "C" int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B)
 {
     if (h->fifo.size() >= 2) { h->err = "two batches are already in flight: collect one first"; return LAMSA_HP_EINVAL; }
+    // the vectors handed out by the last collect stay untouched (the caller may still be reading them, as with the product):
+    // they are parked while this batch is computed into fresh ones
+    lamsa_hp_handle::Done keep;
+    keep.stream.swap(h->stream); keep.len.swap(h->len); keep.status.swap(h->status); keep.tb.swap(h->tb); keep.off.swap(h->off);
     lamsa_hp_result r;
     const int rc = lamsa_hp_align_batch(h, B, &r);
-    if (rc) return rc;
     h->fifo.emplace_back();
     lamsa_hp_handle::Done &d = h->fifo.back();
     d.stream.swap(h->stream); d.len.swap(h->len); d.status.swap(h->status); d.tb.swap(h->tb); d.off.swap(h->off);
+    h->stream.swap(keep.stream); h->len.swap(keep.len); h->status.swap(keep.status); h->tb.swap(keep.tb); h->off.swap(keep.off);
+    if (rc) { h->fifo.pop_back(); return rc; }
     return LAMSA_HP_OK;
 }
 extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
@@ -80,3 +95,21 @@ extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
 }
 extern "C" void *lamsa_hp_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 extern "C" void lamsa_hp_host_free(void *p) { free(p); }
+
+extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, lamsa_hp_dp_out *O)
+{
+    const int n = J->n_jobs;
+    std::vector<int64_t> cap((size_t)n + 1, 0);
+    size_t need = 1 << 20;
+    for (int i = 0; i < n; ++i) { cap[i + 1] = cap[i] + J->qlen[i] + J->tlen[i] + 8; const size_t z = (size_t)(J->qlen[i] + 64) * (size_t)(J->tlen[i] + 64) + (1 << 16); if (z > need) need = z; }
+    std::vector<int32_t> cn((size_t)n + 1, 0), raw((size_t)cap[n] + 4, 0);
+    h->d_score.assign((size_t)n + 1, 0); h->d_qle.assign((size_t)n + 1, 0); h->d_tle.assign((size_t)n + 1, 0); h->d_status.assign((size_t)n + 1, 0);
+    emu_dp_batch(&h->P, n, J->seq, J->q_off, J->qlen, J->t_off, J->tlen, J->kind, J->w, J->h0, h->d_score.data(), h->d_qle.data(), h->d_tle.data(), h->d_status.data(),
+                 cn.data(), cap.data(), raw.data(), need + (1 << 20));
+    h->d_off.assign((size_t)n + 1, 0); h->d_cig.clear();
+    for (int i = 0; i < n; ++i) { h->d_off[i] = (int64_t)h->d_cig.size(); h->d_cig.insert(h->d_cig.end(), raw.begin() + cap[i], raw.begin() + cap[i] + cn[i]); }
+    h->d_off[n] = (int64_t)h->d_cig.size();
+    if (h->d_cig.empty()) h->d_cig.push_back(0);
+    O->score = h->d_score.data(); O->qle = h->d_qle.data(); O->tle = h->d_tle.data(); O->status = h->d_status.data(); O->cig_off = h->d_off.data(); O->cigar = h->d_cig.data();
+    return LAMSA_HP_OK;
+}

@@ -41,7 +41,8 @@ def same_dp(exp, got, kind):
     return bad
 
 
-SCENARIOS = ("c1_perfect", "c2_pacbio", "c3_ont", "c4_pb20k", "c5_sv", "c6_edge")
+SCENARIOS = ("c1_perfect", "c2_pacbio", "c3_ont", "c4_pb20k", "c5_sv", "c6_edge", "c7_rescue", "c8_rescue_ont")
+RESCUE_SCENARIOS = ("c7_rescue", "c8_rescue_ont")      # stage 4 changes their output: golden_full.sam is the default run
 
 
 def stage_scenario(name, tmpdir):
@@ -50,7 +51,7 @@ def stage_scenario(name, tmpdir):
     import gzip
     import shutil
     d = os.path.join(GOLD, name)
-    for ext in (".ann", ".amb", ".pac"):
+    for ext in (".ann", ".amb", ".pac", ".bwt", ".sa"):
         shutil.copy(os.path.join(GOLD, "ref", "ref.fa" + ext), os.path.join(tmpdir, "ref.fa" + ext))
     shutil.copy(os.path.join(d, "reads.fa"), os.path.join(tmpdir, "reads.fa"))
     with gzip.open(os.path.join(d, "reads.fa.seed.gem.map.gz"), "rb") as f, open(os.path.join(tmpdir, "reads.fa.seed.gem.map"), "wb") as g:
@@ -58,6 +59,11 @@ def stage_scenario(name, tmpdir):
     args = open(os.path.join(d, "args.txt")).read().split()
     gold = open(os.path.join(d, "golden_R0.sam")).read()
     return os.path.join(tmpdir, "ref.fa"), os.path.join(tmpdir, "reads.fa"), args, gold
+
+
+def golden_full(name):
+    """SAM of the reference's default run (stage 4 on) for the scenarios where it differs from -R 0."""
+    return open(os.path.join(GOLD, name, "golden_full.sam")).read()
 
 
 def strip_pg(text):

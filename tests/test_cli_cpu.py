@@ -74,3 +74,19 @@ def test_binary_hit_stream_round_trip(cli, tmp_path):
     ref2, reads2, args2, _ = G.stage_scenario("c2_pacbio", str(tmp_path / "other"))
     bad = subprocess.run([cli, "aln", "-R", "0", "--hits", hits] + args + [ref, reads2], capture_output=True, text=True)
     assert bad.returncode != 0 and "hit stream" in bad.stderr
+
+
+@pytest.mark.parametrize("name", G.RESCUE_SCENARIOS)
+def test_stage4_bwt_rescue_matches_reference_default_run(cli, name, tmp_path):
+    """Default -R: regions the first rounds left uncovered are searched in the FM index (<ref>.bwt/.sa), chained and
+    aligned (lamsa_amd/host/rescue.cpp + one DP batch) -- SAM identical to the reference's default run; without the index
+    files the stage is skipped with a note and the output is the -R 0 one."""
+    ref, reads, args, want_r0 = G.stage_scenario(name, str(tmp_path))
+    p = subprocess.run([cli, "aln", "-N", "--batch", "5"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full(name))
+    assert G.strip_pg(G.golden_full(name)) != G.strip_pg(want_r0)
+    os.remove(ref + ".sa")
+    q = subprocess.run([cli, "aln", "-N"] + args + [ref, reads], capture_output=True, text=True)
+    assert q.returncode == 0 and "stage 4" in q.stderr
+    assert G.strip_pg(q.stdout) == G.strip_pg(want_r0)

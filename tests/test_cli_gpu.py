@@ -51,3 +51,13 @@ def test_end_to_end_files_at_scale(tmp_path):
     a, b = G.strip_pg(got.stdout), G.strip_pg(want.stdout)
     assert len(a.splitlines()) >= 1024 + 6
     assert a == b
+
+
+@pytest.mark.parametrize("name", G.RESCUE_SCENARIOS)
+def test_stage4_bwt_rescue_matches_reference_default_run(name, tmp_path):
+    """Default -R on the MI355X: stage 4 plans on the host, runs its DP jobs as one lamsa_hp_dp_batch on a second handle,
+    and the SAM equals the reference's default run."""
+    ref, reads, args, _ = G.stage_scenario(name, str(tmp_path))
+    p = subprocess.run([BIN, "aln", "-N", "--batch", "5"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full(name))

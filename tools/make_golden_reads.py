@@ -1,6 +1,6 @@
 """Whole-path golden fixtures: simulated reads -> real GEM seeding -> reference SAM.
 
-Shared index: tests/golden/ref/ref.fa.{ann,amb,pac}.  For every scenario: tests/golden/<name>/{reads.fa,
+Shared index: tests/golden/ref/ref.fa.{ann,amb,pac,bwt,sa}.  For every scenario: tests/golden/<name>/{reads.fa,
 reads.fa.seed.gem.map.gz,args.txt,golden_R0.sam[,golden_full.sam if it differs]}.  `golden_R0.sam` is the
 reference run with `-N -I -R 0` (stage 4, the BWT rescue, disabled from the command line),
 `golden_full.sam` the default run.  Inputs and outputs only -- nothing of the reference's code.
@@ -29,14 +29,50 @@ SCEN = [  # name, args, n_reads, length, profile, extra
     ("c4_pb20k", ["-T", "pacbio", "-w", "200"], 2, 20000, "pb20k", {}),
     ("c5_sv", ["-V", "10000"], 10, 10000, "lowerr", {"sv_frac": 0.67}),
     ("c6_edge", ["-T", "ont2d"], 6, 2500, "ont", {"n_frac": 0.01, "edge": True}),
+    # stage 4 (BWT rescue): reads carrying 40-320 bp pieces of other loci between their flanks; default -R
+    ("c7_rescue", [], 14, 4000, "lowerr", {"rescue": True}),
+    ("c8_rescue_ont", ["-T", "ont2d"], 8, 6000, "ont", {"rescue": True}),
 ]
+
+
+def rescue_reads(rng, contigs, n, length, sub, ins, dele):
+    """Reads of contig 0 with one to three short foreign pieces (other contig or 50 kbp away, either strand) spliced in or
+    replacing as many bases; independent errors everywhere; half of the reads reverse-complemented."""
+    reads = []
+    for k in range(n):
+        p = int(rng.integers(20000, 200000)); base = contigs[0][p:p + length].copy()
+        pieces, cur = [], 0
+        for m in sorted(rng.integers(300, length - 300, int(rng.integers(1, 4))).tolist()):
+            if m <= cur + 200:
+                continue
+            w = int(rng.integers(40, 320)); q = int(rng.integers(5000, 120000))
+            piece = contigs[1][q:q + w].copy() if rng.random() < 0.7 else contigs[0][(p + 50000) % 200000:(p + 50000) % 200000 + w].copy()
+            if rng.random() < 0.4:
+                piece = simdata.COMP[piece[::-1]]
+            pieces += [base[cur:m], piece]; cur = m + (w if rng.random() < 0.5 else 0)
+        pieces.append(base[cur:])
+        r, out, e = np.concatenate(pieces), [], None
+        e = rng.random(len(r))
+        for i, c in enumerate(r):
+            if e[i] < sub:
+                out.append((int(c) + 1 + int(rng.integers(0, 3))) % 4)
+            elif e[i] < sub + ins:
+                out += [int(c), int(rng.integers(0, 4))]
+            elif e[i] >= sub + ins + dele:
+                out.append(int(c))
+        r = np.array(out, dtype=np.uint8)
+        if rng.random() < 0.5:
+            r = simdata.COMP[r[::-1]]
+        reads.append(("rescue_%d" % k, r))
+    return reads
 
 
 def run(cmd, **kw):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
 
 
-def make_reads():
+def make_reads(only=None):
+    """only: names of the scenarios to (re)generate; default all."""
     rng = np.random.default_rng(REF["seed"])
     contigs = simdata.make_reference(rng, REF["contigs"], REF["repeats"])
     tmp = tempfile.mkdtemp(prefix="lamsa_gold_")
@@ -44,11 +80,16 @@ def make_reads():
     simdata.write_fasta(ref, [("chr%d" % (i + 1), c) for i, c in enumerate(contigs)])
     run([LAMSA, "index", ref])
     for si, (name, args, n, length, prof, extra) in enumerate(SCEN):
+        if only and name not in only:
+            continue
         d = os.path.join(GOLD, name)
         os.makedirs(d, exist_ok=True)
         rng = np.random.default_rng(1000 + si)
         sub, ins, dele = simdata.PROFILES[prof]
-        reads = simdata.simulate_reads(rng, contigs, n, length, sub, ins, dele, extra.get("sv_frac", 0.0), n_frac=extra.get("n_frac", 0.0))
+        if extra.get("rescue"):
+            reads = rescue_reads(rng, contigs, n, length, sub, ins, dele)
+        else:
+            reads = simdata.simulate_reads(rng, contigs, n, length, sub, ins, dele, extra.get("sv_frac", 0.0), n_frac=extra.get("n_frac", 0.0))
         if extra.get("edge"):
             reads.append(("short_read", rng.integers(0, 4, 30, dtype=np.uint8)))                 # shorter than a seed
             reads.append(("random_read", rng.integers(0, 4, 3000, dtype=np.uint8)))               # no seed hits
@@ -60,7 +101,7 @@ def make_reads():
         run([LAMSA, "aln"] + args + ["-t", "1", ref, rd, "-o", os.path.join(tmp, name + ".full.sam")])
         run([LAMSA, "aln"] + args + ["-t", "1", "-N", "-I", "-R", "0", ref, rd, "-o", os.path.join(tmp, name + ".R0.sam")])
         os.makedirs(os.path.join(GOLD, "ref"), exist_ok=True)
-        for ext in (".ann", ".amb", ".pac"):
+        for ext in (".ann", ".amb", ".pac", ".bwt", ".sa"):      # .bwt / .sa: the FM index stage 4 searches
             shutil.copy(ref + ext, os.path.join(GOLD, "ref", "ref.fa" + ext))
         shutil.copy(rd, os.path.join(d, "reads.fa"))
         with open(rd + ".seed.gem.map", "rb") as f, gzip.GzipFile(os.path.join(d, "reads.fa.seed.gem.map.gz"), "wb", mtime=0) as g:
@@ -82,4 +123,4 @@ def make_reads():
 
 
 if __name__ == "__main__":
-    make_reads()
+    make_reads(set(sys.argv[1:]) or None)
