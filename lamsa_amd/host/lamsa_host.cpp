@@ -9,8 +9,7 @@
 //   write_sam       <- aln_res_output / print_sam_header        src/lamsa_aln.c:1001-1100,1215
 //   run_aln         <- lamsa_aln_core chunk loop                src/lamsa_aln.c:1116-1177
 // The per-read stages (2),(3),(2'),(3') are NOT here: they run on the GPU behind lamsa_hp_align_batch()
-// (include/lamsa_hp.h).  Stage (4), the BWT rescue of short uncovered gaps (src/bwt_aln.c), is not built yet:
-// the output equals the reference's with `-R 0`.
+// (include/lamsa_hp.h).  Stage (4), the BWT rescue of short uncovered regions (src/bwt_aln.c), is in rescue.cpp.
 #include "lamsa_host.h"
 #include "rescue.h"
 #include <algorithm>
