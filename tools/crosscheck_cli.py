@@ -1,5 +1,5 @@
 """Local cross-check (needs /root/reference built into oracle/_ref, so it runs in the build container only):
-simulated reads -> reference `lamsa aln -R 0` vs this repo's host CLI (tests/_build/lamsa_emu by default, or the
+simulated reads -> reference `lamsa aln` (default run, stage 4 included) vs this repo's host CLI (tests/_build/lamsa_emu by default, or the
 product binary given as argv[1] on a GPU box holding the staged inputs).  Also covers FASTQ input and the output options.
 
     python tools/crosscheck_cli.py [binary] [n_reads]
@@ -34,12 +34,16 @@ def main():
     cases = [("pacbio", ["-T", "pacbio"], 5000, "pacbio", {}), ("ont", ["-T", "ont2d"], 8000, "ont", {}), ("sv", [], 10000, "lowerr", {"sv_frac": 0.67}),
              ("soft", ["-T", "ont2d", "-S"], 4000, "ont", {}), ("split", ["-T", "pacbio", "-g", "50", "-r", "3"], 6000, "pacbio", {"sv_frac": 0.5}),
              ("score", ["-m", "2", "-M", "5", "-O", "4,6", "-E", "1,2", "-w", "50", "-b", "3", "-v", "0.5", "-s", "5"], 5000, "lowerr", {"sv_frac": 0.3}),
-             ("fastq", ["-T", "ont2d"], 3000, "ont", {"fastq": True}), ("fa_C", ["-C"], 3000, "lowerr", {})]
+             ("fastq", ["-T", "ont2d"], 3000, "ont", {"fastq": True}), ("fa_C", ["-C"], 3000, "lowerr", {}),
+             ("rescue", [], 4000, "lowerr", {"rescue": True}), ("rescueP", ["-T", "pacbio"], 5000, "pacbio", {"rescue": True}), ("rescueR", ["-R", "150", "-k", "15"], 4000, "lowerr", {"rescue": True})]
     # (`-C` together with FASTQ input is not compared: the reference's reverse-strand QUAL loop, src/lamsa_aln.c:1043, runs off the array.)
     for si, (name, args, length, prof, extra) in enumerate(cases):
         rng = np.random.default_rng(7000 + si)
         sub, ins, dele = simdata.PROFILES[prof]
-        reads = simdata.simulate_reads(rng, contigs, n_reads, length, sub, ins, dele, extra.get("sv_frac", 0.0))
+        if extra.get("rescue"):
+            reads = M.rescue_reads(rng, contigs, n_reads, length, sub, ins, dele)
+        else:
+            reads = simdata.simulate_reads(rng, contigs, n_reads, length, sub, ins, dele, extra.get("sv_frac", 0.0))
         rd = os.path.join(tmp, name + (".fq" if extra.get("fastq") else ".fa"))
         if extra.get("fastq"):
             with open(rd, "w") as f:
@@ -48,8 +52,8 @@ def main():
                     f.write("@%s some comment\n%s\n+\n%s\n" % (nm, "".join("ACGTN"[int(c)] for c in s), q))
         else:
             simdata.write_fasta(rd, reads, width=70)
-        want = subprocess.run([LAMSA, "aln"] + args + ["-t", "1", "-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
-        got = subprocess.run([binary, "aln", "-N"] + args + ["-R", "0", ref, rd], check=True, capture_output=True, text=True).stdout
+        want = subprocess.run([LAMSA, "aln"] + args + ["-t", "1", ref, rd], check=True, capture_output=True, text=True).stdout      # default -R: stage 4 on
+        got = subprocess.run([binary, "aln", "-N"] + args + [ref, rd], check=True, capture_output=True, text=True).stdout
         same = G.strip_pg(got) == G.strip_pg(want)
         print("%-8s %s  %d lines" % (name, "identical" if same else "DIFFERENT", len(want.splitlines())))
         if not same:
