@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <future>
 #include <memory>
 #include <thread>
@@ -667,15 +668,21 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     FastxReader fx;
     if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
     lamsa_hp_ref ref; ref.pac = ix.pac.data(); ref.l_pac = ix.l_pac; ref.n_seqs = (int32_t)ix.name.size(); ref.seq_offset = ix.off.data(); ref.seq_len = ix.len.data();
-    lamsa_hp_handle *h = nullptr;
-    int rc = opt.parse_only ? LAMSA_HP_OK : lamsa_hp_create(&h, &P, &ref, opt.device);
+    // one handle per GPU: the read stream is dealt out chunk by chunk, the reference is resident on
+    // every device, nothing is exchanged between devices
+    std::vector<int> devs = opt.devices.empty() ? std::vector<int>(1, opt.device) : opt.devices;
+    std::vector<lamsa_hp_handle *> hs;
+    int rc = LAMSA_HP_OK;
+    for (size_t g = 0; g < devs.size() && rc == LAMSA_HP_OK && !opt.parse_only; ++g) { lamsa_hp_handle *hh = nullptr; rc = lamsa_hp_create(&hh, &P, &ref, devs[g]); if (rc == LAMSA_HP_OK) hs.push_back(hh); }
+    if (rc != LAMSA_HP_OK) for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh);
+    const int G = (int)std::max<size_t>(1, hs.size());
     if (rc != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] no usable MI355X / HIP device (lamsa_hp_create: %d); this build has no CPU path\n", rc); return 2; }
     // stage (4): needs the reference's FM index files and a second handle for its DP batches (a handle is single-threaded)
     FmIndex fm; lamsa_hp_handle *h_dp = nullptr; bool rescue = false; long n_rescue_jobs = 0;
     if (P.bwt_max_len > 0 && !opt.parse_only) {
         std::string e2;
         if (!fm.load(opt.ref_prefix, e2)) fprintf(stderr, "[lamsa_aln] note: stage 4 (BWT rescue of uncovered regions <= -R %d bp) is skipped: %s; output equals the reference's with -R 0\n", P.bwt_max_len, e2.c_str());
-        else if (lamsa_hp_create(&h_dp, &P, nullptr, opt.device) != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] cannot create the stage-4 handle\n"); lamsa_hp_destroy(h); return 2; }
+        else if (lamsa_hp_create(&h_dp, &P, nullptr, devs[0]) != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] cannot create the stage-4 handle\n"); for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh); return 2; }
         else rescue = true;
     }
     const double load_s = now_s() - t_begin;
@@ -689,14 +696,14 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
     // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
     // The chunk buffers are recycled.
-    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; };
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; int dev = 0; };
     HitsWriter saver;
     if (!opt.save_hits.empty() && !from_hits && !saver.open(opt.save_hits, P)) { fprintf(stderr, "[lamsa_aln] Can't write hit stream %s\n", opt.save_hits.c_str()); return 1; }
-    Chunk pool[6]; int n_scanned = 0;
+    std::vector<Chunk> pool((size_t)G + 6); int n_scanned = 0;      // scanning, parsing, submitted (G + 1), being written, slack
     std::vector<Batch> parts((size_t)threads);              // per-thread partial batches of the parse, recycled too
     const bool trace = getenv("LAMSA_TRACE") != nullptr;
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
-        Chunk *c = &pool[n_scanned++ % 6];
+        Chunk *c = &pool[(size_t)(n_scanned++ % (G + 6))];
         Batch &B = c->B;
         B.clear(); c->ret = 0; c->span.clear(); c->mapped = false;
         if (eof) return c;
@@ -760,6 +767,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         parse_s += now_s() - t0;                            // one prepare() runs at a time
         return c;
     };
+    long n_submitted = 0;
     auto submit = [&](Chunk &ck) -> int {
         Batch &B = ck.B;
         lamsa_hp_batch hb;
@@ -775,9 +783,10 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!hb.read_seq) hb.read_seq = &zero8;
         }
         const double t0 = now_s();
-        const int e = lamsa_hp_submit_batch(h, &hb);
+        ck.dev = (int)(n_submitted++ % G);
+        const int e = lamsa_hp_submit_batch(hs[(size_t)ck.dev], &hb);
         submit_s += now_s() - t0;
-        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_submit_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
+        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_submit_batch failed: %d %s\n", e, lamsa_hp_last_error(hs[(size_t)ck.dev])); return 2; }
         return 0;
     };
     // records -> MAPQ / XA -> SAM text, on all host threads; written in input order
@@ -855,10 +864,11 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (writer.valid()) { const int e = writer.get(); if (e) return e; }      // its result buffers are about to be reused
         lamsa_hp_result res;
         const double t0 = now_s();
-        const int e = lamsa_hp_collect_batch(h, &res);
+        lamsa_hp_handle *hc = hs[(size_t)ck->dev];
+        const int e = lamsa_hp_collect_batch(hc, &res);
         wait_s += now_s() - t0;
-        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(h)); return 2; }
-        kernel_ms += lamsa_hp_last_kernel_ms(h, 0) + lamsa_hp_last_kernel_ms(h, 1);
+        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(hc)); return 2; }
+        kernel_ms += lamsa_hp_last_kernel_ms(hc, 0) + lamsa_hp_last_kernel_ms(hc, 1);
         writer = std::async(std::launch::async, write_chunk, ck, res);
         return 0;
     };
@@ -876,7 +886,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         return ret;
     }
     std::future<Chunk *> next = std::async(std::launch::async, prepare);
-    Chunk *flying = nullptr;                                 // submitted, not yet collected
+    std::deque<Chunk *> flying;                              // submitted, not yet collected: at most two per device
     for (;;) {
         Chunk *cur = next.get();
         if (cur->ret) ret = cur->ret;
@@ -884,16 +894,19 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (have) {
             next = std::async(std::launch::async, prepare);  // overlaps with everything below
             ret = submit(*cur);
+            if (!ret) flying.push_back(cur);
         }
-        if (flying) { const int e = collect_and_write(flying); if (e && !ret) ret = e; flying = nullptr; }
+        while (!flying.empty() && ((int)flying.size() > G || !have || ret)) {
+            const int e = collect_and_write(flying.front()); if (e && !ret) ret = e;
+            flying.pop_front();
+        }
         if (!have || ret) break;
-        flying = cur;
     }
     if (writer.valid()) { const int e = writer.get(); if (e && !ret) ret = e; }
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();
     saver.close();
-    lamsa_hp_destroy(h);
+    for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh);
     if (h_dp) lamsa_hp_destroy(h_dp);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
                  stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; }

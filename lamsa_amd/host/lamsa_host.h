@@ -60,6 +60,7 @@ void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P);
 struct Options {
     std::string ref_prefix, reads, seed_result;
     int supp_soft = 0, comm = 0, device = 0, n_thread = 1;
+    std::vector<int> devices;                             // --devices 0,1,...: chunks go round-robin over these GPUs (default: --device)
     // seeding front end (lamsa_aln_c, src/lamsa_aln.c:1224-1275): -N reuses <reads>.seed.gem.map, otherwise the read file is
     // cut into seeds and the GEM mapper of the reference's bundle is run on them
     int no_seed_aln = 0, fastest = 0;

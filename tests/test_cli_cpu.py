@@ -90,3 +90,11 @@ def test_stage4_bwt_rescue_matches_reference_default_run(cli, name, tmp_path):
     q = subprocess.run([cli, "aln", "-N"] + args + [ref, reads], capture_output=True, text=True)
     assert q.returncode == 0 and "stage 4" in q.stderr
     assert G.strip_pg(q.stdout) == G.strip_pg(want_r0)
+
+
+def test_chunks_dealt_over_several_devices(cli, tmp_path):
+    """--devices: one handle per listed device, chunks round-robin, output in input order (two handles on device 0 here)."""
+    ref, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path))
+    p = subprocess.run([cli, "aln", "-N", "--batch", "2", "--devices", "0,0,0"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full("c7_rescue"))

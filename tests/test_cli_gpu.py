@@ -61,3 +61,11 @@ def test_stage4_bwt_rescue_matches_reference_default_run(name, tmp_path):
     p = subprocess.run([BIN, "aln", "-N", "--batch", "5"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full(name))
+
+
+def test_chunks_dealt_over_several_devices(tmp_path):
+    """--devices: one handle per listed device, chunks round-robin, output in input order (two handles on device 0 here)."""
+    ref, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path))
+    p = subprocess.run([BIN, "aln", "-N", "--batch", "2", "--devices", "0,0,0"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full("c7_rescue"))
