@@ -98,3 +98,14 @@ def test_chunks_dealt_over_several_devices(cli, tmp_path):
     p = subprocess.run([cli, "aln", "-N", "--batch", "2", "--devices", "0,0,0"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(G.golden_full("c7_rescue"))
+
+
+@pytest.mark.parametrize("name", G.SCENARIOS)
+def test_default_run_equals_reference_default_run(cli, name, tmp_path):
+    """No -R on the command line (stage 4 on, -R 300): the reference's default output -- golden_full.sam where stage 4
+    changed something, golden_R0.sam where the reference's two runs were identical."""
+    ref, reads, args, want_r0 = G.stage_scenario(name, str(tmp_path))
+    want = G.golden_full(name) if name in G.RESCUE_SCENARIOS else want_r0
+    p = subprocess.run([cli, "aln", "-N"] + args + [ref, reads], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(want)
