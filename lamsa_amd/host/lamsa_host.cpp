@@ -813,6 +813,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 if (rescue && R.status == 0) rescue_plan(R, codes + roff[r], L, ix, fm, P, plans[(size_t)r], tj[(size_t)t]);
             }
         });
+        const double t2 = now_s();
         // the DP jobs of all threads as one batch
         std::vector<int64_t> base((size_t)threads + 1, 0);
         for (int t = 0; t < threads; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)tj[(size_t)t].qlen.size();
@@ -836,6 +837,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             for (int32_t k = 0; k < dj.n_jobs; ++k) if (dpo.status[k] != 0) { fprintf(stderr, "[lamsa_aln] a stage-4 DP job overflowed its work buffer\n"); return 2; }
             n_rescue_jobs += dj.n_jobs;
         }
+        const double t3 = now_s();
         std::vector<std::string> sams((size_t)threads);
         parallel_blocks(n, threads, [&](int t, int, int) {
             std::string &o = sams[(size_t)t];
@@ -857,6 +859,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
         sam_s += now_s() - t1;
+        if (trace) fprintf(stderr, "[write] %d reads: records%s %.3f s, stage-4 DP batch (%ld jobs) %.3f s, finish + rank + SAM %.3f s\n", n, rescue ? " + stage-4 plan" : "", t2 - t1, (long)base[(size_t)threads], t3 - t2, now_s() - t3);
         return 0;
     };
     std::future<int> writer;                                 // the write_chunk task of the chunk collected last
