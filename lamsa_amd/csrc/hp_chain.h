@@ -261,7 +261,7 @@ HP_INL void scan_eval(const EdgeK &K, const ScanT &S, const NodeS &Q, int p, int
     const int flag = edge_flag_packed(K, Q, S.T);
     const int ok = inwin & (qslot >= start_slot) & (qslot < S.x) & (Q.dp_flag == dp_flag) & !((Q.strand == 1) & (Q.son_flag <= F_MATCH_THD)) &
                    (flag != F_UNCONNECT) & (flag != F_CHR_DIF);
-    const int pos = ((S.x - 1 - qslot) << 14) | (Q.slot_j & 16383);            // scan order: seeds descending, hits ascending
+    const int pos = (int)((unsigned)(S.x - 1 - qslot) << 14) | (Q.slot_j & 16383);            // scan order: seeds descending, hits ascending
     const int cand = Q.score + 1 + score_table(flag);
     const int nm = Q.NM + S.t_NM;
     const int isneg = ok & (Q.strand == -1) & (flag <= F_MATCH_THD);           // '-': first match precursor wins, :726-733

@@ -903,8 +903,8 @@ HP_INL void sw_mid_fix(Ctx &cx, CigV &out, const cig_t *lc, int ln, const cig_t 
     int Sn = qlen - lqe - rqe, Hn = tlen - lte - rte, half = P->split_len / 2;
     if (iabs(Sn) >= half || iabs(Hn) >= half || iabs(Sn - Hn) >= half || tlen < 0 || qlen < 0) {
         cig_pushv(cx, out, lc, ln);
-        cig_push0(cx, out, (Sn << 4) | C_S);
-        cig_push0(cx, out, (Hn << 4) | C_H);
+        cig_push0(cx, out, (cig_t)((uint32_t)Sn << 4) | C_S);          // the counts can be negative here, as in the reference (src/ksw.c:855): same bits, no UB
+        cig_push0(cx, out, (cig_t)((uint32_t)Hn << 4) | C_H);
         cig_pushv(cx, out, rc, rn);
     } else {
         const size_t mark = arena_mark(cx.tmp);
