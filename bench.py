@@ -212,6 +212,11 @@ def main():
                 "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
         # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
         t0 = time.perf_counter(); h.upload_batch(B); h.run_uploaded(fetch=True, raw=True); t_pcie = time.perf_counter() - t0
+        # the same resident batch one step at a time (every step waited for before the next starts), for comparison with `value`
+        t0 = time.perf_counter()
+        for _ in range(2):
+            h.run_uploaded(fetch=True, raw=True)
+        r_seq = 2 * a.reads / (time.perf_counter() - t0)
 
         def streamed(Bx, k=4):
             """k chunks through the streaming boundary (submit/collect, two in flight): upload of chunk i overlaps the kernel of chunk i-1"""
@@ -248,7 +253,8 @@ def main():
             "config": {"workload": "%s: %d reads/step/GPU x %d bp; reference stand-in %d bp in 24 contigs, %d repeat copies; seed hits simulated "
                                    "(GEM thresholds, <=200/seed): %.1f hits/seed, %.0f hits/read" % (a.workload, a.reads, wl["length"], ref.l_pac, ref.n_copies, hits.mean() if len(hits) else 0, B.n_hits / max(1, a.reads)),
                        "reads_per_step_per_gpu": a.reads, "read_len": wl["length"], "read_type": wl["read_type"], "parallelism": "reads sharded over %d GPU(s), no collectives" % a.gpus},
-            "reads_not_ok": int(tot[3]), "pcie_inclusive_reads_per_s": round(a.reads / t_pcie, 2),
+            "reads_not_ok": int(tot[3]), "steps_queued_two_deep": not a.sequential, "reads_per_s_one_step_at_a_time_rank0": round(r_seq, 2),
+            "pcie_inclusive_reads_per_s": round(a.reads / t_pcie, 2),
             "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": r_stream, "pinned_host_arrays": r_stream_pinned, "chunks": a.stream_chunks},
             "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
             "roofline": roof, "cpu_baseline": cpu,
