@@ -20,7 +20,7 @@ threads = os.cpu_count() or 8
 d = tempfile.mkdtemp(prefix="clib_", dir=os.environ.get("TMPDIR", "/tmp"))
 t = time.time(); ref = simbatch.SimRef(ref_bp, n_contigs=24, seed=5, threads=min(threads, 16))
 B = simbatch.SimBatch(ref, n, L, "ont2d", seed=31, threads=min(threads, 16))
-simfiles.write_index(d + "/ref.fa", ref); simfiles.write_reads(d + "/reads.fa", B)
+simfiles.write_index(d + "/ref.fa", ref); simfiles.write_reads(d + "/reads.fa", B, workers=min(threads, 32))
 print("files written in %.1f s: %d reads, %.0f hits/read, map %.1f MB" % (time.time() - t, n, B.n_hits / n, os.path.getsize(d + "/reads.fa.seed.gem.map") / 1e6), flush=True)
 batch = sys.argv[4] if len(sys.argv) > 4 else "2048"
 for rep, extra in enumerate((["--parse-only"], ["--save-hits", d + "/hits.bin"], [], ["--hits", d + "/hits.bin", "--parse-only"], ["--hits", d + "/hits.bin"], ["--hits", d + "/hits.bin"])):

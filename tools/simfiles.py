@@ -49,10 +49,11 @@ def gigar(words, nm, reverse):
     return "".join(out)
 
 
-def write_reads(path, B, seed_len=50, seed_step=25):
-    """reads.fa + reads.fa.seed.gem.map for batch B (names r0, r1, ...)."""
-    with open(path, "w") as fa, open(path + ".seed.gem.map", "w") as mp:
-        for r in range(B.n_reads):
+def _write_part(args):
+    path, r0, r1, seed_len, seed_step = args
+    B = _SHARED["B"]
+    with open(path + ".fa", "w") as fa, open(path + ".map", "w") as mp:
+        for r in range(r0, r1):
             seq = B.read_seq[int(B.read_off[r]):int(B.read_off[r + 1])]
             fa.write(">r%d\n%s\n" % (r, BASES[seq].tobytes().decode()))
             L = len(seq)
@@ -68,3 +69,32 @@ def write_reads(path, B, seed_len=50, seed_step=25):
                         st = int(B.h_strand[k])
                         hits.append("chr%d:%s:%d:%s" % (int(B.h_chr[k]), "+" if st > 0 else "-", int(B.h_pos[k]), gigar(B.cig[co:co + cn], int(B.h_nm[k]), st < 0)))
                 mp.write("r%d_%d\tN\t*\t0\t%s\n" % (r, sd, ",".join(hits) if hits else "-"))
+    return path
+
+
+_SHARED = {}
+
+
+def write_reads(path, B, seed_len=50, seed_step=25, workers=1):
+    """reads.fa + reads.fa.seed.gem.map for batch B (names r0, r1, ...).  workers > 1: the reads are split over forked
+    worker processes (the batch is shared copy-on-write), their part files concatenated in order."""
+    import os
+    import shutil
+    n = B.n_reads
+    workers = max(1, min(workers, n // 64 if n >= 128 else 1))
+    _SHARED["B"] = B
+    per = (n + workers - 1) // workers
+    jobs = [(path + ".part%d" % w, w * per, min(n, (w + 1) * per), seed_len, seed_step) for w in range(workers) if w * per < n]
+    if workers == 1:
+        parts = [_write_part(j) for j in jobs]
+    else:
+        import multiprocessing as mpc
+        with mpc.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_write_part, jobs)
+    with open(path, "wb") as fa, open(path + ".seed.gem.map", "wb") as mp:
+        for q in parts:
+            for ext, dst in ((".fa", fa), (".map", mp)):
+                with open(q + ext, "rb") as f:
+                    shutil.copyfileobj(f, dst, 1 << 24)
+                os.remove(q + ext)
+    _SHARED.clear()
