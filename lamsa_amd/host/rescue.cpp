@@ -75,13 +75,34 @@ uint64_t FmIndex::sa_at(uint64_t k) const
     return s + sa[(size_t)(k / sa_intv)];
 }
 
+// occ(k, c) and occ(l, c) for k <= l: one walk over the block when both fall into the same 128-symbol block (bwt_2occ :132)
+static inline void occ2(const FmIndex &fm, uint64_t k, uint64_t l, int c, uint64_t *ok, uint64_t *ol)
+{
+    const uint64_t kk = k >= fm.primary ? k - 1 : k, ll = l >= fm.primary ? l - 1 : l;
+    if ((ll >> 7) != (kk >> 7) || k == (uint64_t)-1 || l == (uint64_t)-1 || l == fm.seq_len || k == fm.seq_len) { *ok = fm.occ(k, c); *ol = fm.occ(l, c); return; }
+    const uint32_t *p = fm.bwt.data() + ((kk >> 7) << 4);
+    uint64_t n; memcpy(&n, p + 2 * c, 8);
+    p += 8;
+    uint64_t i = kk & ~127ull;
+    for (const uint64_t j = kk >> 5 << 5; i < j; i += 32, p += 2) n += (uint64_t)occ_aux((uint64_t)p[0] << 32 | p[1], c);
+    uint64_t m = n;
+    n += (uint64_t)occ_aux(((uint64_t)p[0] << 32 | p[1]) & ~((1ull << ((~kk & 31) << 1)) - 1), c);
+    if (c == 0) n -= ~kk & 31;
+    *ok = n;
+    for (const uint64_t j = ll >> 5 << 5; i < j; i += 32, p += 2) m += (uint64_t)occ_aux((uint64_t)p[0] << 32 | p[1], c);
+    m += (uint64_t)occ_aux(((uint64_t)p[0] << 32 | p[1]) & ~((1ull << ((~ll & 31) << 1)) - 1), c);
+    if (c == 0) m -= ~ll & 31;
+    *ol = m;
+}
+
 uint64_t FmIndex::match(int len, const uint8_t *s, uint64_t *k0, uint64_t *l0) const
 {
     uint64_t k = *k0, l = *l0;
     for (int i = len - 1; i >= 0; --i) {
         const int c = s[i];
         if (c > 3) return 0;
-        const uint64_t ok = occ(k - 1, c), ol = occ(l, c);      // bwt_2occ gives the same two values
+        uint64_t ok, ol;
+        occ2(*this, k - 1, l, c, &ok, &ol);
         k = L2[c] + ok + 1; l = L2[c] + ol;
         if (k > l) return 0;
     }

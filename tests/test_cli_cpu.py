@@ -109,3 +109,18 @@ def test_default_run_equals_reference_default_run(cli, name, tmp_path):
     p = subprocess.run([cli, "aln", "-N"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(want)
+
+
+def test_fm_index_queries_against_brute_force(tmp_path):
+    """The FM-index code of stage 4 (occurrence counts, backward search, suffix-array lookup on the reference's .bwt/.sa):
+    hit counts and positions of 3 000 k-mers (k = 19 and k = 12, present and absent) equal a brute-force table of both strands."""
+    exe = str(tmp_path / "fm_check")
+    host = os.path.join(G.ROOT, "lamsa_amd", "host")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", host, "-I", os.path.join(G.ROOT, "include"), "-o", exe,
+                    os.path.join(G.ROOT, "tests", "host", "fm_check.cpp"), os.path.join(host, "rescue.cpp"), os.path.join(host, "lamsa_host.cpp"),
+                    os.path.join(G.ROOT, "tests", "emu", "emu_api.cpp"), os.path.join(G.ROOT, "tests", "emu", "emu_capi.cpp"),
+                    "-I", os.path.join(G.ROOT, "tests", "emu"), "-I", os.path.join(G.ROOT, "lamsa_amd", "csrc"), "-lz", "-lpthread"], check=True)
+    ref, _, _, _ = G.stage_scenario("c7_rescue", str(tmp_path))
+    for k, n in ((19, 2000), (12, 1000)):
+        p = subprocess.run([exe, ref, str(k), str(n)], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.startswith("ok"), p.stdout + p.stderr
