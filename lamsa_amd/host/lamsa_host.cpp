@@ -47,7 +47,11 @@ bool load_index(const std::string &prefix, Index &ix, std::string &err)
         unsigned gi; int c, n_ambs; long long off; std::string line;
         if (fscanf(fp, "%u", &gi) != 1) { fclose(fp); err = "bad .ann record"; return false; }
         while ((c = fgetc(fp)) != '\n' && c != EOF) line.push_back((char)c);
-        ix.name[i] = line.size() > 1 ? line.substr(1) : std::string();
+        {   // bns_restore_core reads the name with %s: the first blank-delimited word; the rest of the line is the comment
+            size_t a = 0; while (a < line.size() && isspace((unsigned char)line[a])) ++a;
+            size_t b = a; while (b < line.size() && !isspace((unsigned char)line[b])) ++b;
+            ix.name[i] = line.substr(a, b - a);
+        }
         if (fscanf(fp, "%lld%d%d", &off, &ix.len[i], &n_ambs) != 3) { fclose(fp); err = "bad .ann record"; return false; }
         ix.off[i] = off;
     }

@@ -192,7 +192,7 @@ def emu_cli():
     os.makedirs(EMU_DIR, exist_ok=True)
     out = os.path.join(EMU_DIR, "lamsa_emu")
     host = os.path.join(ROOT, "lamsa_amd", "host")
-    srcs = [os.path.join(host, "main.cpp"), os.path.join(host, "lamsa_host.cpp"), os.path.join(host, "rescue.cpp"),
+    srcs = [os.path.join(host, "main.cpp"), os.path.join(host, "lamsa_host.cpp"), os.path.join(host, "rescue.cpp"), os.path.join(host, "index.cpp"),
             os.path.join(ROOT, "tests", "emu", "emu_api.cpp"), os.path.join(ROOT, "tests", "emu", "emu_capi.cpp")]
     deps = srcs + [os.path.join(host, "lamsa_host.h"), os.path.join(host, "rescue.h"), os.path.join(ROOT, "include", "lamsa_hp.h"), os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
         [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]

@@ -124,3 +124,37 @@ def test_fm_index_queries_against_brute_force(tmp_path):
     for k, n in ((19, 2000), (12, 1000)):
         p = subprocess.run([exe, ref, str(k), str(n)], capture_output=True, text=True)
         assert p.returncode == 0 and p.stdout.startswith("ok"), p.stdout + p.stderr
+
+
+def test_index_files_identical_to_the_reference(cli, tmp_path):
+    """`lamsa index --no-gem`: .pac/.ann/.amb/.bwt/.sa byte-identical to the reference's `lamsa index` -- on the fixture
+    reference (regenerated from its recipe; expected files = tests/golden/ref) and on a small FASTA with runs of N, other
+    ambiguity codes, lower case, wrapped lines and header comments (tests/golden/index_nrich, expected files made by the
+    reference); then `lamsa aln` runs on the index just built."""
+    import sys
+    sys.path.insert(0, os.path.join(G.ROOT, "tools"))
+    import numpy as np
+    import simdata
+    import make_golden_reads as M
+    rng = np.random.default_rng(M.REF["seed"])
+    contigs = simdata.make_reference(rng, M.REF["contigs"], M.REF["repeats"])
+    ref = str(tmp_path / "ref.fa")
+    simdata.write_fasta(ref, [("chr%d" % (i + 1), c) for i, c in enumerate(contigs)])
+    p = subprocess.run([cli, "index", "--no-gem", ref], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    for ext in (".pac", ".ann", ".amb", ".bwt", ".sa"):
+        assert open(ref + ext, "rb").read() == open(os.path.join(G.GOLD, "ref", "ref.fa" + ext), "rb").read(), ext
+    d = os.path.join(G.GOLD, "index_nrich")
+    small = str(tmp_path / "small.fa")
+    shutil.copy(os.path.join(d, "ref.fa"), small)
+    p = subprocess.run([cli, "index", "--no-gem", small], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    for ext in ("pac", "ann", "amb", "bwt", "sa"):
+        assert open(small + "." + ext, "rb").read() == open(os.path.join(d, "expected." + ext), "rb").read(), ext
+    # the index just built serves `lamsa aln` (default run, stage 4 on)
+    os.makedirs(str(tmp_path / "s"))
+    _, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path / "s"))
+    shutil.copy(reads, str(tmp_path / "reads.fa")); shutil.copy(reads + ".seed.gem.map", str(tmp_path / "reads.fa.seed.gem.map"))
+    q = subprocess.run([cli, "aln", "-N"] + args + [ref, str(tmp_path / "reads.fa")], capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr[-2000:]
+    assert G.strip_pg(q.stdout) == G.strip_pg(G.golden_full("c7_rescue"))
