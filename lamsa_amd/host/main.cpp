@@ -3,8 +3,8 @@
 // soft clipping (missing break, :1509-1510); `-C` gates QUAL instead of appending the comment (:1037).
 // Seeding works as in the reference: unless -N (or --seed-result FILE) is given, the reads are cut into seeds and the
 // GEM mapper of the reference's bundle is run on them (--gem-dir DIR, default <directory of this binary>/gem; the
-// <ref>.gem index comes from the reference's `lamsa index`).  Stage (4), the BWT rescue, needs the reference's <ref>.bwt and
-// <ref>.sa and is skipped with a note when they are missing; `lamsa index` is left to the reference.
+// <ref>.gem index comes from `lamsa index`, here or the reference's).  Stage (4), the BWT rescue, needs <ref>.bwt and
+// <ref>.sa and is skipped with a note when they are missing.  `lamsa index` (index.cpp) writes the reference's index files.
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
