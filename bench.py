@@ -24,6 +24,7 @@ import time
 
 import numpy as np
 
+os.environ["LAMSA_NO_BUILD"] = "1"      # only prebuilt libraries (built by __graft_entry__.build()): never start make / gcc from here
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -35,6 +36,7 @@ WORKLOADS = {
     "pb5k": dict(read_type="pacbio", profile="pacbio", length=5000, over={}, desc="5 kbp PacBio-error reads (~15%), -T pacbio"),
     "pb20k": dict(read_type="pacbio", profile="pb20k", length=20000, over={"band_w": 200}, desc="20 kbp reads at 15% error, -T pacbio -w 200"),
     "mol5k": dict(read_type="default", profile="default", length=5000, over={}, desc="5 kbp 1%-error reads, default type"),
+    "sv10k": dict(read_type="default", profile="sv10k", length=10000, over={"SV_len_thd": 10000}, desc="10 kbp 1%-error reads, 2/3 with a 1-10 kbp deletion or 1-5 kbp insertion, -V 10000"),
 }
 
 
@@ -116,12 +118,13 @@ def main():
     ap.add_argument("--reads", type=int, default=65536, help="reads per batch (= per step) and per GPU; the metric's configuration is 1 M reads over 8 GPUs = 125 k per GPU, "
                     "and one batch holds at most 2^31 seed CIGAR words (~ 125 k reads of this kind)")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
-    ap.add_argument("--threads", type=int, default=16, help="host threads for input generation and the CPU baseline")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for input generation and the CPU baseline (0 = every core of the box, os.cpu_count())")
     ap.add_argument("--sequential", action="store_true", help="wait for every step before starting the next (default: consecutive steps are queued two deep)")
     ap.add_argument("--stream-chunks", type=int, default=8, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
                     "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--bare", action="store_true", help="profiling runs: only set-up, warm-up and the timed steps (no one-call / streamed / CPU legs afterwards)")
     ap.add_argument("--rehearse", action="store_true", help="development only: run the N > 1 code path with the gloo backend and every rank on GPU 0 "
                     "(a one-GPU box cannot run RCCL with two ranks); the driver never passes this")
     a = ap.parse_args()
@@ -148,7 +151,14 @@ def main():
     from lamsa_amd import hp
 
     wl = WORKLOADS[a.workload]
-    threads = max(1, min(a.threads, os.cpu_count() or 1))
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))               # the cores this process may actually use
+    except (AttributeError, OSError):
+        pass
+    threads = ncpu if a.threads <= 0 else max(1, min(a.threads, ncpu))
+    if world > 1:
+        threads = max(1, threads // world)                 # ranks share the box's cores while they simulate their shards
     t0 = time.time()
     ref = simbatch.SimRef(a.ref_bp, n_contigs=24, seed=5, threads=threads, repeats=not a.no_repeats)
     t_ref = time.time() - t0
@@ -170,25 +180,31 @@ def main():
         two deep (lamsa_hp_start_uploaded / finish_uploaded) like the kernels of consecutive training steps: the waves
         of pass i+1 start on the SIMDs that the tail of pass i leaves idle.  --sequential waits for every pass instead."""
         ms, raw = [], None
+
+        def note():
+            ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+            phase_ms.append([h.last_kernel_ms(i) for i in range(1, 13)])
         if a.sequential or k < 2:
             for _ in range(k):
                 raw = h.run_uploaded(fetch=True, raw=True)      # kernels + download of the result streams into host memory
-                ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+                note()
             return ms, raw
         h.start_uploaded()
         for _ in range(k - 1):
             h.start_uploaded()
             raw = h.finish_uploaded(fetch=True, raw=True)
-            ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+            note()
         raw = h.finish_uploaded(fetch=True, raw=True)
-        ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
+        note()
         return ms, raw
 
+    phase_ms = []                                       # per step: retry pass, then the five launches of the main pass (HIP events)
     if not a.sequential:                                # set-up, untimed: both launch lanes allocate their scratch and output buffers
         h.start_uploaded(); h.start_uploaded(); h.finish_uploaded(fetch=False); h.finish_uploaded(fetch=False)
     if a.warmup:
         run_steps(a.warmup)
     sync()
+    del phase_ms[:]
     t0 = time.perf_counter()
     kernel_ms, raw = run_steps(a.steps)
     sync()
@@ -210,13 +226,15 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_align_batch", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
-        # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
-        t0 = time.perf_counter(); h.upload_batch(B); h.run_uploaded(fetch=True, raw=True); t_pcie = time.perf_counter() - t0
-        # the same resident batch one step at a time (every step waited for before the next starts), for comparison with `value`
-        t0 = time.perf_counter()
-        for _ in range(2):
-            h.run_uploaded(fetch=True, raw=True)
-        r_seq = 2 * a.reads / (time.perf_counter() - t0)
+        t_pcie = r_seq = float("nan")
+        if not a.bare:
+            # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
+            t0 = time.perf_counter(); h.upload_batch(B); h.run_uploaded(fetch=True, raw=True); t_pcie = time.perf_counter() - t0
+            # the same resident batch one step at a time (every step waited for before the next starts), for comparison with `value`
+            t0 = time.perf_counter()
+            for _ in range(2):
+                h.run_uploaded(fetch=True, raw=True)
+            r_seq = 2 * a.reads / (time.perf_counter() - t0)
 
         def streamed(Bx, k=4):
             """k chunks through the streaming boundary (submit/collect, two in flight): upload of chunk i overlaps the kernel of chunk i-1"""
@@ -227,13 +245,13 @@ def main():
             h.collect_batch(raw=True)
             return k * a.reads / (time.perf_counter() - t0)
         r_stream = r_stream_pinned = None
-        if a.stream_chunks > 1:
+        if a.stream_chunks > 1 and not a.bare:
             r_stream = round(streamed(B, a.stream_chunks), 2)
             Bp = hp.pinned_batch(B)
             r_stream_pinned = round(streamed(Bp, a.stream_chunks), 2)
             Bp.release()
         cpu = None
-        if a.cpu_seconds > 0 and world == 1:               # the CPU baseline is measured on rank 0 of the single-GPU run only
+        if a.cpu_seconds > 0 and world == 1 and not a.bare:               # the CPU baseline is measured on rank 0 of the single-GPU run only
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
             probe = min(256, a.reads)                      # estimate the rate on a probe, then size the sample for ~cpu_seconds
             t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, threads); tp = time.perf_counter() - t0
@@ -242,8 +260,12 @@ def main():
             t0 = time.perf_counter(); want = reflib.oracle_streams(sample, lp, threads); tc = time.perf_counter() - t0
             same = sum(1 for i in range(n_s) if want[i] == streams[i])
             cpu = {"value": round(float(sample.read_off[-1]) / tc / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "port",
-                   "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path), %d threads, %.1f s" % (n_s, threads, tc),
-                   "reads_per_s": round(n_s / tc, 3), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s)}
+                   "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path, one read per task) on all %d cores of the box, %.1f s" % (n_s, threads, tc),
+                   "reads_per_s": round(n_s / tc, 3), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s), "host_cpu": cpu_model()}
+            try:
+                cpu["reference_binary"] = reference_binary_baseline(B, ref, wl, threads, a.cpu_seconds)
+            except Exception as e:                           # a reported extra, never a reason to lose the bench line
+                cpu["reference_binary"] = {"error": repr(e)[:200]}
         hits = np.diff(B.hit_off)
         out = {
             "metric": "aligned Gbase/s, %s vs GRCh37-sized stand-in" % wl["desc"], "value": round(gbase_per_s, 6), "unit": "Gbase/s",
@@ -253,16 +275,79 @@ def main():
             "config": {"workload": "%s: %d reads/step/GPU x %d bp; reference stand-in %d bp in 24 contigs, %d repeat copies; seed hits simulated "
                                    "(GEM thresholds, <=200/seed): %.1f hits/seed, %.0f hits/read" % (a.workload, a.reads, wl["length"], ref.l_pac, ref.n_copies, hits.mean() if len(hits) else 0, B.n_hits / max(1, a.reads)),
                        "reads_per_step_per_gpu": a.reads, "read_len": wl["length"], "read_type": wl["read_type"], "parallelism": "reads sharded over %d GPU(s), no collectives" % a.gpus},
-            "reads_not_ok": int(tot[3]), "steps_queued_two_deep": not a.sequential, "reads_per_s_one_step_at_a_time_rank0": round(r_seq, 2),
-            "pcie_inclusive_reads_per_s": round(a.reads / t_pcie, 2),
+            "reads_not_ok": int(tot[3]), "steps_queued_two_deep": not a.sequential, "reads_per_s_one_step_at_a_time_rank0": None if a.bare else round(r_seq, 2),
+            "pcie_inclusive_reads_per_s": None if a.bare else round(a.reads / t_pcie, 2),
             "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": r_stream, "pinned_host_arrays": r_stream_pinned, "chunks": a.stream_chunks},
             "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
+            "launch_ms": dict(zip(["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2"],
+                                  [round(float(x), 3) for x in np.mean(np.array(phase_ms), axis=0)])),
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     h.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_binary_baseline(B, ref, wl, threads, seconds):
+    """`lamsa aln -t <all cores> -N -I -R 0` of the REFERENCE ITSELF (oracle/_ref/lamsa, compiled from /root/reference in the build
+    container and shipped as a binary) on files holding a sample of the same batch: FASTA reads, the seed hits as GEM map text,
+    .seed.info, and the stand-in's .ann/.amb/.pac.  The reference refuses to start without <ref>.bwt/.sa (src/lamsa_aln.c:1233);
+    with -R 0 they are loaded and never searched, so the pair of the small fixture reference (tests/golden/ref) stands in for
+    them -- nothing on this box can build the BWT of a 3.1 Gbp text.  Wall time of the whole process (index load, text parse,
+    alignment, SAM) as in BASELINE.md's "hot path" column.  None when the binary did not travel."""
+    import shutil
+    import subprocess
+    import tempfile
+    import simfiles
+    exe = os.path.join(ROOT, "oracle", "_ref", "lamsa")
+    if not os.path.exists(exe):
+        return None
+    p = __import__("simbatch").PROFILES[wl["profile"]]
+    args = [] if wl["read_type"] == "default" else ["-T", wl["read_type"]]
+    flag = {"band_w": "-w", "SV_len_thd": "-V"}
+    for k, v in wl["over"].items():
+        args += [flag[k], str(v)]
+    d = tempfile.mkdtemp(prefix="lamsa_cpu_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        simfiles.write_index(d + "/ref.fa", ref)
+        for ext in ("bwt", "sa"):
+            shutil.copy(os.path.join(ROOT, "tests", "golden", "ref", "ref.fa." + ext), d + "/ref.fa." + ext)
+
+        def run(n):
+            sample = take_first(B, n)
+            simfiles.write_reads(d + "/reads.fa", sample, seed_len=50, seed_step=p["seed_step"], workers=min(threads, 32))
+            with open(d + "/reads.fa.seed.info", "w") as f:
+                for r in range(n):
+                    f.write("r%d %d %d %d\n" % (r, int(sample.seed_all[r]), int(sample.last_len[r]), int(sample.read_off[r + 1] - sample.read_off[r])))
+            t0 = time.perf_counter()
+            q = subprocess.run([exe, "aln"] + args + ["-t", str(threads), "-N", "-I", "-R", "0", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=600)
+            dt = time.perf_counter() - t0
+            if q.returncode != 0:
+                raise RuntimeError("reference exited with %d: %s" % (q.returncode, q.stderr[-200:]))
+            return sample, dt
+        probe = min(128, B.n_reads)
+        _, t_load = run(1)                                  # start-up: .pac / .ann load of the stand-in reference
+        _, tp = run(probe)
+        rate = probe / max(tp - t_load, 1e-3)
+        n = int(max(probe, min(B.n_reads, rate * seconds)))
+        sample, dt = run(n)
+        return {"value": round(float(sample.read_off[-1]) / dt / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "reference",
+                "reads_per_s": round(n / dt, 3), "reads_per_s_excluding_startup": round(n / max(dt - t_load, 1e-3), 3), "startup_s": round(t_load, 2),
+                "sample": "first %d reads as files, `lamsa aln %s -t %d -N -I -R 0` of the compiled reference, %.1f s wall" % (n, " ".join(args), threads, dt)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def take_first(B, n):

@@ -145,6 +145,7 @@ typedef struct lamsa_hp_result {
     const int32_t *read_len;      /* [n_reads] its length in words      */
     const int32_t *read_status;   /* [n_reads] LAMSA_HP_ST_* bits       */
     const int32_t *read_tbases;   /* [n_reads] reference bases the read's DP jobs fetched from the packed reference (accounting) */
+    const int32_t *read_work;     /* [2*n_reads] per read: DP cells updated, chaining edge classes evaluated (accounting: GCUPS, pair evaluations/s) */
 } lamsa_hp_result;
 
 int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_hp_result *res);
@@ -180,7 +181,9 @@ void  lamsa_hp_host_free(void *p);
 
 /* Wall time in milliseconds of the kernel(s) of the most recent call on this handle (for the streaming form: of the
  * batch just collected), measured with HIP events on the stream the kernels ran on; which = 0: the main pass,
- * 1: the second pass over the reads that overflowed their scratch (0 when none did). */
+ * 1: the second pass over the reads that overflowed their scratch (0 when none did); 2..6: the five launches the main
+ * pass consists of (chaining round 1, gap fill of its lines, chaining round 2, gap fill of its lines, result assembly); 7..10: how long each of the first four spent draining (first wave
+ * that found the queue empty -> last wave done, i.e. time with idle wave slots); 11, 12: lines filled in round 1 / round 2. */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
 
 /* Cap the per-wave scratch slab of the first pass at `bytes` (0 = size it from the batch, the default).  The slab

@@ -53,6 +53,7 @@ HP_INL void sync() {
 }
 HP_INL bool leader() { return lane() == 0; }
 HP_INL long long clock() { return (long long)__builtin_readcyclecounter(); }     // diagnostic builds only (-DHP_PROF)
+HP_INL unsigned long long wall() { return (unsigned long long)wall_clock64(); }       // constant-rate counter (100 MHz): launch drain accounting
 HP_INL int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 HP_INL long long uni64(long long v) {
     int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));

@@ -96,6 +96,60 @@ HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap,
     arena_release(cx.tmp, mark);
 }
 
+// ---- one read's view of the batch (hp_batch.h) and its scratch ----
+HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, const BatchIn &in, int rd, char *slab, size_t slab_bytes, HP_L int32_t *lds, long long *prof)
+{
+    r.cx.P = &P; r.cx.status = 0; r.cx.n_cells = 0; r.n_pairs = 0; r.cx.lds = lds; r.cx.prof = prof ? prof + (size_t)rd * 64 : nullptr;
+    arena_init(r.cx.tmp, slab, slab_bytes);
+    r.ref = ref;
+    r.L = (int)(in.read_off[rd + 1] - in.read_off[rd]);
+    r.read = in.read_seq + in.read_off[rd];
+    r.seed_all = in.seed_all[rd]; r.last_len = in.last_len[rd];
+    const int64_t s0 = in.seed_off[rd];
+    r.seed_out = (int)(in.seed_off[rd + 1] - s0);
+    r.seed_id = in.seed_id + s0; r.hit_off = in.hit_off + s0;
+    r.hb = r.hit_off[0];
+    r.H = (int)(r.hit_off[r.seed_out] - r.hb);
+    r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
+    r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
+    r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.rc_read = nullptr; r.t_bases = 0;
+    r.prof = r.cx.prof;
+}
+
+// the packed 32-byte record and the seed slot of every hit, one hit per lane: its slot by binary search in the read's
+// hit offsets (a few hundred entries, cache-resident)
+HP_FN void nodes_fill(ReadCtx &r)
+{
+    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+    const HP_G int32_t *g_sid = (const HP_G int32_t *)r.seed_id;
+    const int64_t hb = r.hb;
+    const int H = r.H;
+    for (int k0 = 0; k0 < H; k0 += 64) {
+        WAVE_FOR(l) {
+            const int k = k0 + l;
+            if (k < H) {
+                int lo = 0, hi = r.seed_out;                 // largest slot s with hit_off[s] - hb <= k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)(g_hoff[mid] - hb) <= k) lo = mid; else hi = mid; }
+                const int s = lo, b = (int)(g_hoff[s] - hb);
+                r.n_seed[k] = s;
+                NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)g_sid[s];
+                q.strand = r.h_strand[k]; q.len_dif8 = (int8_t)r.h_len_dif[k]; q.pad_ = 0;
+                q.dp_flag = 0; q.son_flag = F_INIT; q.match_flag = 0; q.score = 0; q.NM = 0;
+                r.nd[k] = q;
+            }
+        }
+    }
+    wv::sync();
+}
+
+HP_INL void aux_bind(ReadCtx &r, int32_t *nm)
+{
+    const int c = r.H + 1;
+    r.n_from = nm; r.n_in_de = nm + c; r.n_son_n = nm + 2 * c; r.n_first = nm + 3 * c;
+    r.n_last = nm + 4 * c; r.n_next = nm + 5 * c; r.n_max_score = nm + 6 * c; r.n_max_NM = nm + 7 * c; r.n_max_node = nm + 8 * c;
+    r.n_node_n = nm + 9 * c;
+}
+
 // ---- the per-read entry point ----
 #ifdef HP_PROF
 #define HP_STAMP(k) do { const long long now_ = wv::clock(); if (a.prof) a.prof[(size_t)rd * 64 + (k)] += now_ - t_last_; t_last_ = now_; } while (0)
@@ -109,22 +163,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     long long t_last_ = wv::clock();
 #endif
     ReadCtx r;
-    r.cx.P = &a.P; r.cx.status = 0; r.cx.lds = lds; r.cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
-    arena_init(r.cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
-    r.ref = a.ref;
-    const BatchIn &in = a.in;
-    r.L = (int)(in.read_off[rd + 1] - in.read_off[rd]);
-    r.read = in.read_seq + in.read_off[rd];
-    r.seed_all = in.seed_all[rd]; r.last_len = in.last_len[rd];
-    const int64_t s0 = in.seed_off[rd];
-    r.seed_out = (int)(in.seed_off[rd + 1] - s0);
-    r.seed_id = in.seed_id + s0; r.hit_off = in.hit_off + s0;
-    r.hb = r.hit_off[0];
-    r.H = (int)(r.hit_off[r.seed_out] - r.hb);
-    r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
-    r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
-    r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.t_bases = 0;
-    r.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
     Ctx &cx = r.cx;
     const int H = r.H;
     // read-lifetime allocations
@@ -151,31 +190,8 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
         HP_TADD(cx, 46, t_sort_); }
         arena_release(cx.tmp, sort_mark);
         r.srt = sidx; r.rnk = sidx + c;
-        r.n_from = nm; r.n_in_de = nm + c; r.n_son_n = nm + 2 * c; r.n_first = nm + 3 * c;
-        r.n_last = nm + 4 * c; r.n_next = nm + 5 * c; r.n_max_score = nm + 6 * c; r.n_max_NM = nm + 7 * c; r.n_max_node = nm + 8 * c;
-        r.n_node_n = nm + 9 * c; r.n_seed = nm + 10 * c;
-        {   // one hit per lane: its seed slot by binary search in the read's hit offsets (a few hundred entries,
-            // cache-resident), then the packed 32-byte record
-            const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
-            const HP_G int32_t *g_sid = (const HP_G int32_t *)r.seed_id;
-            const int64_t hb = r.hb;
-            for (int k0 = 0; k0 < H; k0 += 64) {
-                WAVE_FOR(l) {
-                    const int k = k0 + l;
-                    if (k < H) {
-                        int lo = 0, hi = r.seed_out;                 // largest slot s with hit_off[s] - hb <= k
-                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)(g_hoff[mid] - hb) <= k) lo = mid; else hi = mid; }
-                        const int s = lo, b = (int)(g_hoff[s] - hb);
-                        r.n_seed[k] = s;
-                        NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)g_sid[s];
-                        q.strand = r.h_strand[k]; q.len_dif8 = (int8_t)r.h_len_dif[k]; q.pad_ = 0;
-                        q.dp_flag = 0; q.son_flag = F_INIT; q.match_flag = 0; q.score = 0; q.NM = 0;
-                        r.nd[k] = q;
-                    }
-                }
-            }
-        }
-        wv::sync();
+        aux_bind(r, nm); r.n_seed = nm + 10 * c;
+        nodes_fill(r);
         out_put(cx, o, 0); out_put(cx, o, 0); out_put(cx, o, 0);
         HP_STAMP(0);
         // round 1: frag_line_BCC + frag_check + get_reg   (lamsa_aln.c:857-865)
@@ -219,6 +235,10 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     a.out.read_status[rd] = st;
     HP_STAMP(5);
     if (a.out.read_tbases) a.out.read_tbases[rd] = (int32_t)(r.t_bases > 0x7fffffffLL ? 0x7fffffffLL : r.t_bases);
+    if (a.out.read_work) {
+        a.out.read_work[2 * rd] = (int32_t)(cx.n_cells > 0x7fffffffLL ? 0x7fffffffLL : cx.n_cells);
+        a.out.read_work[2 * rd + 1] = (int32_t)(r.n_pairs > 0x7fffffffLL ? 0x7fffffffLL : r.n_pairs);
+    }
 }
 
 }  // namespace hp

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
-#include "hp_align.h"
+#include "hp_phase.h"
 #include "hp_handle.h"
 #include "hp_hostprep.h"
 
@@ -33,8 +33,76 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
     }
 }
 
+// The main pass as five launches (hp_phase.h).  Every kernel is a persistent grid of single-wave workgroups pulling
+// its units from a queue head; every wave reaches the exit test (the heads only grow, the unit counts are final when
+// the launch starts: they were written by the previous launch of the same stream).
+#ifndef HP_CHAIN_WAVES_PER_SIMD
+#define HP_CHAIN_WAVES_PER_SIMD 4
+#endif
+#ifndef HP_FILL_WAVES_PER_SIMD
+#define HP_FILL_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
+{
+    const PhaseArgs &a = *ap;        // in device memory: scalar loads, no private copy of the argument block
+    __shared__ int32_t lds[HP_LDS_WORDS];            // the hit sort's blocks (hp_sort.h)
+    for (;;) {
+        int u = 0;
+        if (wv::leader()) u = atomicAdd(&a.ctl->q_head[0], 1);
+        u = wv::uni(u);
+        if (u >= a.n_reads) break;
+        phase_chain1(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds);
+    }
+    drain_stamp(a, 0);
+}
+__global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain2(const PhaseArgs *ap)
+{
+    const PhaseArgs &a = *ap;
+    __shared__ int32_t lds[HP_LDS_WORDS];
+    for (;;) {
+        int u = 0;
+        if (wv::leader()) u = atomicAdd(&a.ctl->q_head[2], 1);
+        u = wv::uni(u);
+        if (u >= a.n_reads) break;
+        phase_chain2(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds);
+    }
+    drain_stamp(a, 2);
+}
+__global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const PhaseArgs *ap, int round)
+{
+    const PhaseArgs &a = *ap;
+    __shared__ int32_t lds[HP_LDS_WORDS];            // this wave's DP rows, query window and direction matrix (hp_ksw.h)
+    int n = 0;
+    for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
+    n = wv::uni(n);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[1 + 2 * round], 1);
+        g = wv::uni(g);
+        if (g >= n) break;
+        int b = 0;
+        while (b < PH_NBUCKET - 1 && g >= a.ctl->bucket_n[round][b]) { g -= a.ctl->bucket_n[round][b]; ++b; }     // costliest class first
+        const int u = wv::uni(a.bucket_q[((size_t)round * PH_NBUCKET + b) * a.unit_cap + g]);
+        phase_fill(a, round, u, blockIdx.x, (HP_L int32_t *)lds);
+    }
+    drain_stamp(a, 1 + 2 * round);
+}
+__global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
+{
+    const PhaseArgs &a = *ap;
+    if (blockIdx.x == 0) publish_diag(a);
+    for (;;) {
+        int u = 0;
+        if (wv::leader()) u = atomicAdd(&a.ctl->q_head[4], 1);
+        u = wv::uni(u);
+        if (u >= a.n_reads) break;
+        phase_publish(a, u);
+    }
+}
+
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
+static const bool g_mono = getenv("LAMSA_HP_ONE_KERNEL") != nullptr;  // diagnostics: the main pass through k_align_batch (the retry pass's kernel) instead of the phased launches
 
 struct HostBuf {                  // page-locked host memory, mapped into the device's address space
     void *p = nullptr, *dev = nullptr; size_t cap = 0;
@@ -57,13 +125,17 @@ struct HostBuf {                  // page-locked host memory, mapped into the de
 // grid is running (a 0.6 GB copy took 10 ms beside it, five 0.5 MB ones 380 ms).
 struct OutDev {
     DevBuf buf; HostBuf host; int64_t stream_cap = 0; int n_cap = 0;
-    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n); }
+    static size_t hdr(int n) { return 2 * al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256; }      // + 16 words of launch accounting
     int ensure(int n, int64_t cap) { stream_cap = cap; n_cap = n; return buf.ensure(4 * (size_t)cap + 256) || host.ensure(hdr(n) + 256); }
     // device-visible addresses (kernel arguments)
     int64_t *off() const { return (int64_t *)host.dev; }
     int32_t *len(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n)); }
     int32_t *st(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n) + al256(4 * (size_t)n)); }
     int32_t *tb(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n) + 2 * al256(4 * (size_t)n)); }
+    unsigned long long *diag(int n) const { return (unsigned long long *)((char *)host.dev + al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n)); }
+    const unsigned long long *h_diag(int n) const { return (const unsigned long long *)((const char *)host.p + al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n)); }
+    int32_t *work(int n) const { return (int32_t *)((char *)host.dev + al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256); }
+    const int32_t *h_work(int n) const { return (const int32_t *)((const char *)host.p + al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256); }
     // the same arrays as the host sees them (valid once the launch has completed)
     const int64_t *h_off() const { return (const int64_t *)host.p; }
     const int32_t *h_len(int n) const { return (const int32_t *)((const char *)host.p + al256(8 * (size_t)n)); }
@@ -74,11 +146,13 @@ struct OutDev {
 };
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
-    DevBuf bin, misc, slab; OutDev out1;
+    DevBuf bin, misc, slab, pers, prof; OutDev out1;
+    hipEvent_t ep[4] = {nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
-    int32_t n_reads = 0; int64_t n_bases = 0, n_cig = 0;
+    bool phased = false;          // the launch in flight on this slot's resources is the phased main pass
+    int32_t n_reads = 0; int64_t n_bases = 0, n_cig = 0, n_hits = 0;
     BatchIn in; const int32_t *d_order = nullptr;
     std::vector<int32_t> order, h_len, h_H;
     int32_t max_L = 0, max_H = 0;
@@ -94,7 +168,7 @@ struct AlignState {
     OutDev out2;
     // host copies of the results
     HostBuf stream;               // page-locked: the result stream
-    std::vector<int32_t> r_len, r_st, r_tb; std::vector<int64_t> r_off;
+    std::vector<int32_t> r_len, r_st, r_tb, r_work; std::vector<int64_t> r_off;
 };
 
 static std::map<lamsa_hp_handle *, AlignState *> g_states;     // per-handle state of the align entry points
@@ -118,7 +192,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3]}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
 }
@@ -152,13 +226,19 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
     if (B->n_cig < 0 || B->n_cig > 0x7fffffffll) { h->err = "more than 2^31-1 seed CIGAR words in one batch (h_cig_off is 32-bit): split the batch"; return LAMSA_HP_EINVAL; }
     {
-        std::atomic<int> bad(0);                         // 1..6: which check failed (the first one reported wins)
+        std::atomic<int> bad(0);                         // 1..9: which check failed (the first one reported wins)
+        const int64_t sl = h->para.seed_len, ss = h->para.seed_step > 0 ? h->para.seed_step : 1;
         std::atomic<long long> max_pos(0);
         hp_parallel_blocks(n, [&](int r0, int r1) {
             long long mp = 0;
             for (int r = r0; r < r1 && !bad.load(std::memory_order_relaxed); ++r) {
                 const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
                 if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { bad = 1; return; }
+                {   // the seed geometry the kernels derive read windows from (lamsa_aln.c:251-253,281) must be the read's own
+                    const int64_t sa = L < sl ? 0 : 1 + (L - sl) / ss;
+                    if (B->seed_all[r] != sa || B->last_len[r] != L - sl - (sa - 1) * ss) { bad = 7; return; }
+                    if (sa > 32767) { bad = 8; return; }                   // seed ids are kept in 16 bits on the device (NodeS::sid)
+                }
                 int64_t H = 0;
                 for (int64_t s = B->seed_off[r]; s < B->seed_off[r + 1]; ++s) {
                     const int64_t m = B->hit_off[s + 1] - B->hit_off[s];
@@ -170,6 +250,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                 for (int64_t i = B->read_off[r]; i < B->read_off[r + 1]; ++i) if (B->read_seq[i] > 4) { bad = 5; return; }
                 for (int64_t k = B->hit_off[B->seed_off[r]]; k < B->hit_off[B->seed_off[r + 1]]; ++k) {
                     mp = B->h_pos[k] > mp ? B->h_pos[k] : mp;
+                    if (B->h_len_dif[k] < -127 || B->h_len_dif[k] > 127) { bad = 9; return; }     // kept in 8 bits on the device (NodeS::len_dif8)
                     if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) || B->h_pos[k] < 0 || B->h_pos[k] >= (1ll << 40) ||
                         B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig) { bad = 6; return; }
                 }
@@ -178,8 +259,12 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
             long long seen = max_pos.load();
             while (mp > seen && !max_pos.compare_exchange_weak(seen, mp)) { }
         });
-        static const char *why[] = {"", "read too long / too many seeds", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
-                                    "too many hits in one read", "read base code > 4", "bad hit record"};
+        static const char *why[] = {"", "read longer than 2^24 bases or more than 16383 seeds with hits", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
+                                    "too many hits in one read", "read base code > 4",
+                                    "bad hit record (contig id, strand, position or seed CIGAR range)",
+                                    "seed_all / last_len do not match the read length and the handle's seed length and step",
+                                    "read has more than 32767 seeds (longer than 32767 * seed_step bases): not supported",
+                                    "a hit's len_dif is outside [-127, 127]"};
         if (bad) { h->err = why[bad.load()]; return LAMSA_HP_EINVAL; }
         for (int r = 0; r < n; ++r) { S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
         auto bits = [](unsigned long long x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
@@ -226,50 +311,19 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     in.h_len_dif = (const int16_t *)(d + o_ld); in.h_strand = (const int8_t *)(d + o_st); in.h_cig_n = (const uint8_t *)(d + o_cn);
     in.cig = (const int32_t *)(d + o_cig);
     S->d_order = (const int32_t *)(d + o_ord);
-    S->n_reads = n; S->n_bases = n_bases; S->n_cig = B->n_cig;
+    S->n_reads = n; S->n_bases = n_bases; S->n_cig = B->n_cig; S->n_hits = n_hits;
     S->valid = true;
     return LAMSA_HP_OK;
 }
 
-// one launch over `n_units` reads of the batch in slot `T` (order list on the device) with the launch resources
-// (scratch slab, queue head, stream, events) of slot `Ln`; results into `O`.  The kernel
-// is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
-static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
-                        hipEvent_t e0, hipEvent_t e1, bool wait)
-{
-    size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
-    if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    int n_waves = h->n_cu * per_cu;
-    if (n_waves > n_units) n_waves = n_units;
-    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
-    const int n = T.n_reads;
-    AlignArgs a;
-    a.P = h->para;
-    a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
-    a.in = T.in;
-    a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.stream = O.stream(n);
-    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64);
-    a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)Ln.misc.p;
-    a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
-    // Two main passes may be queued at a time, one per slot and stream.  The earlier one holds every wave slot until its
-    // read queue runs empty; the later one's workgroups are dispatched as those slots fall free, i.e. it takes over the
-    // SIMDs exactly as the earlier one's tail leaves them.  (Holding the later launch back explicitly, with
-    // hipStreamWaitValue32 on a flag the earlier kernel sets, measured the same and could hang under tools that
-    // serialise dispatches, so it is not done.)
-    hipStream_t s = Ln.cs;
-    HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
-    hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
-    HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
-    HIPCHK(h, hipEventRecord(e1, s), LAMSA_HP_EKERNEL);
-    if (wait) HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
 #ifdef HP_PROF
-    if (a.prof) {
+// diagnostic builds (-DHP_PROF): per-read cycle counters kept by the kernels, summed and printed after a launch
+static void prof_report(Slot &T, const long long *d_prof, int n)
+{
+    if (!d_prof) return;
+    {
         std::vector<long long> pr((size_t)n * 64);
-        hipMemcpy(pr.data(), a.prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(pr.data(), d_prof, sizeof(long long) * pr.size(), hipMemcpyDeviceToHost);
         if (const char *dump = getenv("LAMSA_HP_PROF_DUMP")) {          // per read: H, L, then the 64 counters
             if (FILE *fp = fopen(dump, "wb")) {
                 for (int r = 0; r < n; ++r) { long long hl[2] = {T.h_H[r], T.h_len[r]}; fwrite(hl, 8, 2, fp); fwrite(&pr[(size_t)r * 64], 8, 64, fp); }
@@ -292,6 +346,109 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, Ou
           for (int k = 0; k < 2; ++k) fprintf(stderr, "[HP_PROF] ksw_extend qlen %-8s %8lld Mcyc %10lld calls\n", bn[k], sum[48 + 2 * k] / 1000000, sum[49 + 2 * k]); }
         for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, T.h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }
     }
+}
+#endif
+
+// The main pass of the batch in slot `T` as the five launches of hp_phase.h, with the launch resources of slot `Ln`.
+static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, hipEvent_t e0, hipEvent_t e1)
+{
+    const int n = T.n_reads;
+    const int64_t n_hits = T.n_hits;
+    size_t slab_per_wave = slab_bytes_for(h->para, T.max_L, T.max_H, 1);
+    if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
+    int pc = 0, pf = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
+    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf;
+    int n_waves = std::max(w_chain, w_fill);
+    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves);
+    // state between the launches (hp_phase.h): per-hit arrays indexed by global hit index + read index, the fragment and
+    // line arenas, the fill units and their cost-class queues
+    const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
+    const int unit_cap = 8 * n + 1024;
+    const int64_t fl_cap = 2 * (int64_t)n_hits + 512 * (int64_t)n + 4096, line_cap = O.stream_cap + 64 * (int64_t)unit_cap;
+    size_t off = 0;
+    auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
+    const size_t o_args = place(sizeof(PhaseArgs)), o_ctl = place(sizeof(PhaseCtl)), o_meta = place(sizeof(RdMeta) * ((size_t)n + 1)), o_nd = place(sizeof(NodeS) * n_ent), o_ns = place(4 * n_ent),
+                 o_sx = place(8 * n_ent), o_un = place(sizeof(UnitRec) * 2 * (size_t)unit_cap), o_bq = place(4 * 2 * (size_t)PH_NBUCKET * unit_cap),
+                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap);
+    if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    char *d = (char *)Ln.pers.p;
+    PhaseArgs a;
+    a.P = h->para;
+    a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
+    a.in = T.in;
+    a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.read_work = O.work(n); a.out.stream = O.stream(n);
+    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64); a.out.diag = O.diag(n);
+    a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
+    a.order = T.d_order; a.n_reads = n; a.prof = nullptr;
+#ifdef HP_PROF
+    if (Ln.prof.ensure(sizeof(long long) * 64 * ((size_t)n + 1))) { h->err = "hipMalloc(prof)"; return LAMSA_HP_ENOMEM; }
+    a.prof = (long long *)Ln.prof.p;
+    HIPCHK(h, hipMemsetAsync(Ln.prof.p, 0, sizeof(long long) * 64 * ((size_t)n + 1), Ln.cs), LAMSA_HP_EKERNEL);
+#endif
+    a.g_nd = (NodeS *)(d + o_nd); a.g_nseed = (int32_t *)(d + o_ns); a.g_sidx = (int32_t *)(d + o_sx); a.meta = (RdMeta *)(d + o_meta);
+    a.units = (UnitRec *)(d + o_un); a.unit_cap = unit_cap; a.bucket_q = (int32_t *)(d + o_bq);
+    a.fl_base = (int32_t *)(d + o_fl); a.fl_cap = fl_cap; a.line_base = (int32_t *)(d + o_ln); a.line_cap = line_cap; a.ctl = (PhaseCtl *)(d + o_ctl);
+    hipStream_t s = Ln.cs;
+    HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipMemsetAsync(d + o_ctl, 0, (o_meta - o_ctl) + sizeof(RdMeta) * ((size_t)n + 1), s), LAMSA_HP_EKERNEL);      // counters + per-read state
+    HIPCHK(h, hipMemcpyAsync(d + o_args, &a, sizeof a, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);         // pageable source: staged before the call returns
+    const PhaseArgs *da = (const PhaseArgs *)(d + o_args);
+    HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
+    HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
+    HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
+    HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 1);
+    HIPCHK(h, hipEventRecord(Ln.ep[3], s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_publish, dim3(std::min(h->n_cu * 8, n)), dim3(64), 0, s, da);
+    HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventRecord(e1, s), LAMSA_HP_EKERNEL);
+    Ln.phased = true;
+    return LAMSA_HP_OK;
+}
+
+// one launch over `n_units` reads of the batch in slot `T` (order list on the device) with the launch resources
+// (scratch slab, queue head, stream, events) of slot `Ln`; results into `O`.  The kernel
+// is queued on the compute stream between the events e0/e1; `wait` blocks until it has finished.
+static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, const int32_t *d_order, int n_units, int scale, int max_L, int max_H,
+                        hipEvent_t e0, hipEvent_t e1, bool wait)
+{
+    size_t slab_per_wave = slab_bytes_for(h->para, max_L, max_H, scale);
+    if (scale == 1 && h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    int n_waves = h->n_cu * per_cu;
+    if (n_waves > n_units) n_waves = n_units;
+    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+    const int n = T.n_reads;
+    AlignArgs a;
+    a.P = h->para;
+    a.ref.pac = h->d_pac; a.ref.l_pac = h->l_pac; a.ref.n_seqs = h->n_seqs; a.ref.seq_off = h->d_seq_off; a.ref.seq_len = h->d_seq_len;
+    a.in = T.in;
+    a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.read_work = O.work(n); a.out.stream = O.stream(n);
+    a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64); a.out.diag = nullptr;
+    a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)Ln.misc.p;
+    a.order = d_order; a.n_units = n_units; a.scale = scale; a.prof = nullptr; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
+    // Two main passes may be queued at a time, one per slot and stream.  The earlier one holds every wave slot until its
+    // read queue runs empty; the later one's workgroups are dispatched as those slots fall free, i.e. it takes over the
+    // SIMDs exactly as the earlier one's tail leaves them.  (Holding the later launch back explicitly, with
+    // hipStreamWaitValue32 on a flag the earlier kernel sets, measured the same and could hang under tools that
+    // serialise dispatches, so it is not done.)
+    hipStream_t s = Ln.cs;
+    HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
+    hipLaunchKernelGGL(k_align_batch, dim3(n_waves), dim3(64), 0, s, a);
+    HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipEventRecord(e1, s), LAMSA_HP_EKERNEL);
+    if (wait) HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
+#ifdef HP_PROF
+    prof_report(T, a.prof, n);
 #endif
     return LAMSA_HP_OK;
 }
@@ -301,6 +458,7 @@ static int slot_events(lamsa_hp_handle *h, Slot &Ln)
     Ln.cs = &Ln == &state_of(h)->slot[1] ? h->stream_b : h->stream;
     if (!Ln.e0) HIPCHK(h, hipEventCreate(&Ln.e0), LAMSA_HP_EKERNEL);
     if (!Ln.e1) HIPCHK(h, hipEventCreate(&Ln.e1), LAMSA_HP_EKERNEL);
+    for (hipEvent_t &e : Ln.ep) if (!e) HIPCHK(h, hipEventCreate(&e), LAMSA_HP_EKERNEL);
     return LAMSA_HP_OK;
 }
 
@@ -312,6 +470,8 @@ static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln)
     const int n = T.n_reads;
     if (n == 0) return LAMSA_HP_OK;
     if (Ln.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
+    Ln.phased = false;
+    if (!g_mono) return launch_phased(h, S, T, Ln, Ln.out1, Ln.e0, Ln.e1);
     return launch_align(h, S, T, Ln, Ln.out1, T.d_order, n, 1, T.max_L, T.max_H, Ln.e0, Ln.e1, false);
 }
 
@@ -322,21 +482,31 @@ static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln)
 static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lamsa_hp_result *R)
 {
     const int n = T.n_reads;
-    h->kernel_ms[0] = h->kernel_ms[1] = 0;
-    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0);   // never empty: pointers stay valid
+    for (float &v : h->kernel_ms) v = 0;
+    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0); S->r_work.assign(2 * (size_t)n + 2, 0);   // never empty: pointers stay valid
     if (S->stream.ensure(64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
     if (n == 0) {
-        if (R) { R->stream = (const int32_t *)S->stream.p; R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); }
+        if (R) { R->stream = (const int32_t *)S->stream.p; R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); R->read_work = S->r_work.data(); }
         return LAMSA_HP_OK;
     }
     const double t_0 = now_s();
     HIPCHK(h, hipEventSynchronize(Ln.e1), LAMSA_HP_EKERNEL);
     const double t_1 = now_s();
     hipEventElapsedTime(&h->kernel_ms[0], Ln.e0, Ln.e1);
+    if (Ln.phased) {                                     // the five launches of the main pass: chain1, fill, chain2, fill, publish
+        hipEvent_t ev[6] = {Ln.e0, Ln.ep[0], Ln.ep[1], Ln.ep[2], Ln.ep[3], Ln.e1};
+        for (int k = 0; k < 5; ++k) hipEventElapsedTime(&h->kernel_ms[2 + k], ev[k], ev[k + 1]);
+        const unsigned long long *dg = Ln.out1.h_diag(n);          // drain of the four long launches: first wave out -> last wave out (100 MHz ticks)
+        for (int k = 0; k < 4; ++k) h->kernel_ms[7 + k] = dg[2 * k + 1] >= dg[2 * k] && dg[2 * k + 1] ? (float)((double)(dg[2 * k + 1] - dg[2 * k]) * 1e-5) : 0.f;
+        h->kernel_ms[11] = (float)dg[8]; h->kernel_ms[12] = (float)dg[9];                // fill units of the two rounds
+#ifdef HP_PROF
+        prof_report(T, (const long long *)Ln.prof.p, n);
+#endif
+    }
     // the per-read arrays are in mapped host memory already (OutDev); the slot may be reused while the caller still
     // reads the results, so they are copied out
     memcpy(S->r_off.data(), Ln.out1.h_off(), 8 * (size_t)n); memcpy(S->r_len.data(), Ln.out1.h_len(n), 4 * (size_t)n);
-    memcpy(S->r_st.data(), Ln.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), Ln.out1.h_tb(n), 4 * (size_t)n);
+    memcpy(S->r_st.data(), Ln.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), Ln.out1.h_tb(n), 4 * (size_t)n); memcpy(S->r_work.data(), Ln.out1.h_work(n), 8 * (size_t)n);
     unsigned long long used1 = 0;                        // the arena is handed out front to back: its fill is the largest end
     for (int r = 0; r < n; ++r) if (S->r_off[r] >= 0 && (unsigned long long)(S->r_off[r] + S->r_len[r]) > used1) used1 = (unsigned long long)(S->r_off[r] + S->r_len[r]);
     if ((int64_t)used1 > Ln.out1.stream_cap) used1 = (unsigned long long)Ln.out1.stream_cap;
@@ -354,10 +524,10 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
         int rc = launch_align(h, S, T, Ln, S->out2, (const int32_t *)S->retry_list.p, (int)again.size(), 8, mL, mH, h->ev0, h->ev1, true);
         if (rc) return rc;
         hipEventElapsedTime(&h->kernel_ms[1], h->ev0, h->ev1);
-        const int64_t *off2 = S->out2.h_off(); const int32_t *len2 = S->out2.h_len(n), *st2 = S->out2.h_st(n), *tb2 = S->out2.h_tb(n);
+        const int64_t *off2 = S->out2.h_off(); const int32_t *len2 = S->out2.h_len(n), *st2 = S->out2.h_st(n), *tb2 = S->out2.h_tb(n), *wk2 = S->out2.h_work(n);
         for (int r : again) if (off2[r] >= 0 && (unsigned long long)(off2[r] + len2[r]) > used2) used2 = (unsigned long long)(off2[r] + len2[r]);
         if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
-        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
+        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_work[2 * r] = wk2[2 * r]; S->r_work[2 * r + 1] = wk2[2 * r + 1]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
     }
     for (int r = 0; r < n; ++r) if (S->r_off[r] < 0) { S->r_off[r] = 0; S->r_len[r] = 0; S->r_st[r] |= LAMSA_HP_ST_OVERFLOW; }
     if (!R) return LAMSA_HP_OK;
@@ -367,7 +537,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
     if (used2) DL(hs + used1, S->out2.stream(n), 4 * (size_t)used2);
     DLSYNC();
     if (g_trace) fprintf(stderr, "[lamsa_hp] collect: waited %.1f ms for the kernel (%.1f ms), results %.1f ms (%.2f GB)\n", 1e3 * (t_1 - t_0), h->kernel_ms[0], 1e3 * (now_s() - t_1), 4e-9 * (double)(used1 + used2));
-    R->stream = hs; R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data();
+    R->stream = hs; R->stream_words = (int64_t)(used1 + used2); R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); R->read_work = S->r_work.data();
     return LAMSA_HP_OK;
 }
 #undef DL

@@ -76,7 +76,7 @@ extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
 }
 
 extern "C" const char *lamsa_hp_last_error(const lamsa_hp_handle *h) { return h ? h->err.c_str() : "null handle"; }
-extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 4) ? h->kernel_ms[which] : -1.f; }
+extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 16) ? h->kernel_ms[which] : -1.f; }
 
 
 extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, lamsa_hp_dp_out *O)

@@ -47,6 +47,8 @@ struct BatchOut {
     int32_t *read_out_len;       // [n_reads]
     int32_t *read_status;        // [n_reads]
     int32_t *read_tbases;        // [n_reads] reference bases fetched (2-bit windows), or nullptr
+    int32_t *read_work;          // [2 * n_reads] per read: DP cells updated, chaining edge classifications executed; or nullptr
+    unsigned long long *diag;    // 16 words of launch accounting (hp_phase.h), or nullptr
 };
 
 struct AlignArgs {

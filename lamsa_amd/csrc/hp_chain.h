@@ -23,6 +23,7 @@
 // Nodes are struct-of-arrays in the wave's HBM slab; sons are intrusive linked lists.
 #pragma once
 #include "hp_batch.h"
+#include "hp_sort.h"
 
 namespace hp {
 
@@ -61,6 +62,7 @@ struct ReadCtx {
     uint8_t *rc_read; bool rc_ready;   // reverse complement, filled on first use (frag_check.c:922-925)
     const uint8_t *cur_read;    // strand-appropriate read of the line being filled
     long long t_bases;          // reference bases fetched for this read (sum of DP target / NM window lengths): roofline accounting
+    long long n_pairs;          // edge classifications (get_fseed_dis evaluations) executed for this read: accounting
     bool flip;                  // seed ids flipped (k -> seed_all+1-k) while a '-' line is filled (frag_check.c:926,953)
     const int32_t *seed_id;     // [seed_out]
     const int64_t *hit_off;     // [seed_out+1], global; local hit index = global - hb
@@ -185,7 +187,7 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
     const EdgeK K = edge_consts(r.cx.P);
     NodeS F; F.pos = 0; F.chr = 0; F.slot_j = 0; F.sid = 0; F.strand = 0; F.len_dif8 = 0; F.pad_ = 0; F.dp_flag = 0; F.son_flag = 0; F.match_flag = 0; F.score = 0; F.NM = 0;
     int from_nm = 0;
-    if (from >= 0) { F = node_load(ns + from); from_nm = r.h_nm[from]; }
+    if (from >= 0) { F = node_load(ns + from); from_nm = r.h_nm[from]; r.n_pairs += k1 > k0 ? k1 - k0 : 0; }
     for (int b = k0; b < k1; b += 64) {
         WAVE_FOR(l) {
             const int k = b + l;
@@ -275,8 +277,9 @@ HP_INL void scan_eval(const EdgeK &K, const ScanT &S, const NodeS &Q, int p, int
     oka |= ok;
 }
 
-HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force, bool sons)
+HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp_flag, bool force, bool sons, const uint8_t *only = nullptr)
 {
+    const HP_G uint8_t *g_only = (const HP_G uint8_t *)only;     // when given: only hits flagged here are targets (their clusters did not fit LDS, hp_cluster.h)
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from;
@@ -308,7 +311,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             int due = 0;
             if (!force) {
                 const NodeS Tk = node_unpack(a, b);
-                if (k < k1 && Tk.dp_flag == dp_flag) {
+                if (k < k1 && Tk.dp_flag == dp_flag && g_only) due = g_only[kk];
+                else if (k < k1 && Tk.dp_flag == dp_flag) {
                     const int dm = Tk.sid - sid_lo;
                     const int mdm_ = K.match_dis * (K.high_err ? dm : 1);
                     long long Rk = K.sv_len > dm * K.seed_step ? K.sv_len : dm * K.seed_step;
@@ -400,6 +404,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
                     pm0[l] = g_srt[i0 >= 0 ? i0 : rT2]; pm1[l] = g_srt[i1 < H ? i1 : rT2];
                 }
             }
+            r.n_pairs += (rT < 64 ? rT : 64) + (H - 1 - rT < 64 ? H - 1 - rT : 64);
             wv::Lane<long long> key;
             wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, out0, out1, okl;
             WAVE_FOR(l) {                                // first trip: the records are already here
@@ -427,6 +432,8 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
 #ifdef HP_PROF
                 if (r.prof) r.prof[12] += 1;
 #endif
+                {   const int lo_left = rT - cc * 64, hi_left = H - 1 - rT - cc * 64;
+                    r.n_pairs += (live0 ? (lo_left < 0 ? 0 : (lo_left < 64 ? lo_left : 64)) : 0) + (live1 ? (hi_left < 0 ? 0 : (hi_left < 64 ? hi_left : 64)) : 0); }
                 WAVE_FOR(l) {
                     int idx[2], inb[2], pn[2];
 #pragma unroll
@@ -562,6 +569,7 @@ HP_NOINL void min_extend_all(ReadCtx &r, int min_n)
                 qdiag[l] = (long long)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]) - (long long)(st_ * sid_ * K.seed_step);
             }
             const int last = H - 1 - base < 63 ? H - 1 - base : 63;
+            r.n_pairs += (long long)__builtin_popcountll(mset) * (last + 1);
             const int s_last = wv::bcast(sd, last), st_last = wv::bcast(seg, last);
             unsigned long long next_carry = 0;
             for (unsigned long long mm = mset; mm; mm &= mm - 1) {
@@ -874,6 +882,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
     else { old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm; }
     // ---- gather + frag_dp_per_init (:766-784, :1086-1091)
+    if (head >= 0) r.n_pairs += n_ids;
     wv::Lane<int> A0[NS], A1[NS], A2[NS], A3[NS], B0[NS];
     wv::Lane<int> Dpf[NS], Son[NS], Mf[NS], Sc[NS], Nm[NS], Fr[NS], Nn[NS], Cf[NS], Id[NS], Tk[NS];
 #pragma unroll
@@ -907,6 +916,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
         int b_[4] = { B0[j][l], (Dpf[j][l] & 0xff) | (Son[j][l] << 8) | (Mf[j][l] << 16), Sc[j][l], Nm[j][l] }; Q = node_unpack(a_, b_); } while (0)
     // one target T against every loaded hit; returns the winner (cidx, or -1) and its edge class, score and NM
 #define HP_MS_SCAN(S, t_from_id, w_c, w_flag, w_score, w_nm, changed_) do { \
+        r.n_pairs += n_ids; \
         wv::Lane<long long> key; wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl; \
         WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; } \
         _Pragma("unroll") for (int j = 0; j < NS; ++j) { \
@@ -1411,13 +1421,32 @@ struct FLines {
     int32_t *fr_seed;                                             // node indices, fragment seeds in the reference's order
 };
 
-HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
+// Where the fragments of a round are kept.  The one-kernel path keeps them in the wave's slab; the phased path (hp_phase.h)
+// hands them from the chaining kernel to the fill kernel through an arena in HBM shared by the batch (`base`, bump
+// cursor advanced once per read and round).
+struct FlStore { int32_t *base; int64_t cap; unsigned long long *cursor; int64_t got_off; int32_t got_tot; };
+HP_INL int flines_words(int line_n, int tot) { return 4 * (line_n + 1) + (tot + 2) + tot + 4; }
+HP_INL void flines_bind(FLines &F, int32_t *m, int line_n, int tot)
+{
+    F.line_score = m; F.left_bound = m + (line_n + 1); F.right_bound = m + 2 * (line_n + 1); F.frag_off = m + 3 * (line_n + 1);
+    F.fr_seed_off = m + 4 * (line_n + 1); F.fr_seed = F.fr_seed_off + (tot + 2);
+}
+
+HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F, FlStore *fs = nullptr)
 {
     F.n = 0; F.nfrag = 0;
     if (line_n == 0) return true;
     int tot = 0;
     for (int _l = 0; _l < line_n; ++_l) tot += L.len[L.rank[_l]];
-    int32_t *m = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(4 * (line_n + 1) + (tot + 2) + tot + 4));
+    int32_t *m = nullptr;
+    if (fs) {
+        const int words = (flines_words(line_n, tot) + 3) & ~3;
+        unsigned long long off = 0;
+        if (wv::leader()) off = atomicAdd(fs->cursor, (unsigned long long)words);
+        off = (unsigned long long)wv::uni64((long long)off);
+        if ((int64_t)(off + (unsigned long long)words) > fs->cap) { r.cx.status |= ST_OVERFLOW; return false; }
+        m = fs->base + off; fs->got_off = (int64_t)off; fs->got_tot = tot;
+    } else m = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)flines_words(line_n, tot));
     if (!m) return false;
     F.line_score = m; F.left_bound = m + (line_n + 1); F.right_bound = m + 2 * (line_n + 1); F.frag_off = m + 3 * (line_n + 1);
     F.fr_seed_off = m + 4 * (line_n + 1); F.fr_seed = F.fr_seed_off + (tot + 2);
@@ -1493,6 +1522,10 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
     return true;
 }
 
+}  // namespace hp
+#include "hp_cluster.h"
+namespace hp {
+
 // ---------------------------------------------------------------- round 1: frag_line_BCC, :1305-1445
 #ifdef HP_PROF
 #define HP_CSTAMP(k) do { const long long now_ = wv::clock(); if (r.prof) r.prof[(k)] += now_ - tc_; tc_ = now_; } while (0)
@@ -1500,7 +1533,7 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F)
 #define HP_CSTAMP(k) do { } while (0)
 #endif
 
-HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
+HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
 {
 #ifdef HP_PROF
     long long tc_ = wv::clock();
@@ -1540,7 +1573,35 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     { const long long t2_ = wv::clock(); if (r.prof) { r.prof[58] += t2_ - tq_; r.prof[59] += all_min ? 0 : 1; } }
 #endif
     HP_CSTAMP(6);
-    if (seed_out > 1) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, true);                      // main pass, :1345-1350
+    if (seed_out > 1) {                                                                           // main pass, :1345-1350
+        // cluster by cluster out of LDS (hp_cluster.h); clusters that do not fit LDS through dp_update_range; then the son lists
+        const size_t cmark = arena_mark(r.cx.tmp);
+        Clusters C;
+        bool any_big = false;
+        if (!clusters_build(r, C, (HP_L uint64_t *)r.cx.lds, HP_LDS_WORDS / 2)) {
+            if (r.cx.status & ST_OVERFLOW) return false;
+            dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false);                          // keys too wide for the packed sort: everything through HBM
+        } else {
+            const HP_G int32_t *g_cs = (const HP_G int32_t *)C.cs, *g_srt = (const HP_G int32_t *)r.srt;
+            HP_G uint8_t *g_big = (HP_G uint8_t *)C.big;
+            for (int c0 = 0; c0 < C.n_cl; c0 += 63) {
+                wv::Lane<int> csl;
+                WAVE_FOR(l) { const int c = c0 + l; csl[l] = c <= C.n_cl ? g_cs[c] : H; }
+                const int cn = C.n_cl - c0 < 63 ? C.n_cl - c0 : 63;
+                for (int q = 0; q < cn; ++q) {
+                    const int lo = wv::bcast(csl, q), n = wv::bcast(csl, q + 1) - lo;
+                    if (n < 2) continue;                                                          // a lone hit has no predecessor
+                    if (n <= HP_CL_CAP_RT && dp_cluster_lds(r, C, lo, n)) continue;
+                    for (int i0 = 0; i0 < n; i0 += 64) { WAVE_FOR(l) { if (i0 + l < n) g_big[g_srt[lo + i0 + l]] = 1; } }
+                    any_big = true;
+                }
+            }
+            wv::sync();
+            if (any_big) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false, C.big);
+        }
+        arena_release(r.cx.tmp, cmark);
+        if (!build_sons(r, (HP_L uint64_t *)r.cx.lds, HP_LDS_WORDS / 2)) return false;
+    }
 
     HP_CSTAMP(7);
     NScore ns;
@@ -1608,7 +1669,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F)
     L.n = l_i;
     HP_CSTAMP(9);
     const int line_n = set_bound(r, L, 0, l_i, &T);                   // :1435
-    const bool okf = build_flines(r, L, line_n, F);
+    const bool okf = build_flines(r, L, line_n, F, fs);
     HP_CSTAMP(10);
     if (r.prof) { r.prof[14] = o_l; r.prof[15] = H; }
     return okf;
@@ -1672,7 +1733,7 @@ HP_NOINL int multi_line(ReadCtx &r, int left_b, int right_b, const Regs &G, int 
 }
 
 // frag_line_remain, :1252-1302
-HP_NOINL bool chain_remain(ReadCtx &r, const Regs &G, FLines &F)
+HP_NOINL bool chain_remain(ReadCtx &r, const Regs &G, FLines &F, FlStore *fs = nullptr)
 {
     const lamsa_hp_para *P = r.cx.P;
     const int seed_out = r.seed_out, H = r.H;
@@ -1705,7 +1766,7 @@ HP_NOINL bool chain_remain(ReadCtx &r, const Regs &G, FLines &F)
         l_n += l;
     }
     L.n = l_n;
-    return build_flines(r, L, l_n, F);
+    return build_flines(r, L, l_n, F, fs);
 }
 
 }  // namespace hp

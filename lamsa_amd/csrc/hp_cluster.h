@@ -1,0 +1,301 @@
+// hp_cluster.h -- the main chaining pass of round 1 (frag_dp_update over all MIN hits, src/lamsa_dp_con.c:1345-1350) cluster by
+// cluster, with the cluster's node state in LDS.  Included by hp_chain.h.
+//
+// get_fseed_dis (:596-634) connects two hits only if they lie on the same contig and strand within Rcl bases of each other,
+// Rcl bounded by the read's seed span (see `cluster_reach`).  In the (contig, strand, position) order of hp_sort.h the
+// hits of a read therefore fall into CLUSTERS -- maximal runs in which neighbours are at most Rcl apart -- and no edge of
+// any class other than F_CHR_DIF / F_UNCONNECT ever joins two clusters.  frag_dp_update skips exactly those two classes
+// (:722), so the DP over the read's hits is the union of independent DPs over its clusters, each visiting its own hits in
+// the reference's order (seed slot ascending, hit index ascending).  A read against a repeat-rich genome has one cluster
+// of a few hundred hits at its true locus and hundreds of tiny ones at repeat copies; the reference (and the HBM path of
+// dp_update_range) scans every earlier hit of the big cluster for every one of its targets, O(n^2) loads of 32-byte
+// records.  Here a cluster of up to HP_CL_CAP hits is packed into this wave's LDS (20 bytes per hit, positions relative to
+// the cluster's first hit, the dynamic DP fields included), the whole pass runs out of LDS -- every trip of the
+// predecessor scan is five conflict-free ds_read_b32 -- and the cluster is written back once.  Clusters of one hit have no
+// predecessor at all and are skipped; clusters that do not fit go through dp_update_range as before.
+//
+// The son lists (fnode_add_son, :683) that branch tracking walks are not maintained target by target any more: in this
+// pass every target starts from START (fnode_set has just reset it) and changes its predecessor at most once, targets
+// being visited in ascending hit order, so the list of a node is the set of hits whose final predecessor it is, in
+// ascending order -- built for the whole read afterwards by one sort on (predecessor, hit) (build_sons).
+#pragma once
+
+namespace hp {
+
+#define HP_CL_CAP (HP_LDS_WORDS / 5)      // hits of one cluster that fit this wave's LDS (five words per hit)
+#ifndef HP_CL_CAP_RT
+#define HP_CL_CAP_RT HP_CL_CAP            // the tests' CPU build makes this a variable, to send small clusters down the HBM path too
+#endif
+
+struct Clusters {
+    int n_cl;                    // number of clusters
+    int32_t *cs;                 // [n_cl + 1] first rank of each cluster (cs[n_cl] = H)
+    int32_t *cl_lo_r;            // [H] by rank: first rank of the rank's cluster
+    int32_t *csrt;               // [H] rank positions lo..hi-1 of a cluster hold its hits in ascending hit order
+    uint8_t *big;                // [H] by hit: 1 = the hit's cluster did not fit LDS (dp_update_range handles its targets)
+    long long reach;             // Rcl
+};
+
+// Upper bound, over every pair of seeds of the read, of the distance at which get_fseed_dis still connects two hits:
+// |dis| < max(SV_len_thd, did*step, mat_dis+1), |act - exp| <= |dis| + |len_dif|, exp within did*step of the predecessor
+// (the window of dp_update_range for the largest seed distance of the read); frag_min_extend's match-class test
+// (|dis| <= match_dis * did) lies inside it.
+HP_INL long long cluster_reach(const ReadCtx &r)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    const int did = r.seed_out > 0 ? r.seed_id[r.seed_out - 1] - r.seed_id[0] : 0;
+    const int mdm = P->match_dis * ((P->aln_mode & 2) ? did : 1);
+    long long R = P->SV_len_thd > did * P->seed_step ? P->SV_len_thd : (long long)did * P->seed_step;
+    if (mdm + 1 > R) R = mdm + 1;
+    R += 128 + (long long)did * P->seed_step;
+    const long long R2 = (long long)did * (P->seed_step + P->match_dis) + 256;
+    return R > R2 ? R : R2;
+}
+
+HP_NOINL bool clusters_build(ReadCtx &r, Clusters &C, HP_L uint64_t *lw, int lds_n)
+{
+    const int H = r.H;
+    C.n_cl = 0; C.reach = cluster_reach(r);
+    C.cs = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 2));
+    C.cl_lo_r = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
+    C.csrt = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
+    C.big = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
+    if (!C.cs || !C.cl_lo_r || !C.csrt || !C.big) return false;
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
+    HP_G int32_t *g_cs = (HP_G int32_t *)C.cs, *g_lo = (HP_G int32_t *)C.cl_lo_r;
+    HP_G uint8_t *g_big = (HP_G uint8_t *)C.big;
+    const long long R = C.reach;
+    int n_cl = 0, run_start = 0;
+    for (int i0 = 0; i0 < H; i0 += 64) {
+        wv::Lane<int> b;
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            int v = 0;
+            if (i < H) {
+                g_big[i] = 0;
+                if (i == 0) v = 1;
+                else {
+                    const NodeS A = node_load(ns + g_srt[i]), B = node_load(ns + g_srt[i - 1]);
+                    v = (A.chr != B.chr) | (A.strand != B.strand) | (A.pos - B.pos > R);
+                }
+            }
+            b[l] = v;
+        }
+        const unsigned long long m = wv::ballot(b);
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            if (i < H) {
+                const unsigned long long below = m & ((2ull << l) - 1);          // starts at or below this lane
+                g_lo[i] = below ? i0 + 63 - __builtin_clzll(below) : run_start;
+                if (b[l]) g_cs[n_cl + __builtin_popcountll(m & ((1ull << l) - 1))] = i;
+            }
+        }
+        n_cl += __builtin_popcountll(m);
+        if (m) run_start = i0 + 63 - __builtin_clzll(m);
+    }
+    wv::sync();
+    g_cs[n_cl] = H;
+    C.n_cl = n_cl;
+    wv::sync();
+    // the hits of every cluster in ascending hit order: one sort on (first rank of the cluster, hit index); the clusters keep
+    // their rank ranges
+    const size_t mark = arena_mark(r.cx.tmp);
+    uint64_t *work = (uint64_t *)arena_alloc(r.cx, sizeof(uint64_t) * (size_t)(H + 1));
+    if (!work) return false;
+    const bool ok = sort_packed([&](int k) { return (uint64_t)(unsigned)g_lo[g_rnk[k]]; }, bits_of((unsigned)(H > 0 ? H : 1)), H,
+                                (HP_G int32_t *)C.csrt, (HP_G int32_t *)nullptr, (HP_G uint64_t *)work, lw, lds_n);
+    arena_release(r.cx.tmp, mark);
+    return ok;
+}
+
+// ---------------------------------------------------------------- the cluster in LDS
+// five arrays of HP_CL_CAP words: W0 position relative to the cluster's first hit | W1 slot:14 j:14 dp_flag:4 |
+// W2 sid:15 len_dif:8 son_flag:5 match_flag:4 | W3 score:16 NM:16 | W4 (predecessor's index in the cluster + 1):16 node_n:16
+struct ClLds { HP_L int32_t *w0, *w1, *w2, *w3, *w4; };
+HP_INL ClLds cl_lds(HP_L int32_t *lds) { ClLds c; c.w0 = lds; c.w1 = lds + HP_CL_CAP; c.w2 = lds + 2 * HP_CL_CAP; c.w3 = lds + 3 * HP_CL_CAP; c.w4 = lds + 4 * HP_CL_CAP; return c; }
+
+HP_INL NodeS cl_unpack(int w0, int w1, int w2, int w3, int chr, int strand)
+{
+    NodeS q;
+    q.pos = (int64_t)(unsigned)w0; q.chr = chr; q.slot_j = (int)((unsigned)w1 >> 4);
+    q.sid = (int16_t)((unsigned)w2 >> 17); q.strand = (int8_t)strand; q.len_dif8 = (int8_t)((w2 >> 9) & 0xff);
+    q.dp_flag = (int8_t)((int)((unsigned)w1 << 28) >> 28); q.son_flag = (uint8_t)((w2 >> 4) & 31); q.match_flag = (uint8_t)(w2 & 15); q.pad_ = 0;
+    q.score = w3 >> 16; q.NM = w3 & 0xffff;
+    return q;
+}
+
+// One cluster [lo, lo + n) (ranks), n <= HP_CL_CAP: frag_dp_update (:701-764) for its MIN hits, out of LDS.
+// Returns false when the cluster cannot be packed (span or NM beyond the field widths): the caller marks it big.
+HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk, *g_csrt = (const HP_G int32_t *)C.csrt;
+    const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
+    const ClLds L = cl_lds(r.cx.lds);
+    const EdgeK K = edge_consts(r.cx.P);
+    const int dp_flag = MIN_FLAG;
+    // ---- load + pack
+    const NodeS first = node_load(ns + g_srt[lo]);
+    const int64_t pos0 = first.pos; const int chr = first.chr, strand = first.strand;
+    int nm_sum = 0; int bad = 0;
+    wv::sync();                                                    // whatever used this LDS before is done
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        wv::Lane<int> nml, badl;
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            int nmv = 0, bv = 0;
+            if (i < n) {
+                const int id = g_srt[lo + i];
+                const NodeS q = node_load(ns + id);
+                const int64_t rel = q.pos - pos0;
+                bv = rel < 0 || rel > 0x7fffffffll || q.score < -32768 || q.score > 32767 || q.NM < 0 || q.NM > 65535 || (q.slot_j & 16383) > 16383;
+                nmv = g_hnm[id];
+                L.w0[i] = (int)(unsigned)rel;
+                L.w1[i] = (int)(((unsigned)q.slot_j << 4) | ((unsigned)q.dp_flag & 15u));
+                L.w2[i] = (int)(((unsigned)(unsigned short)q.sid << 17) | (((unsigned)q.len_dif8 & 255u) << 9) | (((unsigned)q.son_flag & 31u) << 4) | ((unsigned)q.match_flag & 15u));
+                L.w3[i] = (int)(((unsigned)q.score << 16) | ((unsigned)q.NM & 0xffffu));
+                L.w4[i] = 1;                                       // from = START, node_n = 1 (fnode_set has just run for every hit)
+            }
+            nml[l] = nmv; badl[l] = bv;
+        }
+        nm_sum += wv::reduce_sum(nml);
+        if (wv::ballot(badl) != 0) bad = 1;
+    }
+    if (bad || nm_sum > 65535) return false;                       // a chain's NM is at most the sum over the cluster: 16 bits suffice
+    wv::sync();
+    // ---- targets in ascending hit order (C.csrt), 64 at a time: their places in the cluster
+    for (int o0 = 0; o0 < n; o0 += 64) {
+        wv::Lane<int> tloc;
+        WAVE_FOR(l) { const int o = o0 + l; tloc[l] = o < n ? g_rnk[g_csrt[lo + o]] - lo : 0; }
+        const int cnt = n - o0 < 64 ? n - o0 : 64;
+        for (int q = 0; q < cnt; ++q) {
+            const int ct = wv::bcast(tloc, q);
+            const int t1 = wv::uni(L.w1[ct]);
+            if ((int)((unsigned)t1 << 28) >> 28 != dp_flag) continue;
+            ScanT S;
+            S.T = cl_unpack(wv::uni(L.w0[ct]), t1, wv::uni(L.w2[ct]), wv::uni(L.w3[ct]), chr, strand);
+            S.x = S.T.slot_j >> 14; S.t_NM = S.T.NM; S.tkey = chr * 2 + (strand > 0 ? 1 : 0); S.Rw = 0x7fffffffffffll;
+            if (S.x == 0) continue;                                // a hit of the first seed slot has no predecessor
+            wv::Lane<long long> key;
+            wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl;
+            WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; }
+            r.n_pairs += n;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                WAVE_FOR(l) {
+                    const int i = i0 + l, ii = i < n ? i : 0;
+                    const NodeS Q = cl_unpack(L.w0[ii], L.w1[ii], L.w2[ii], L.w3[ii], chr, strand);
+                    int ow, oka = 0;
+                    scan_eval(K, S, Q, i, i < n, 0, dp_flag, key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow, oka);
+                    okl[l] |= oka;
+                }
+            }
+            if (wv::ballot(okl) == 0) continue;                    // no connectable predecessor: the node keeps its state
+            int max_from = -1, max_score = S.T.score, max_NM = S.t_NM, max_flag = 0;
+            bool changed = false;
+            const int npos = wv::reduce_max(negp);
+            if (npos != -0x7fffffff) {                             // '-' strand: the first match precursor in scan order, :726-733
+                wv::Lane<int> w;
+                WAVE_FOR(l) w[l] = negp[l] == npos;
+                const int wl = __builtin_ctzll(wv::ballot(w));
+                max_from = wv::bcast(n_p, wl); max_flag = wv::bcast(n_f, wl); max_score = wv::bcast(n_c, wl); max_NM = wv::bcast(n_n, wl);
+                changed = true;
+            } else {
+                const long long best_key = wv::reduce_max64(key);
+                if (best_key >= 0) {
+                    const int nm = 524287 - (int)((best_key >> 28) & 524287);
+                    const int cand = (int)(best_key >> 47) - 32768;
+                    if (cand > max_score || (cand == max_score && nm < max_NM)) {
+                        wv::Lane<int> w;
+                        WAVE_FOR(l) w[l] = key[l] == best_key;
+                        const int wl = __builtin_ctzll(wv::ballot(w));
+                        max_from = wv::bcast(bp, wl); max_flag = wv::bcast(bf, wl); max_score = cand; max_NM = nm;
+                        changed = true;
+                    }
+                }
+            }
+            if (changed) {                                         // :753-761; the LDS copy is the node state until the write-back
+                const int f2 = wv::uni(L.w2[max_from]), f4 = wv::uni(L.w4[max_from]);
+                wv::sync();
+                L.w2[max_from] = (f2 & ~(31 << 4)) | ((max_flag & 31) << 4);
+                const int t2 = wv::uni(L.w2[ct]);
+                L.w2[ct] = (t2 & ~15) | (max_flag & 15);
+                L.w3[ct] = (int)(((unsigned)max_score << 16) | ((unsigned)max_NM & 0xffffu));
+                L.w4[ct] = ((max_from + 1) << 16) | (((f4 & 0xffff) + 1) & 0xffff);
+                wv::sync();
+            }
+        }
+    }
+    // ---- write back: the dynamic half of the record, predecessor and node count
+    wv::sync();
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            if (i < n) {
+                const int id = g_srt[lo + i];
+                const int w1 = L.w1[i], w2 = L.w2[i], w3 = L.w3[i], w4 = L.w4[i];
+                const int b0 = (int)(((unsigned)w2 >> 17) & 0xffffu) | ((strand & 0xff) << 16) | (((w2 >> 9) & 0xff) << 24);
+                const int dpf = (int)((unsigned)w1 << 28) >> 28;
+                hp_store16((HP_G char *)(gd + id) + 16, b0, (dpf & 0xff) | (((w2 >> 4) & 31) << 8) | ((w2 & 15) << 16), w3 >> 16, w3 & 0xffff);
+                const int fl = (int)((unsigned)w4 >> 16);
+                g_from[id] = fl ? g_srt[lo + fl - 1] : -1;
+                g_node_n[id] = w4 & 0xffff;
+            }
+        }
+    }
+    wv::sync();
+    return true;
+}
+
+// fnode_add_son (:683) for every hit whose predecessor the pass has set, all at once: hits ordered by (predecessor, hit
+// index); a run of equal predecessors is that node's son list in insertion order (see the header comment).
+HP_NOINL bool build_sons(ReadCtx &r, HP_L uint64_t *lw, int lds_n)
+{
+    const int H = r.H;
+    if (H == 0) return true;
+    const size_t mark = arena_mark(r.cx.tmp);
+    int32_t *ps = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
+    uint64_t *work = (uint64_t *)arena_alloc(r.cx, sizeof(uint64_t) * (size_t)(H + 1));
+    if (!ps || !work) { arena_release(r.cx.tmp, mark); return false; }
+    const HP_G int32_t *g_from = (const HP_G int32_t *)r.n_from;
+    HP_G int32_t *g_ps = (HP_G int32_t *)ps;
+    HP_G int32_t *g_in_de = (HP_G int32_t *)r.n_in_de, *g_son_n = (HP_G int32_t *)r.n_son_n;
+    HP_G int32_t *g_first = (HP_G int32_t *)r.n_first, *g_last = (HP_G int32_t *)r.n_last, *g_next = (HP_G int32_t *)r.n_next;
+    const bool ok = sort_packed([&](int k) { const int f = g_from[k]; return (uint64_t)(unsigned)(f >= 0 ? f : H); }, bits_of((unsigned)H) , H,
+                                g_ps, (HP_G int32_t *)nullptr, (HP_G uint64_t *)work, lw, lds_n);
+    if (!ok) { arena_release(r.cx.tmp, mark); return false; }
+    int run_start = 0;                                             // position where the run reaching into this chunk began
+    for (int i0 = 0; i0 < H; i0 += 64) {
+        wv::Lane<int> st, tl, fl, fnl;
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            int t = -1, f = -1, fp = -2, fn = -2;
+            if (i < H) {
+                t = g_ps[i]; f = g_from[t];
+                fp = i > 0 ? g_from[g_ps[i - 1]] : -2;
+                fn = i + 1 < H ? g_from[g_ps[i + 1]] : -2;
+            }
+            tl[l] = t; fl[l] = f; fnl[l] = fn;
+            st[l] = i < H && f >= 0 && fp != f;
+        }
+        const unsigned long long m = wv::ballot(st);
+        WAVE_FOR(l) {
+            const int i = i0 + l, t = tl[l], f = fl[l];
+            if (i < H && f >= 0) {
+                const unsigned long long below = m & ((2ull << l) - 1);
+                const int rs = below ? i0 + 63 - __builtin_clzll(below) : run_start;
+                if (st[l]) g_first[f] = t;
+                if (fnl[l] == f) g_next[t] = g_ps[i + 1];
+                else { g_next[t] = -1; g_last[f] = t; g_son_n[f] = i - rs + 1; g_in_de[f] = i - rs + 1; }
+            }
+        }
+        if (m) run_start = i0 + 63 - __builtin_clzll(m);
+    }
+    wv::sync();
+    arena_release(r.cx.tmp, mark);
+    return true;
+}
+
+}  // namespace hp

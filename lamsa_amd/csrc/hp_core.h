@@ -37,6 +37,7 @@ struct Ctx {
     HP_L int32_t *lds;        // HP_LDS_WORDS words of LDS owned by this wave
     Arena tmp;                // scratch slab of this wave
     int status;               // ST_* bits for the unit (read / job) being processed
+    long long n_cells;        // DP cells updated (accounting: GCUPS)
     long long *prof;          // per-read cycle counters of diagnostic builds (-DHP_PROF), else nullptr
 };
 #ifdef HP_PROF

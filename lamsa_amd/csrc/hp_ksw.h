@@ -131,6 +131,7 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         const int ti = gt[(long)i * ts];
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
         int carryH = gH[beg];          // H(i-1,beg-1), read before the in-place update below
         int Fin = HP_NEG_INF;         // F(i,beg)
@@ -238,6 +239,7 @@ HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
+        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
@@ -384,6 +386,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
         if (end > hw) {                                                    // columns entering the window
             for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_GH0(j); LE[j & HP_LDS_MASK] = HP_NEG_INF; } } }
             hw = end;
@@ -494,6 +497,7 @@ HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
             const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
             const int beg = i > w ? i - w : 0;
             const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+            cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
             if (out && zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
             const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
             wv::Lane<int> m, key, hcur;
@@ -585,6 +589,7 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
             if (beg < i - w) beg = i - w;                                  // :718-720
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
+            cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
             if (zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
             else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
             int h1_init;
@@ -733,6 +738,7 @@ HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
+        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
         if (end > hw) {                                                    // columns entering the window
             for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_EH0(j); LE[j & HP_LDS_MASK] = 0; } } }
             hw = end;

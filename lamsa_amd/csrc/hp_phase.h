@@ -1,0 +1,324 @@
+// hp_phase.h -- the per-read path of hp_align.h cut at frag_dp_path into separate launches:
+//
+//   chain1  (one read per wave)   sort index, frag_line_BCC                       lamsa_dp_con.c:1305-1445
+//   fill    (one LINE per wave)   frag_check of one line of round 1 + its get_reg  frag_check.c:856-961, lamsa_aln.c:571-605
+//   chain2  (one read per wave)   get_remain_reg, frag_line_remain                lamsa_aln.c:550-569, lamsa_dp_con.c:1252-1302
+//   fill    (one LINE per wave)   frag_check of one line of round 2
+//   publish (one read per wave)   the read's result stream (hp_batch.h) from its lines, in line order
+//
+// Why: (i) the work unit of the expensive half (banded DP, junctions) becomes a line instead of a read, and the lines of a
+// batch are handed out costliest first by what chaining has found (extension lengths, seeds), so a launch no longer ends
+// with a few heavy reads running alone; (ii) each kernel carries only its own code and registers; (iii) the chaining
+// kernels need no DP rows in LDS and the fill kernels no node arrays in their slab.
+// Between the launches a read's state lives in HBM: the 32-byte node records (their TRACKED flags are what round 2 needs),
+// the seed slot of every hit, the sort index, and per round one block of fragments (FLines) in an arena shared by the
+// batch.  Every line writes its serialised records (+ the covered read intervals of round 1) into a second arena; the
+// publish launch gathers them per read.  Lines of a read are independent (frag_check.c:886-955 reads only the line's own
+// fragments), and a line that fails flags the whole read exactly as the per-read loop does (fill_round in hp_align.h).
+// A read that overflows a buffer in any phase is re-run by the one-kernel path with larger buffers (hp_align_api.hip).
+#pragma once
+#include "hp_align.h"
+
+namespace hp {
+
+struct RdMeta {                  // 64 bytes per read, zeroed before chain1
+    int64_t fl_off[2];           // the FLines block of each round in the fragment arena (words)
+    int32_t fl_n[2], fl_tot[2], fl_nfrag[2];
+    int32_t unit_base[2];        // first fill unit of each round (units of a read and round are consecutive, in line order)
+    int32_t status;              // ST_* bits, OR-ed in by every phase
+    int32_t tbases;              // reference bases fetched by the read's DP jobs (roofline accounting)
+    int32_t cells, pairs;        // DP cells updated / chaining edge classifications executed (accounting)
+};
+
+struct UnitRec {                 // one line to fill
+    int32_t read, line;
+    int64_t out_off;             // its serialised result in the line arena (words): out_line words, then 10 words per region
+    int32_t out_len, n_reg;
+    int32_t pad[2];
+};
+
+enum { PH_NBUCKET = 8, PH_REG_WORDS = 10 };
+
+struct PhaseCtl {                // counters of one launch sequence, zeroed before chain1
+    int32_t q_head[8];           // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish
+    int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
+    int32_t bucket_n[2][PH_NBUCKET];
+    unsigned long long fl_cursor, line_cursor;
+    // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
+    // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
+    // draining, i.e. with idle wave slots
+    unsigned long long t_first_inv[4], t_last[4];
+};
+
+struct PhaseArgs {
+    lamsa_hp_para P;
+    RefView ref;
+    BatchIn in;
+    BatchOut out;
+    char *slab; size_t slab_per_wave;
+    int32_t sort_pb, sort_cb;
+    const int32_t *order;        // reads, costliest chaining first (or nullptr)
+    int32_t n_reads;
+    long long *prof;
+    // state of the batch between the launches; per-hit arrays are indexed by (global hit index + read index)
+    NodeS *g_nd; int32_t *g_nseed; int32_t *g_sidx;
+    RdMeta *meta;
+    UnitRec *units; int32_t unit_cap;            // [2][unit_cap]
+    int32_t *bucket_q;                           // [2][PH_NBUCKET][unit_cap] unit indices by cost class, costliest class first
+    int32_t *fl_base; int64_t fl_cap;            // fragment arena (words)
+    int32_t *line_base; int64_t line_cap;        // line arena (words)
+    PhaseCtl *ctl;
+};
+
+HP_INL void drain_stamp(const PhaseArgs &a, int k)
+{
+    if (wv::leader()) { const unsigned long long now = wv::wall(); atomicMax(&a.ctl->t_first_inv[k], ~now); atomicMax(&a.ctl->t_last[k], now); }
+}
+
+HP_INL void meta_flag(const PhaseArgs &a, int rd, const ReadCtx &r)
+{
+    if (wv::leader()) {
+        const long long tb = r.t_bases, nc = r.cx.n_cells, np = r.n_pairs;
+        if (r.cx.status) atomicOr(&a.meta[rd].status, r.cx.status);
+        if (tb > 0) atomicAdd(&a.meta[rd].tbases, (int)(tb > 0x3fffffffLL ? 0x3fffffffLL : tb));
+        if (nc > 0) atomicAdd(&a.meta[rd].cells, (int)(nc > 0x3fffffffLL ? 0x3fffffffLL : nc));
+        if (np > 0) atomicAdd(&a.meta[rd].pairs, (int)(np > 0x3fffffffLL ? 0x3fffffffLL : np));
+    }
+}
+
+// hand the lines of one round to the fill launch: one unit per line, queued by cost class
+HP_FN void units_push(const PhaseArgs &a, ReadCtx &r, int rd, int round, const FLines &F, const FlStore &fs)
+{
+    RdMeta &M = a.meta[rd];
+    int base = 0;
+    if (wv::leader()) base = atomicAdd(&a.ctl->n_units[round], F.n);
+    base = wv::uni(base);
+    if (base + F.n > a.unit_cap) { r.cx.status |= ST_OVERFLOW; return; }
+    M.fl_off[round] = fs.got_off; M.fl_n[round] = F.n; M.fl_tot[round] = fs.got_tot; M.fl_nfrag[round] = F.nfrag; M.unit_base[round] = base;
+    const lamsa_hp_para *P = r.cx.P;
+    const int tiles = (2 * P->band_w + 1 + 63) / 64;
+    for (int j = 0; j < F.n; ++j) {
+        // cost class of line j: the two end extensions run over the read bases outside the line (frag_check.c:576-707)
+        // with a DP row per base, the junctions cost roughly per seed
+        const int f0 = F.frag_off[j], f1 = F.frag_off[j + 1];
+        const int n_seed = F.fr_seed_off[f1] - F.fr_seed_off[f0];
+        const int sa = r.seed_id[r.n_seed[F.fr_seed[F.fr_seed_off[f0]]]], sb = r.seed_id[r.n_seed[F.fr_seed[F.fr_seed_off[f1] - 1]]];
+        const int s_lo = sa < sb ? sa : sb, s_hi = sa < sb ? sb : sa;
+        long long ext = (long long)(s_lo - 1 + r.seed_all - s_hi) * P->seed_step;
+        if (ext < 0) ext = 0;
+        const long long cost = ext * tiles * 8 + (long long)n_seed * 64;
+        int b = 0;
+        for (long long c = cost >> 10; c > 0 && b < PH_NBUCKET - 1; c >>= 1) ++b;
+        const int bucket = PH_NBUCKET - 1 - b;                        // bucket 0 = costliest
+        UnitRec &U = a.units[(size_t)round * a.unit_cap + base + j];
+        U.read = rd; U.line = j; U.out_off = 0; U.out_len = 0; U.n_reg = 0;
+        int at = 0;
+        if (wv::leader()) at = atomicAdd(&a.ctl->bucket_n[round][bucket], 1);
+        at = wv::uni(at);
+        a.bucket_q[((size_t)round * PH_NBUCKET + bucket) * a.unit_cap + at] = base + j;
+    }
+}
+
+HP_INL void pers_bind(ReadCtx &r, const PhaseArgs &a, int rd)
+{
+    const int64_t pb = r.hb + rd;
+    r.nd = a.g_nd + pb; r.n_seed = a.g_nseed + pb;
+    r.srt = a.g_sidx + 2 * pb; r.rnk = a.g_sidx + 2 * pb + (r.H + 1);
+}
+
+// ---------------------------------------------------------------- chain1: one read
+#ifdef HP_PROF
+#define PH_T0() const long long ph_t0_ = wv::clock()
+#define PH_TADD(k) do { if (r.prof) r.prof[k] += wv::clock() - ph_t0_; } while (0)
+#define PH_TMID(k, v) do { if (r.prof) { const long long now_ = wv::clock(); r.prof[k] += now_ - v; v = now_; } } while (0)
+#else
+#define PH_T0() do { } while (0)
+#define PH_TADD(k) do { } while (0)
+#define PH_TMID(k, v) do { } while (0)
+#endif
+
+HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds)
+{
+#ifdef HP_PROF
+    long long ph_t_ = wv::clock();
+#endif
+    ReadCtx r;
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    pers_bind(r, a, rd);
+    Ctx &cx = r.cx;
+    const int H = r.H, c = H + 1;
+    int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 10 * (size_t)c);
+    const size_t sort_mark = arena_mark(cx.tmp);
+    uint64_t *sort_work = (uint64_t *)arena_alloc(cx, sizeof(uint64_t) * (size_t)c);
+    if (nm && sort_work) {
+        int32_t *sidx = a.g_sidx + 2 * (r.hb + rd);
+        { HP_T0(t_sort_);
+        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
+        HP_TADD(cx, 46, t_sort_); }
+        arena_release(cx.tmp, sort_mark);
+        aux_bind(r, nm);
+        nodes_fill(r);
+        PH_TMID(0, ph_t_);
+        FLines F;
+        FlStore fs; fs.base = a.fl_base; fs.cap = a.fl_cap; fs.cursor = &a.ctl->fl_cursor; fs.got_off = 0; fs.got_tot = 0;
+        const bool ok1 = chain_first(r, F, &fs);
+        PH_TMID(1, ph_t_);
+        if (ok1 && F.n > 0) units_push(a, r, rd, 0, F, fs);
+        else if (!ok1 && !(cx.status & (ST_REFEXIT | ST_OVERFLOW))) cx.status |= ST_OVERFLOW;
+    }
+    meta_flag(a, rd, r);
+}
+
+// ---------------------------------------------------------------- fill: one line of one read
+HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP_L int32_t *lds)
+{
+    UnitRec &U = a.units[(size_t)round * a.unit_cap + u];
+    const int rd = U.read, line = U.line;
+    RdMeta &M = a.meta[rd];
+    if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;       // the read is lost already (another line or phase failed)
+    PH_T0();
+    ReadCtx r;
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    pers_bind(r, a, rd);
+    Ctx &cx = r.cx;
+    FLines F;
+    F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
+    flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
+    const int cur_cap = 2 * r.L + 512;
+    const int out_cap = 64 + 12 * r.L + PH_REG_WORDS * HP_REC_MAX;
+    OutBuf o; o.n = 0; o.cap = out_cap;
+    o.w = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)out_cap);
+    r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
+    LineRes *la = (LineRes *)arena_alloc(cx, sizeof(LineRes));
+    cig_t *cur_buf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)cur_cap);
+    cig_t *rec_buf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(cur_cap + 4 * HP_REC_MAX));
+    int n_reg = 0;
+    if (o.w && r.rc_read && la && cur_buf && rec_buf) {
+        const bool ok = fill_line(r, F, line, *la, cur_buf, cur_cap, rec_buf, cur_cap + 4 * HP_REC_MAX);
+        if (!ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW))) cx.status |= ST_OVERFLOW;
+        if (ok) {
+            out_line(cx, o, *la);
+            if (round == 0 && la->tol_score >= 0) {                                // get_reg, lamsa_aln.c:597-605
+                Regs G; G.n = 0; G.m = 0;
+                const size_t mark = arena_mark(cx.tmp);
+                G.beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * HP_REC_MAX); G.end = G.beg ? G.beg + HP_REC_MAX : nullptr;
+                G.rb = (RegB *)arena_alloc(cx, sizeof(RegB) * 2 * HP_REC_MAX); G.re = G.rb ? G.rb + HP_REC_MAX : nullptr;
+                if (G.beg && G.rb) {
+                    for (int k = 0; k <= la->cur_res_n; ++k) regs_push(r, G, HP_REC_MAX, la->rec[k]);
+                    for (int k = 0; k < G.n; ++k) {
+                        out_put(cx, o, G.beg[k]); out_put(cx, o, G.end[k]);
+                        out_put(cx, o, G.rb[k].is_rev); out_put(cx, o, G.rb[k].chr); out_put(cx, o, (int32_t)(G.rb[k].pos & 0xffffffffll)); out_put(cx, o, (int32_t)(G.rb[k].pos >> 32));
+                        out_put(cx, o, G.re[k].is_rev); out_put(cx, o, G.re[k].chr); out_put(cx, o, (int32_t)(G.re[k].pos & 0xffffffffll)); out_put(cx, o, (int32_t)(G.re[k].pos >> 32));
+                    }
+                    n_reg = G.n;
+                }
+                arena_release(cx.tmp, mark);
+            }
+        }
+    }
+    if (!(cx.status & (ST_REFEXIT | ST_OVERFLOW))) {
+        unsigned long long off = 0;
+        if (wv::leader()) off = atomicAdd(&a.ctl->line_cursor, (unsigned long long)o.n);
+        off = (unsigned long long)wv::uni64((long long)off);
+        if ((int64_t)(off + (unsigned long long)o.n) <= a.line_cap) {
+            HP_G int32_t *dst = (HP_G int32_t *)(a.line_base + off);
+            const HP_G int32_t *src = (const HP_G int32_t *)o.w;
+            wv::sync();
+            for (int b = 0; b < o.n; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < o.n) dst[i] = src[i]; } }
+            U.out_off = (int64_t)off; U.out_len = o.n; U.n_reg = n_reg;
+        } else cx.status |= ST_OVERFLOW;
+    }
+    PH_TADD(round == 0 ? 2 : 4);
+    meta_flag(a, rd, r);
+}
+
+// ---------------------------------------------------------------- chain2: one read
+HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds)
+{
+    RdMeta &M = a.meta[rd];
+    if (M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
+    PH_T0();
+    ReadCtx r;
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    pers_bind(r, a, rd);
+    Ctx &cx = r.cx;
+    const int H = r.H, c = H + 1;
+    int32_t *nm = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 10 * (size_t)c);
+    const int reg_cap = 256;
+    Regs G; G.n = 0; G.m = 0;
+    G.beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)reg_cap); G.end = G.beg + reg_cap;
+    G.rb = (RegB *)arena_alloc(cx, sizeof(RegB) * 2 * (size_t)reg_cap); G.re = G.rb + reg_cap;
+    G.r_beg = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 6 * (size_t)(reg_cap + 2));
+    G.r_end = G.r_beg + (reg_cap + 2); G.r_bs = G.r_end + (reg_cap + 2); G.r_bn = G.r_bs + (reg_cap + 2); G.r_es = G.r_bn + (reg_cap + 2); G.r_en = G.r_es + (reg_cap + 2);
+    if (nm && G.beg && G.rb && G.r_beg) {
+        aux_bind(r, nm);
+        // the covered read intervals of round 1, in line and record order (push_reg_res, lamsa_aln.c:571-595)
+        for (int j = 0; j < M.fl_n[0]; ++j) {
+            const UnitRec &U = a.units[M.unit_base[0] + j];
+            const int32_t *w = a.line_base + U.out_off + (U.out_len - PH_REG_WORDS * U.n_reg);
+            for (int k = 0; k < U.n_reg; ++k, w += PH_REG_WORDS) {
+                if (G.n >= reg_cap) { cx.status |= ST_OVERFLOW; break; }
+                const int g = G.n++;
+                G.beg[g] = w[0]; G.end[g] = w[1];
+                G.rb[g].is_rev = w[2]; G.rb[g].chr = w[3]; G.rb[g].pos = (int64_t)(((unsigned long long)(unsigned)w[5] << 32) | (unsigned)w[4]);
+                G.re[g].is_rev = w[6]; G.re[g].chr = w[7]; G.re[g].pos = (int64_t)(((unsigned long long)(unsigned)w[9] << 32) | (unsigned)w[8]);
+            }
+        }
+        wv::sync();
+        if (!(cx.status & ST_OVERFLOW)) {
+            regs_remain(r, G, a.P.seed_len, r.L);
+            FLines F;
+            FlStore fs; fs.base = a.fl_base; fs.cap = a.fl_cap; fs.cursor = &a.ctl->fl_cursor; fs.got_off = 0; fs.got_tot = 0;
+            const bool ok2 = chain_remain(r, G, F, &fs);
+            if (ok2 && F.n > 0) units_push(a, r, rd, 1, F, fs);
+            else if (!ok2 && !(cx.status & (ST_REFEXIT | ST_OVERFLOW))) cx.status |= ST_OVERFLOW;
+        }
+    }
+    PH_TADD(3);
+    meta_flag(a, rd, r);
+}
+
+// ---------------------------------------------------------------- publish: one read's result stream
+HP_NOINL void phase_publish(const PhaseArgs &a, int rd)
+{
+    const RdMeta &M = a.meta[rd];
+    const int st = M.status;
+    const bool dead = (st & (ST_REFEXIT | ST_OVERFLOW)) != 0;
+    int n_words = 3;
+    if (!dead)
+        for (int round = 0; round < 2; ++round)
+            for (int j = 0; j < M.fl_n[round]; ++j) { const UnitRec &U = a.units[(size_t)round * a.unit_cap + M.unit_base[round] + j]; n_words += U.out_len - PH_REG_WORDS * U.n_reg; }
+    unsigned long long off = 0;
+    if (wv::leader()) off = atomicAdd(a.out.cursor, (unsigned long long)n_words);
+    off = (unsigned long long)wv::uni64((long long)off);
+    if ((int64_t)(off + (unsigned long long)n_words) <= a.out.stream_cap) {
+        HP_G int32_t *dst = (HP_G int32_t *)(a.out.stream + off);
+        dst[0] = st; dst[1] = dead ? 0 : M.fl_n[0]; dst[2] = dead ? 0 : M.fl_n[1];
+        int at = 3;
+        if (!dead)
+            for (int round = 0; round < 2; ++round)
+                for (int j = 0; j < M.fl_n[round]; ++j) {
+                    const UnitRec &U = a.units[(size_t)round * a.unit_cap + M.unit_base[round] + j];
+                    const int n = U.out_len - PH_REG_WORDS * U.n_reg;
+                    const HP_G int32_t *src = (const HP_G int32_t *)(a.line_base + U.out_off);
+                    for (int b = 0; b < n; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < n) dst[at + i] = src[i]; } }
+                    at += n;
+                }
+        a.out.read_out_off[rd] = (int64_t)off; a.out.read_out_len[rd] = n_words;
+    } else { a.out.read_out_off[rd] = -1; a.out.read_out_len[rd] = 0; }
+    a.out.read_status[rd] = st;
+    if (a.out.read_tbases) a.out.read_tbases[rd] = M.tbases;
+    if (a.out.read_work) { a.out.read_work[2 * rd] = M.cells; a.out.read_work[2 * rd + 1] = M.pairs; }
+}
+
+// launch accounting for the host: the earlier launches are complete when publish starts
+HP_INL void publish_diag(const PhaseArgs &a)
+{
+    if (a.out.diag && wv::leader()) {
+        for (int k = 0; k < 4; ++k) { a.out.diag[2 * k] = ~a.ctl->t_first_inv[k]; a.out.diag[2 * k + 1] = a.ctl->t_last[k]; }
+        a.out.diag[8] = (unsigned long long)a.ctl->n_units[0]; a.out.diag[9] = (unsigned long long)a.ctl->n_units[1];
+        a.out.diag[10] = a.ctl->fl_cursor; a.out.diag[11] = a.ctl->line_cursor;
+    }
+}
+
+}  // namespace hp

@@ -68,7 +68,7 @@ HP_INL void block_store(const HP_L uint64_t *lw, HP_G uint64_t *work, int b0, in
         const int k = i + l;
         if (k < Hb) {
             const uint64_t v = lw[k];
-            if (final) { const int s = (int)(v & ((1ull << ib) - 1)); srt[b0 + k] = s; rnk[s] = b0 + k; }
+            if (final) { const int s = (int)(v & ((1ull << ib) - 1)); srt[b0 + k] = s; if (rnk) rnk[s] = b0 + k; }
             else work[b0 + k] = v;
         }
     }
@@ -97,6 +97,46 @@ HP_FN void bitonic_pairs(HP_G uint64_t *key, HP_G int32_t *srt, int H)
     }
 }
 
+// The network on packed words (major key << ib | element index), `major(k)` < 2^major_bits evaluated per lane.  srt[i] = the
+// element that is i-th in (major, index) order; rnk (may be null) the inverse.  work: 8*H bytes of scratch in HBM, lw: lds_n
+// 64-bit words of LDS owned by this wave.  Returns false when the words would not fit 64 bits (the caller then sorts pairs).
+template <class MajorFn>
+HP_INL bool sort_packed(MajorFn major, int major_bits, int H, HP_G int32_t *srt, HP_G int32_t *rnk, HP_G uint64_t *work, HP_L uint64_t *lw, int lds_n)
+{
+    const int ib = H > 1 ? bits_of((unsigned)(H - 1)) : 0, C = HP_SORT_BLOCK;
+    if (!(major_bits + ib <= 64 && lds_n >= C)) return false;
+    // every block: packed straight into LDS, sorted there
+    const bool one = H <= C;
+    for (int b0 = 0; b0 < H; b0 += C) {
+        const int Hb = H - b0 < C ? H - b0 : C;
+        for (int i = 0; i < Hb; i += 4 * wv::W) WAVE_FOR(l) {
+            uint64_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = b0 + i + u * wv::W + l; kk[u] = k < H ? major(k) : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = i + u * wv::W + l;
+                if (k < Hb) lw[k] = (kk[u] << ib) | (uint64_t)(b0 + k);
+            }
+        }
+        wv::sync();
+        for (int k = 2; (k >> 1) < Hb; k <<= 1)
+            for (int j = k >> 1; j >= 1; j >>= 1) bitonic_stage(lw, Hb, j, j == (k >> 1) ? k - 1 : j);
+        block_store(lw, work, b0, Hb, one, ib, srt, rnk);
+    }
+    // merges of blocks of k/2 into blocks of k: the far stages (distance >= C) in HBM, the rest block by block in LDS
+    for (int k = 2 * C; (k >> 1) < H; k <<= 1) {
+        for (int j = k >> 1; j >= C; j >>= 1) bitonic_stage(work, H, j, j == (k >> 1) ? k - 1 : j);
+        for (int b0 = 0; b0 < H; b0 += C) {
+            const int Hb = H - b0 < C ? H - b0 : C;
+            block_load(lw, work, b0, Hb);
+            for (int j = C >> 1; j >= 1; j >>= 1) bitonic_stage(lw, Hb, j, j);
+            block_store(lw, work, b0, Hb, k >= H, ib, srt, rnk);
+        }
+    }
+    return true;
+}
+
 // pos/chr/strand: the H hits of one read.  srt_/rnk_: H entries each.  work_: 8*H bytes of scratch in HBM.
 // lw: lds_n 64-bit words of LDS owned by this wave.  pb / cb: bits of the largest position / of the largest
 // contig*2+strand code in the batch (host, from the validation pass).
@@ -109,39 +149,10 @@ HP_NOINL void sort_read_hits(const int64_t *pos_, const int32_t *chr_, const int
     const HP_G int64_t *pos = (const HP_G int64_t *)pos_;
     const HP_G int32_t *chr = (const HP_G int32_t *)chr_;
     const HP_G int8_t *strand = (const HP_G int8_t *)strand_;
-    const int ib = H > 1 ? bits_of((unsigned)(H - 1)) : 0, C = HP_SORT_BLOCK;
-    if (pb + cb + ib <= 64 && pb + ib <= 62 && lds_n >= C) {
-        // every block: packed straight from the hit arrays into LDS, sorted there
-        const bool one = H <= C;
-        for (int b0 = 0; b0 < H; b0 += C) {
-            const int Hb = H - b0 < C ? H - b0 : C;
-            for (int i = 0; i < Hb; i += 4 * wv::W) WAVE_FOR(l) {
-                uint64_t kk[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int k = b0 + i + u * wv::W + l; kk[u] = k < H ? hit_sort_key(chr[k], strand[k], pos[k]) : 0ull; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = i + u * wv::W + l;
-                    if (k < Hb) lw[k] = ((kk[u] >> 40) << (pb + ib)) | ((kk[u] & ((1ull << 40) - 1)) << ib) | (uint64_t)(b0 + k);
-                }
-            }
-            wv::sync();
-            for (int k = 2; (k >> 1) < Hb; k <<= 1)
-                for (int j = k >> 1; j >= 1; j >>= 1) bitonic_stage(lw, Hb, j, j == (k >> 1) ? k - 1 : j);
-            block_store(lw, work, b0, Hb, one, ib, srt, rnk);
-        }
-        // merges of blocks of k/2 into blocks of k: the far stages (distance >= C) in HBM, the rest block by block in LDS
-        for (int k = 2 * C; (k >> 1) < H; k <<= 1) {
-            for (int j = k >> 1; j >= C; j >>= 1) bitonic_stage(work, H, j, j == (k >> 1) ? k - 1 : j);
-            for (int b0 = 0; b0 < H; b0 += C) {
-                const int Hb = H - b0 < C ? H - b0 : C;
-                block_load(lw, work, b0, Hb);
-                for (int j = C >> 1; j >= 1; j >>= 1) bitonic_stage(lw, Hb, j, j);
-                block_store(lw, work, b0, Hb, k >= H, ib, srt, rnk);
-            }
-        }
-        return;
-    }
+    const int ib = H > 1 ? bits_of((unsigned)(H - 1)) : 0;
+    if (pb + ib <= 62 &&
+        sort_packed([&](int k) { const uint64_t kk = hit_sort_key(chr[k], strand[k], pos[k]); return ((kk >> 40) << pb) | (kk & ((1ull << 40) - 1)); },
+                    pb + cb, H, srt, rnk, work, lw, lds_n)) return;
     for (int b = 0; b < H; b += wv::W) WAVE_FOR(l) {
         const int k = b + l;
         if (k < H) { work[k] = hit_sort_key(chr[k], strand[k], pos[k]); srt[k] = k; }

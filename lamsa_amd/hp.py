@@ -51,7 +51,7 @@ class HpBatch(C.Structure):
 class HpResult(C.Structure):
     """struct lamsa_hp_result"""
     _fields_ = [("stream", C.POINTER(C.c_int32)), ("stream_words", C.c_int64), ("read_off", C.POINTER(C.c_int64)),
-                ("read_len", C.POINTER(C.c_int32)), ("read_status", C.POINTER(C.c_int32)), ("read_tbases", C.POINTER(C.c_int32))]
+                ("read_len", C.POINTER(C.c_int32)), ("read_status", C.POINTER(C.c_int32)), ("read_tbases", C.POINTER(C.c_int32)), ("read_work", C.POINTER(C.c_int32))]
 
 
 EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lamsa_hp_destroy",
@@ -64,8 +64,10 @@ _lib = None
 
 
 def load_library(path=LIB_PATH):
-    """Load liblamsa_hp.so; raises if it has not been built (no fallback)."""
+    """Load liblamsa_hp.so; raises if it has not been built (no fallback).  LAMSA_HP_LIB names another build of the same
+    library (diagnostic builds with cycle counters: make -C lamsa_amd/csrc OUT=... EXTRA=-DHP_PROF)."""
     global _lib
+    path = os.environ.get("LAMSA_HP_LIB", path)
     if _lib is None:
         if not os.path.exists(path):
             raise RuntimeError("HIP hot-path library missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
@@ -212,6 +214,7 @@ class LamsaHp:
         st = np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n].copy()
         stream = np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)).copy()
         self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n].copy()
+        self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n].copy()
         self.last_stream_words = int(R.stream_words)
         return [stream[int(off[i]):int(off[i]) + int(ln[i])].tolist() for i in range(n)], st
 
@@ -243,6 +246,7 @@ class LamsaHp:
         if raw:
             n = self._n_up
             self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
+            self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n]
             self.last_stream_words = int(R.stream_words)
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
@@ -265,6 +269,7 @@ class LamsaHp:
         n = self._n_up
         if raw:
             self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
+            self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n]
             self.last_stream_words = int(R.stream_words)
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])

@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+int g_emu_cl_cap = 1 << 30;            // tests: clusters larger than this take the HBM path of the main chaining pass (hp_cluster.h)
+#define HP_CL_CAP_RT (g_emu_cl_cap < HP_CL_CAP ? g_emu_cl_cap : HP_CL_CAP)
 #include "hp_dp_batch.h"
 
 using namespace hp;
@@ -27,7 +29,7 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
 
 // ---------------------------------------------------------------- whole per-read path, emulated
 #include <algorithm>
-#include "hp_align.h"
+#include "hp_phase.h"
 
 // key field widths of a batch, as the product's validation pass derives them
 static void emu_sort_widths(const BatchIn &in, int n_reads, int &pb, int &cb)
@@ -72,6 +74,12 @@ extern "C" int64_t emu_sort_check(int n_reads, const int64_t *seed_off, const in
     return bad;
 }
 
+// 1 (default): scale-1 batches take the phased path of hp_phase.h, like the product's main pass; 0: the one-kernel path
+static int g_emu_phased = 1, g_emu_unit_cap = 0;
+extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
+extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : 1 << 30; }
+extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
+
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
                                int32_t *stream, int64_t stream_cap, int64_t *n_words, int64_t *read_off, int32_t *read_len, int32_t *status)
 {
@@ -84,10 +92,39 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     emu_sort_widths(a.in, B->n_reads, a.sort_pb, a.sort_cb);
     unsigned long long cursor = 0;
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
-    a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr;
+    a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr; a.out.read_work = nullptr; a.out.diag = nullptr;
     std::vector<char> slab(slab_bytes);
-    a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
     static int32_t lds[HP_LDS_WORDS];
+    if (scale == 1 && g_emu_phased) {
+        // the product's main pass: chain1 -> fill -> chain2 -> fill -> publish, every phase over the whole batch before the next starts
+        PhaseArgs p;
+        p.P = a.P; p.ref = a.ref; p.in = a.in; p.out = a.out; p.slab = slab.data(); p.slab_per_wave = slab_bytes;
+        p.sort_pb = a.sort_pb; p.sort_cb = a.sort_cb; p.order = nullptr; p.n_reads = B->n_reads; p.prof = nullptr;
+        const int n = B->n_reads;
+        const int64_t n_hits = n ? B->hit_off[B->seed_off[n]] : 0, n_bases = n ? B->read_off[n] : 0;
+        std::vector<NodeS> nd((size_t)(n_hits + n) + 1); std::vector<int32_t> nseed((size_t)(n_hits + n) + 1), sidx(2 * (size_t)(n_hits + n) + 2);
+        std::vector<RdMeta> meta((size_t)n + 1); memset(meta.data(), 0, sizeof(RdMeta) * meta.size());
+        p.unit_cap = g_emu_unit_cap > 0 ? g_emu_unit_cap : 8 * n + 64;
+        std::vector<UnitRec> units(2 * (size_t)p.unit_cap); std::vector<int32_t> bq(2 * (size_t)PH_NBUCKET * p.unit_cap);
+        p.fl_cap = 16 * (n_hits + n) + 1024 * (int64_t)n + 1024; p.line_cap = stream_cap + 16 * 2 * (int64_t)p.unit_cap;
+        std::vector<int32_t> fl((size_t)p.fl_cap), lines((size_t)p.line_cap);
+        PhaseCtl ctl; memset(&ctl, 0, sizeof ctl);
+        p.g_nd = nd.data(); p.g_nseed = nseed.data(); p.g_sidx = sidx.data(); p.meta = meta.data(); p.units = units.data(); p.bucket_q = bq.data();
+        p.fl_base = fl.data(); p.line_base = lines.data(); p.ctl = &ctl;
+        (void)n_bases;
+        auto fill_all = [&](int round) {
+            for (int b = 0; b < PH_NBUCKET; ++b)
+                for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
+        };
+        for (int r = 0; r < n; ++r) phase_chain1(p, r, 0, lds);
+        fill_all(0);
+        for (int r = 0; r < n; ++r) phase_chain2(p, r, 0, lds);
+        fill_all(1);
+        for (int r = 0; r < n; ++r) phase_publish(p, r);
+        *n_words = (int64_t)cursor;
+        return 0;
+    }
+    a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
     for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0, lds);
     *n_words = (int64_t)cursor;
     return 0;

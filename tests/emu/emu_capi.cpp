@@ -21,7 +21,7 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
 struct lamsa_hp_handle {
     lamsa_hp_para P; lamsa_hp_ref ref; std::string err;
     std::vector<int32_t> d_score, d_qle, d_tle, d_status, d_cig; std::vector<int64_t> d_off;      // lamsa_hp_dp_batch results
-    std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off;
+    std::vector<int32_t> stream, len, status, tb, work; std::vector<int64_t> off;
     struct Done { std::vector<int32_t> stream, len, status, tb; std::vector<int64_t> off; };
     std::deque<Done> fifo;                 // lamsa_hp_submit_batch computes at once; lamsa_hp_collect_batch hands the oldest out
 };
@@ -61,7 +61,7 @@ extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B,
     h->stream.clear();
     for (int r = 0; r < n; ++r) { h->off[r] = (int64_t)h->stream.size(); h->len[r] = (int32_t)per[r].size(); h->stream.insert(h->stream.end(), per[r].begin(), per[r].end()); }
     res->stream = h->stream.data(); res->stream_words = (int64_t)h->stream.size(); res->read_off = h->off.data(); res->read_len = h->len.data();
-    res->read_status = h->status.data(); res->read_tbases = h->tb.data();
+    res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(2 * h->tb.size() + 2, 0); res->read_work = h->work.data();
     return LAMSA_HP_OK;
 }
 
@@ -90,7 +90,7 @@ extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
     h->fifo.pop_front();
     if (h->stream.empty()) h->stream.push_back(0);
     res->stream = h->stream.data(); res->stream_words = 0; for (size_t r = 0; r + 1 < h->len.size(); ++r) res->stream_words += h->len[r];
-    res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data();
+    res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(2 * h->tb.size() + 2, 0); res->read_work = h->work.data();
     return LAMSA_HP_OK;
 }
 extern "C" void *lamsa_hp_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }

@@ -36,6 +36,7 @@ template <class T> struct Lane {
 HP_INL void sync() {}
 HP_INL bool leader() { return true; }
 HP_INL long long clock() { return 0; }
+HP_INL unsigned long long wall() { return 0; }
 HP_INL int uni(int v) { return v; }
 HP_INL long long uni64(long long v) { return v; }
 HP_INL int bcast(const Lane<int> &x, int src) { return x.v[src]; }
@@ -67,5 +68,7 @@ HP_INL void scan_add_excl(Lane<int> &x) {
 
 // single-threaded stand-ins for the two device atomics the kernels use
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
+static inline int atomicOr(int *p, int v) { int o = *p; *p |= v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 

@@ -61,8 +61,12 @@ def build_oracle():
 def oracle():
     global _oracle
     if _oracle is None:
-        build_oracle()
-        L = C.CDLL(os.path.join(ORACLE_DIR, "liblamsa_oracle.so"))
+        so = os.path.join(ORACLE_DIR, "liblamsa_oracle.so")
+        if not os.environ.get("LAMSA_NO_BUILD"):          # bench.py sets it: no make / gcc children at run time (it may run under a profiler)
+            build_oracle()
+        elif not os.path.exists(so):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first" % so)
+        L = C.CDLL(so)
         L.lo_para_init.argtypes = [C.POINTER(LoPara)]
         L.lo_para_finish.argtypes = [C.POINTER(LoPara)]
         _oracle = L
@@ -181,7 +185,7 @@ def emu():
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
             subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                             "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "lamsa_amd", "csrc"),
-                            "-Wall", "-Wno-unused-function", "-o", out] + srcs, check=True)
+                            "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", out] + srcs, check=True)
         _emu = C.CDLL(out)
     return _emu
 
@@ -334,10 +338,13 @@ def oracle_streams(batch, P, n_threads=4):
     return split_streams(stream, off[:n], ln[:n])
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20):
-    """Per-read result streams from the device sources compiled with the CPU lane emulation."""
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0):
+    """Per-read result streams from the device sources compiled with the CPU lane emulation.
+    phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
+    cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h)."""
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
+    E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap))
     n = batch.n_reads
     hb = batch.c_hp_batch(HpBatch) if hasattr(batch, "c_hp_batch") else hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)

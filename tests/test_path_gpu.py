@@ -64,6 +64,35 @@ def test_hip_rejects_malformed_batches(tmp_path):
     bad = B.take([0, 1]); bad.seed_id = bad.seed_id.copy(); bad.seed_id[1] = bad.seed_id[0]
     with pytest.raises(RuntimeError):
         h.align_batch(bad)
+    # seed geometry that is not the read's own (a stale or foreign hit stream): the kernels would cut read windows from it
+    bad = B.take([0, 1]); bad.seed_all = bad.seed_all.copy(); bad.seed_all[0] += 7
+    with pytest.raises(RuntimeError, match="seed_all"):
+        h.align_batch(bad)
+    bad = B.take([0, 1]); bad.last_len = bad.last_len.copy(); bad.last_len[1] += 1
+    with pytest.raises(RuntimeError, match="last_len"):
+        h.align_batch(bad)
+    # fields the device keeps in fewer bits than the boundary's types: rejected, never wrapped
+    bad = B.take([0, 1]); bad.h_len_dif = bad.h_len_dif.copy(); bad.h_len_dif[0] = 300
+    with pytest.raises(RuntimeError, match="len_dif"):
+        h.align_batch(bad)
+    got, st = h.align_batch(B)                                    # the handle is still usable
+    assert got == reflib.oracle_streams(B, lp) and (st == 0).all()
+    h.close()
+
+
+def test_hip_rejects_a_megabase_read():
+    """A read with more than 32767 seeds (1.2 Mbp at the 25-bp step) is refused with LAMSA_HP_EINVAL and a message: the
+    device keeps seed ids in 16 bits, and wrapped ids would chain into wrong alignments with status 0."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import simbatch
+    from lamsa_amd import hp
+    ref = simbatch.SimRef(4_000_000, n_contigs=2, seed=3, threads=4)
+    B = simbatch.SimBatch(ref, 1, 1_200_000, "ont2d", seed=5, threads=4)
+    h = hp.LamsaHp(hp.make_para("ont2d"), ref=(ref.pac, ref.l_pac, ref.seq_off, ref.seq_len), device=0)
+    with pytest.raises(RuntimeError, match="32767 seeds|16383 seeds"):
+        h.align_batch(B)
     h.close()
 
 

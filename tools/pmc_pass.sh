@@ -15,7 +15,7 @@ i=0
 for set in "${groups[@]}"; do
   i=$((i+1))
   # counter collection serialises the dispatches anyway: one launch at a time (--sequential)
-  rocprofv3 --pmc $set --output-format csv -d $out/pmc_$i -- python3 bench.py "$@" --sequential > $out/bench_pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/bench_pmc_$i.log; exit 1; }
+  rocprofv3 --pmc $set --output-format csv -d $out/pmc_$i -- python3 bench.py "$@" --sequential --bare > $out/bench_pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/bench_pmc_$i.log; exit 1; }
   python3 - "$out/pmc_$i" <<'PY'
 import csv, glob, sys, collections
 tot = collections.defaultdict(float); nd = collections.defaultdict(set)

@@ -34,7 +34,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not os.environ.get("LAMSA_NO_BUILD"):          # bench.py sets it: no gcc child at run time (it may run under a profiler)
+            build()
+        elif not os.path.exists(SO):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first" % SO)
         L = C.CDLL(SO)
         L.sim_ref_new.restype = C.c_void_p
         L.sim_ref_new.argtypes = [C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -81,6 +84,8 @@ PROFILES = {  # read error model + GEM thresholds per read type (gem_map.sh argu
     "pacbio": dict(sub=0.015, ins=0.09, dele=0.045, seed_step=25, max_edit=15, max_mis=2, min_match=35),
     "ont2d": dict(sub=0.04, ins=0.04, dele=0.04, seed_step=25, max_edit=12, max_mis=3, min_match=30),
     "pb20k": dict(sub=0.01, ins=0.09, dele=0.05, seed_step=25, max_edit=15, max_mis=2, min_match=35),
+    # BASELINE.json config 5: 1 % errors, one SV (deletion 1-10 kbp or novel insertion 1-5 kbp at the read's middle) in 2/3 of the reads
+    "sv10k": dict(sub=0.004, ins=0.003, dele=0.003, seed_step=100, max_edit=2, max_mis=2, min_match=40, sv_frac=0.67),
 }
 
 
@@ -90,7 +95,7 @@ class SimBatch:
     def __init__(self, ref, n_reads, length, profile, seed=7, threads=8):
         L = lib()
         p = PROFILES[profile]
-        cfg = SimCfg(n_reads, length, p["sub"], p["ins"], p["dele"], 0.0, 50, p["seed_step"], p["max_edit"], p["max_mis"], p["min_match"], 3, 200)
+        cfg = SimCfg(n_reads, length, p["sub"], p["ins"], p["dele"], p.get("sv_frac", 0.0), 50, p["seed_step"], p["max_edit"], p["max_mis"], p["min_match"], 3, 200)
         bp = L.sim_reads_new(ref._p, seed, C.byref(cfg), threads)
         b = bp.contents
         n, ns, nh = b.n_reads, b.n_slots, b.n_hits

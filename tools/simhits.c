@@ -187,11 +187,22 @@ static void *read_worker(void *arg)
         /* locus */
         int ci; int64_t pos;
         for (;;) { int64_t gp = (int64_t)rndn(&g, (uint64_t)R->l_pac); ci = 0; while (ci + 1 < R->n_seqs && gp >= R->seq_off[ci + 1]) ++ci;
-                   pos = gp - R->seq_off[ci]; if (pos + (int64_t)L0 * 2 + 16 < R->seq_len[ci]) break; }
+                   pos = gp - R->seq_off[ci]; if (pos + (int64_t)L0 * 2 + 16 + (C->sv_frac > 0 ? 10016 : 0) < R->seq_len[ci]) break; }
         const int strand = (rnd(&g) & 1) ? 1 : -1;
+        /* one structural variant at the middle of the read: a deletion of U[1k,10k] reference
+         * bases or a novel insertion of U[1k,5k] random bases.  No random number is drawn when sv_frac is 0, so the other
+         * workloads' reads stay what they were. */
+        int sv_kind = 0, sv_len = 0;
+        if (C->sv_frac > 0 && rnd01(&g) < C->sv_frac) { sv_kind = 1 + (int)(rnd(&g) & 1); sv_len = sv_kind == 1 ? 1000 + (int)rndn(&g, 9001) : 1000 + (int)rndn(&g, 4001); }
         /* walk the reference, apply errors: forward-fragment read fr[] with ref coordinate per base (-1: inserted) */
         int L = 0; int64_t gk = R->seq_off[ci] + pos;
         while (L < L0) {
+            if (sv_kind && L >= L0 / 2) {
+                if (sv_kind == 1) gk += sv_len;
+                else for (int i = 0; i < sv_len && L < L0; ++i) { fr[L] = (uint8_t)rndn(&g, 4); rmap[L] = -1; ++L; }
+                sv_kind = 0;
+                continue;
+            }
             const double x = rnd01(&g);
             if (x < C->del) { ++gk; continue; }
             int b = GETB(R->pac, gk);

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Summarise one tools/prof_bench.sh run (gpurun_out/prof/<tag>/) into the two files kept under profiles/:
     <out>_kernel_stats.csv   the rocprofv3 --kernel-trace --stats table, as written by rocprofv3
-    <out>_pmc.json           per-dispatch averages of every counter over the k_align_batch dispatches, plus the
-                             HBM traffic derived from FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes
+    <out>_pmc.json           per kernel of the hot path: rocprofv3's average duration and the per-dispatch average of every
+                             counter, the HBM traffic derived from FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes
+                             (FETCH_SIZE in KiB; as reported = lower bound, reads doubled for the gfx950 under-count of wide
+                             coalesced reads = upper bound), and the issue / wait shares of wave cycles
 usage: tools/summarize_prof.py gpurun_out/prof/<tag> profiles/<name> "<command line that produced it>" [bench.json]
 """
 import csv
@@ -12,7 +14,14 @@ import os
 import shutil
 import sys
 
-KERNEL = "k_align_batch"
+KERNELS = ("k_chain1", "k_fill", "k_chain2", "k_publish", "k_align_batch", "k_dp_batch")
+
+
+def kname(s):
+    for k in KERNELS:
+        if s.startswith(k) or (" " + k) in s or s.startswith("void " + k):
+            return k
+    return None
 
 
 def main():
@@ -22,35 +31,51 @@ def main():
     if not stats:
         sys.exit("no kernel_stats.csv under %s/stats" % src)
     shutil.copy(stats[0], out + "_kernel_stats.csv")
-    avg_ms = calls = None
+    kern = {}
     for row in csv.DictReader(open(stats[0])):
-        if row["Name"].startswith(KERNEL):
-            avg_ms = float(row["AverageNs"]) / 1e6; calls = int(row["Calls"])
-    per = {}
+        k = kname(row["Name"])
+        if k:
+            kern[k] = {"calls": int(row["Calls"]), "avg_ms_rocprof": round(float(row["AverageNs"]) / 1e6, 3), "total_ms_rocprof": round(float(row["TotalDurationNs"]) / 1e6, 3)}
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
         acc = {}
         for row in csv.DictReader(open(f)):
-            if not row["Kernel_Name"].startswith(KERNEL):
+            k = kname(row["Kernel_Name"])
+            if not k:
                 continue
-            acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
-            acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-        for name, by_disp in acc.items():
-            per[name] = sum(by_disp.values()) / len(by_disp)
-    doc = {"command": cmd, "kernel": KERNEL, "dispatches_per_pass": calls, "kernel_avg_ms_rocprof": round(avg_ms, 3) if avg_ms else None}
+            acc.setdefault((k, row["Counter_Name"]), {}).setdefault(row["Dispatch_Id"], 0.0)
+            acc[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for (k, name), by_disp in acc.items():
+            kern.setdefault(k, {}).setdefault("per_dispatch", {})[name] = sum(by_disp.values()) / len(by_disp)
+            kern[k].setdefault("pmc_dispatches", {})[name] = len(by_disp)
+    for k, d in kern.items():
+        per = d.get("per_dispatch", {})
+        if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+            d["hbm_bytes_per_dispatch_lower"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+            d["hbm_bytes_per_dispatch_upper"] = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+        wc = per.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c, key in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_ACTIVE_INST_ANY", "issuing_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac")):
+                if c in per:
+                    d[key] = round(per[c] / wc, 4)
+        if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per:
+            d["l2_hit_rate"] = round(per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4)
+    doc = {"command": cmd, "kernels": kern,
+           "hbm_traffic_note": "FETCH_SIZE/WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; these kernels mix "
+                               "narrow gathers and coalesced loads, so a lower (as reported) and an upper (reads x2) bound are given; bench.py's roofline.traffic uses the upper one."}
     if bench:
-        doc["kernel_avg_ms_bench_hip_events"] = bench["roofline"]["kernel_ms"]
-        doc["algorithmic_bytes_per_dispatch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
         doc["reads_per_step"] = bench["config"]["reads_per_step_per_gpu"]
         doc["workload"] = bench["config"]["workload"].split(":")[0]
-    doc["per_dispatch"] = per
-    if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
-        doc["hbm_traffic_note"] = ("FETCH_SIZE/WRITE_SIZE are in KiB. Per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; "
-                                   "this kernel mixes narrow gathers and coalesced record loads, so lower (as reported) and upper (reads x2) bounds are given; "
-                                   "`traffic` in bench.py's roofline uses the upper bound.")
-        doc["hbm_bytes_per_dispatch_lower"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
-        doc["hbm_bytes_per_dispatch_upper"] = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+        doc["algorithmic_bytes_per_step"] = bench["roofline"].get("algorithmic_bytes_per_step", bench["roofline"].get("algorithmic_bytes_per_launch"))
+        doc["launch_ms_bench_hip_events"] = bench.get("launch_ms")
+    # one step of the main pass = chain1 + fill + chain2 + fill + publish: traffic of a step
+    main = [k for k in ("k_chain1", "k_fill", "k_chain2", "k_publish") if k in kern and "hbm_bytes_per_dispatch_upper" in kern[k]]
+    if main:
+        mult = {"k_fill": 2}
+        doc["hbm_bytes_per_step_lower"] = sum(kern[k]["hbm_bytes_per_dispatch_lower"] * mult.get(k, 1) for k in main)
+        doc["hbm_bytes_per_step_upper"] = sum(kern[k]["hbm_bytes_per_dispatch_upper"] * mult.get(k, 1) for k in main)
     json.dump(doc, open(out + "_pmc.json", "w"), indent=1)
-    print(json.dumps({k: doc[k] for k in doc if k != "per_dispatch"}, indent=1))
+    brief = {k: {x: v for x, v in d.items() if x not in ("per_dispatch", "pmc_dispatches")} for k, d in kern.items()}
+    print(json.dumps({"kernels": brief, **{k: doc[k] for k in doc if k.startswith("hbm_bytes")}}, indent=1))
 
 
 if __name__ == "__main__":
