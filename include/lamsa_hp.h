@@ -127,10 +127,13 @@ typedef struct lamsa_hp_batch {
     const int8_t  *h_strand;   /* map_t.nstrand (+1 / -1)                                    */
     const int16_t *h_nm;       /* map_t.NM                                                   */
     const int16_t *h_len_dif;  /* map_t.len_dif                                              */
-    const int32_t *h_cig_off;  /* start of the seed CIGAR in cig[]                           */
-    const uint8_t *h_cig_n;    /* its length in words                                        */
-    const int32_t *cig;        /* seed CIGAR words (already reversed for '-' hits, src/gem_parse.c:267) */
-    int64_t        n_cig;
+    const int32_t *h_cig_off;  /* start of the seed CIGAR in cig[] / cig8[]; NULL: the CIGARs lie back to back in hit order
+                                  (offset = sum of h_cig_n of the hits before; no 2^31 limit on n_cig then)           */
+    const uint8_t *h_cig_n;    /* its length in elements                                     */
+    const int32_t *cig;        /* seed CIGAR words, len << 4 | op (already reversed for '-' hits, src/gem_parse.c:267) */
+    int64_t        n_cig;      /* elements in cig[] / cig8[]                                 */
+    const uint8_t *cig8;       /* optional, instead of cig[]: one BYTE per element, op << 6 | len, op 0 M / 1 I / 2 D, len <= 63
+                                  (a seed is seed_len = 50 bases: src/lamsa_aln.h:44) -- a quarter of the bytes over PCIe */
 } lamsa_hp_batch;
 
 /* Results: one int32 stream per read (callee-owned, valid until the next call):

@@ -45,26 +45,26 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;        // in device memory: scalar loads, no private copy of the argument block
-    __shared__ int32_t lds[HP_LDS_WORDS];            // the hit sort's blocks (hp_sort.h)
+    __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];      // the hit sort's blocks (hp_sort.h), then the node state of one cluster at a time (hp_cluster.h)
     for (;;) {
         int u = 0;
         if (wv::leader()) u = atomicAdd(&a.ctl->q_head[0], 1);
         u = wv::uni(u);
         if (u >= a.n_reads) break;
-        phase_chain1(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds);
+        phase_chain1(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, HP_CHAIN_LDS_WORDS);
     }
     drain_stamp(a, 0);
 }
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain2(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;
-    __shared__ int32_t lds[HP_LDS_WORDS];
+    __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];
     for (;;) {
         int u = 0;
         if (wv::leader()) u = atomicAdd(&a.ctl->q_head[2], 1);
         u = wv::uni(u);
         if (u >= a.n_reads) break;
-        phase_chain2(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds);
+        phase_chain2(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, HP_CHAIN_LDS_WORDS);
     }
     drain_stamp(a, 2);
 }
@@ -98,6 +98,58 @@ __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
         if (u >= a.n_reads) break;
         phase_publish(a, u);
     }
+}
+
+// ---- the seed CIGARs on their way in: one byte per element and no offsets over PCIe, words and 64-bit offsets in HBM
+__global__ void k_cig8_expand(const uint8_t *src, int32_t *dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int b = src[i]; dst[i] = ((b & 63) << 4) | (b >> 6); }
+}
+__global__ void k_off_widen(const int32_t *src, int64_t *dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// exclusive prefix sum of n bytes into 64-bit offsets, blocks of 4096 elements: per-block sums, their scan by one workgroup,
+// then the local scan of every block on top of its base
+#define HP_SCAN_BLOCK 4096
+__global__ __launch_bounds__(256) void k_scan_sums(const uint8_t *src, int64_t n, int64_t *sums)
+{
+    __shared__ int part[256];
+    const int64_t b0 = (int64_t)blockIdx.x * HP_SCAN_BLOCK;
+    int s = 0;
+    for (int i = threadIdx.x; i < HP_SCAN_BLOCK; i += 256) { const int64_t k = b0 + i; s += k < n ? src[k] : 0; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st]; __syncthreads(); }
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(256) void k_scan_bases(int64_t *sums, int64_t nb)
+{   // one workgroup: every thread owns a contiguous slice of the block sums
+    __shared__ long long tot[256];
+    const int64_t per = (nb + 255) / 256, a = (int64_t)threadIdx.x * per, b = a + per < nb ? a + per : nb;
+    long long s = 0;
+    for (int64_t i = a; i < b; ++i) s += sums[i];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = tot[t]; tot[t] = run; run += v; } }
+    __syncthreads();
+    long long run = tot[threadIdx.x];
+    for (int64_t i = a; i < b; ++i) { const long long v = sums[i]; sums[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *src, int64_t n, const int64_t *bases, int64_t *dst)
+{
+    __shared__ int part[256];
+    const int64_t b0 = (int64_t)blockIdx.x * HP_SCAN_BLOCK + (int64_t)threadIdx.x * 16;
+    int v[16], s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int64_t k = b0 + i; v[i] = k < n ? src[k] : 0; s += v[i]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int x = part[t]; part[t] = run; run += x; } }
+    __syncthreads();
+    long long run = bases[blockIdx.x] + part[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int64_t k = b0 + i; if (k < n) dst[k] = run; run += v[i]; }
 }
 
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -224,13 +276,15 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     // ---- validate everything the kernels index with, on the host, before anything is launched
     S->h_len.assign((size_t)n, 0); S->h_H.assign((size_t)n, 0); S->max_L = 0; S->max_H = 0;
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
-    if (B->n_cig < 0 || B->n_cig > 0x7fffffffll) { h->err = "more than 2^31-1 seed CIGAR words in one batch (h_cig_off is 32-bit): split the batch"; return LAMSA_HP_EINVAL; }
+    const bool packed_off = B->h_cig_off == nullptr, cig_bytes = B->cig8 != nullptr;
+    if (B->n_cig < 0 || (!packed_off && B->n_cig > 0x7fffffffll)) { h->err = "more than 2^31-1 seed CIGAR elements with 32-bit h_cig_off: pass h_cig_off = NULL (CIGARs back to back in hit order) or split the batch"; return LAMSA_HP_EINVAL; }
+    if (!cig_bytes && !B->cig && B->n_cig > 0) { h->err = "neither cig nor cig8 given"; return LAMSA_HP_EINVAL; }
     {
         std::atomic<int> bad(0);                         // 1..9: which check failed (the first one reported wins)
         const int64_t sl = h->para.seed_len, ss = h->para.seed_step > 0 ? h->para.seed_step : 1;
-        std::atomic<long long> max_pos(0);
+        std::atomic<long long> max_pos(0), sum_cig(0);
         hp_parallel_blocks(n, [&](int r0, int r1) {
-            long long mp = 0;
+            long long mp = 0, sc = 0;
             for (int r = r0; r < r1 && !bad.load(std::memory_order_relaxed); ++r) {
                 const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
                 if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { bad = 1; return; }
@@ -252,12 +306,14 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                     mp = B->h_pos[k] > mp ? B->h_pos[k] : mp;
                     if (B->h_len_dif[k] < -127 || B->h_len_dif[k] > 127) { bad = 9; return; }     // kept in 8 bits on the device (NodeS::len_dif8)
                     if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) || B->h_pos[k] < 0 || B->h_pos[k] >= (1ll << 40) ||
-                        B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig) { bad = 6; return; }
+                        (!packed_off && (B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig))) { bad = 6; return; }
+                    sc += B->h_cig_n[k];
                 }
                 S->h_len[r] = (int32_t)L; S->h_H[r] = (int32_t)H;
             }
             long long seen = max_pos.load();
             while (mp > seen && !max_pos.compare_exchange_weak(seen, mp)) { }
+            sum_cig += sc;
         });
         static const char *why[] = {"", "read longer than 2^24 bases or more than 16383 seeds with hits", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
                                     "too many hits in one read", "read base code > 4",
@@ -266,6 +322,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                                     "read has more than 32767 seeds (longer than 32767 * seed_step bases): not supported",
                                     "a hit's len_dif is outside [-127, 127]"};
         if (bad) { h->err = why[bad.load()]; return LAMSA_HP_EINVAL; }
+        if (packed_off && sum_cig.load() != B->n_cig) { h->err = "h_cig_off is NULL but the h_cig_n do not add up to n_cig"; return LAMSA_HP_EINVAL; }
         for (int r = 0; r < n; ++r) { S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
         auto bits = [](unsigned long long x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
         S->sort_pb = bits((unsigned long long)max_pos.load()); S->sort_cb = bits((unsigned long long)(2 * (long long)h->n_seqs + 1));
@@ -284,8 +341,9 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
     const size_t o_roff = place(8 * ((size_t)n + 1)), o_rseq = place((size_t)n_bases), o_sall = place(4 * (size_t)n), o_last = place(4 * (size_t)n),
                  o_soff = place(8 * ((size_t)n + 1)), o_sid = place(4 * (size_t)n_slots), o_hoff = place(8 * ((size_t)n_slots + 1)),
-                 o_pos = place(8 * (size_t)n_hits), o_chr = place(4 * (size_t)n_hits), o_coff = place(4 * (size_t)n_hits), o_nm = place(2 * (size_t)n_hits),
-                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n);
+                 o_pos = place(8 * (size_t)n_hits), o_chr = place(4 * (size_t)n_hits), o_coff = place(8 * (size_t)n_hits), o_nm = place(2 * (size_t)n_hits),
+                 o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n),
+                 o_stage = place(packed_off ? 8 * ((size_t)n_hits / HP_SCAN_BLOCK + 2) : 4 * (size_t)n_hits), o_cig8 = place(cig_bytes ? (size_t)B->n_cig : 0);
     const double t_3 = now_s();
     if (S->bin.ensure(off)) { h->err = "hipMalloc(batch)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)S->bin.p;
@@ -297,17 +355,31 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     UP(o_rseq, B->read_seq, (size_t)n_bases); UP(o_sall, B->seed_all, 4 * (size_t)n); UP(o_last, B->last_len, 4 * (size_t)n);
     UP(o_sid, B->seed_id, 4 * (size_t)n_slots);
     if (n_slots) UP(o_hoff, B->hit_off, 8 * ((size_t)n_slots + 1)); else UP(o_hoff, &zero64, 8);
-    UP(o_pos, B->h_pos, 8 * (size_t)n_hits); UP(o_chr, B->h_chr, 4 * (size_t)n_hits); UP(o_coff, B->h_cig_off, 4 * (size_t)n_hits);
+    UP(o_pos, B->h_pos, 8 * (size_t)n_hits); UP(o_chr, B->h_chr, 4 * (size_t)n_hits);
+    if (!packed_off) UP(o_stage, B->h_cig_off, 4 * (size_t)n_hits);
     UP(o_nm, B->h_nm, 2 * (size_t)n_hits); UP(o_ld, B->h_len_dif, 2 * (size_t)n_hits); UP(o_st, B->h_strand, (size_t)n_hits); UP(o_cn, B->h_cig_n, (size_t)n_hits);
-    UP(o_cig, B->cig, 4 * (size_t)B->n_cig); UP(o_ord, S->order.data(), 4 * (size_t)n);
+    if (cig_bytes) UP(o_cig8, B->cig8, (size_t)B->n_cig); else UP(o_cig, B->cig, 4 * (size_t)B->n_cig);
+    UP(o_ord, S->order.data(), 4 * (size_t)n);
 #undef UP
+    // on the device: CIGAR bytes -> words, offsets widened or summed up from the lengths (same stream, behind the copies)
+    if (cig_bytes && B->n_cig > 0) hipLaunchKernelGGL(k_cig8_expand, dim3(2048), dim3(256), 0, s, (const uint8_t *)(d + o_cig8), (int32_t *)(d + o_cig), (int64_t)B->n_cig);
+    if (n_hits > 0) {
+        if (!packed_off) hipLaunchKernelGGL(k_off_widen, dim3(2048), dim3(256), 0, s, (const int32_t *)(d + o_stage), (int64_t *)(d + o_coff), (int64_t)n_hits);
+        else {
+            const int64_t nb = (n_hits + HP_SCAN_BLOCK - 1) / HP_SCAN_BLOCK;
+            hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(256), 0, s, (const uint8_t *)(d + o_cn), (int64_t)n_hits, (int64_t *)(d + o_stage));
+            hipLaunchKernelGGL(k_scan_bases, dim3(1), dim3(256), 0, s, (int64_t *)(d + o_stage), nb);
+            hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, s, (const uint8_t *)(d + o_cn), (int64_t)n_hits, (const int64_t *)(d + o_stage), (int64_t *)(d + o_coff));
+        }
+    }
+    HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
     if (g_trace) fprintf(stderr, "[lamsa_hp] upload: validate %.1f ms, order %.1f ms, copy %.1f ms (%.2f GB on the device)\n", 1e3 * (t_1 - t_0), 1e3 * (t_3 - t_1), 1e3 * (now_s() - t_3), off / 1e9);
     BatchIn &in = S->in;
     in.n_reads = n; in.read_off = (const int64_t *)(d + o_roff); in.read_seq = (const uint8_t *)(d + o_rseq);
     in.seed_all = (const int32_t *)(d + o_sall); in.last_len = (const int32_t *)(d + o_last); in.seed_off = (const int64_t *)(d + o_soff);
     in.seed_id = (const int32_t *)(d + o_sid); in.hit_off = (const int64_t *)(d + o_hoff); in.h_pos = (const int64_t *)(d + o_pos);
-    in.h_chr = (const int32_t *)(d + o_chr); in.h_cig_off = (const int32_t *)(d + o_coff); in.h_nm = (const int16_t *)(d + o_nm);
+    in.h_chr = (const int32_t *)(d + o_chr); in.h_cig_off = (const int64_t *)(d + o_coff); in.h_nm = (const int16_t *)(d + o_nm);
     in.h_len_dif = (const int16_t *)(d + o_ld); in.h_strand = (const int8_t *)(d + o_st); in.h_cig_n = (const uint8_t *)(d + o_cn);
     in.cig = (const int32_t *)(d + o_cig);
     S->d_order = (const int32_t *)(d + o_ord);

@@ -28,7 +28,7 @@ struct BatchIn {
     const int64_t *hit_off;      // [n_slots+1]
     const int64_t *h_pos;        // [n_hits] 1-based leftmost reference coordinate
     const int32_t *h_chr;        // 1-based contig id
-    const int32_t *h_cig_off;    // into cig[]
+    const int64_t *h_cig_off;    // into cig[] (the boundary takes 32-bit offsets or none at all; widened / summed up on the device)
     const int16_t *h_nm, *h_len_dif;
     const int8_t  *h_strand;     // +1 / -1
     const uint8_t *h_cig_n;

@@ -67,7 +67,7 @@ struct ReadCtx {
     const int32_t *seed_id;     // [seed_out]
     const int64_t *hit_off;     // [seed_out+1], global; local hit index = global - hb
     int64_t hb;
-    const int64_t *h_pos; const int32_t *h_chr, *h_cig_off; const int16_t *h_nm, *h_len_dif;
+    const int64_t *h_pos, *h_cig_off; const int32_t *h_chr; const int16_t *h_nm, *h_len_dif;
     const int8_t *h_strand; const uint8_t *h_cig_n; const int32_t *cig;
     // chaining DP cells (frag_dp_node, lamsa_aln.h:352-373), indexed by local hit index
     int32_t *n_from, *n_in_de, *n_son_n, *n_first, *n_last, *n_next;
@@ -1566,22 +1566,26 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
     { const long long t2_ = wv::clock(); if (r.prof) r.prof[57] += t2_ - tq_; tq_ = t2_; }
 #endif
     if (all_min) min_n = P->per_aln_m;
-    if (min_n != P->per_aln_m) {                                                                  // :1335-1343
-        min_extend_all(r, min_n);
+    // the clusters of the read's hits (hp_cluster.h): what frag_min_extend and the main pass below work on
+    const size_t cmark = arena_mark(r.cx.tmp);
+    Clusters C;
+    bool have_cl = false;
+    if (seed_out > 1 && HP_CL_CAP_RT(1) > 0) {
+        have_cl = clusters_build(r, C, (HP_L uint64_t *)r.cx.lds, r.cx.lds_words / 2);
+        if (!have_cl && (r.cx.status & ST_OVERFLOW)) return false;
+    }
+    if (min_n != P->per_aln_m && seed_out > 1) {                                                  // :1335-1343
+        if (have_cl) min_extend_clusters(r, C); else min_extend_all(r, min_n);
     }
 #ifdef HP_PROF
     { const long long t2_ = wv::clock(); if (r.prof) { r.prof[58] += t2_ - tq_; r.prof[59] += all_min ? 0 : 1; } }
 #endif
     HP_CSTAMP(6);
     if (seed_out > 1) {                                                                           // main pass, :1345-1350
-        // cluster by cluster out of LDS (hp_cluster.h); clusters that do not fit LDS through dp_update_range; then the son lists
-        const size_t cmark = arena_mark(r.cx.tmp);
-        Clusters C;
+        // cluster by cluster out of LDS; clusters that do not fit LDS through dp_update_range; then the son lists
         bool any_big = false;
-        if (!clusters_build(r, C, (HP_L uint64_t *)r.cx.lds, HP_LDS_WORDS / 2)) {
-            if (r.cx.status & ST_OVERFLOW) return false;
-            dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false);                          // keys too wide for the packed sort: everything through HBM
-        } else {
+        if (!have_cl) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false);               // keys too wide for the packed sort: everything through HBM
+        else {
             const HP_G int32_t *g_cs = (const HP_G int32_t *)C.cs, *g_srt = (const HP_G int32_t *)r.srt;
             HP_G uint8_t *g_big = (HP_G uint8_t *)C.big;
             for (int c0 = 0; c0 < C.n_cl; c0 += 63) {
@@ -1591,7 +1595,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
                 for (int q = 0; q < cn; ++q) {
                     const int lo = wv::bcast(csl, q), n = wv::bcast(csl, q + 1) - lo;
                     if (n < 2) continue;                                                          // a lone hit has no predecessor
-                    if (n <= HP_CL_CAP_RT && dp_cluster_lds(r, C, lo, n)) continue;
+                    if (n <= HP_CL_CAP_RT(r.cx.lds_words / 5) && dp_cluster_lds(r, C, lo, n)) continue;
                     for (int i0 = 0; i0 < n; i0 += 64) { WAVE_FOR(l) { if (i0 + l < n) g_big[g_srt[lo + i0 + l]] = 1; } }
                     any_big = true;
                 }
@@ -1600,7 +1604,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
             if (any_big) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false, C.big);
         }
         arena_release(r.cx.tmp, cmark);
-        if (!build_sons(r, (HP_L uint64_t *)r.cx.lds, HP_LDS_WORDS / 2)) return false;
+        if (!build_sons(r, (HP_L uint64_t *)r.cx.lds, r.cx.lds_words / 2)) return false;
     }
 
     HP_CSTAMP(7);

@@ -9,7 +9,7 @@
 // the reference's order (seed slot ascending, hit index ascending).  A read against a repeat-rich genome has one cluster
 // of a few hundred hits at its true locus and hundreds of tiny ones at repeat copies; the reference (and the HBM path of
 // dp_update_range) scans every earlier hit of the big cluster for every one of its targets, O(n^2) loads of 32-byte
-// records.  Here a cluster of up to HP_CL_CAP hits is packed into this wave's LDS (20 bytes per hit, positions relative to
+// records.  Here a cluster of up to lds_words / 5 hits is packed into this wave's LDS (20 bytes per hit, positions relative to
 // the cluster's first hit, the dynamic DP fields included), the whole pass runs out of LDS -- every trip of the
 // predecessor scan is five conflict-free ds_read_b32 -- and the cluster is written back once.  Clusters of one hit have no
 // predecessor at all and are skipped; clusters that do not fit go through dp_update_range as before.
@@ -22,9 +22,10 @@
 
 namespace hp {
 
-#define HP_CL_CAP (HP_LDS_WORDS / 5)      // hits of one cluster that fit this wave's LDS (five words per hit)
+// hits of one cluster that fit this wave's LDS: five words per hit (cap = lds_words / 5); the tests' CPU build overrides this
+// to send small clusters down the HBM path too
 #ifndef HP_CL_CAP_RT
-#define HP_CL_CAP_RT HP_CL_CAP            // the tests' CPU build makes this a variable, to send small clusters down the HBM path too
+#define HP_CL_CAP_RT(cap) (cap)
 #endif
 
 struct Clusters {
@@ -109,11 +110,118 @@ HP_NOINL bool clusters_build(ReadCtx &r, Clusters &C, HP_L uint64_t *lw, int lds
     return ok;
 }
 
+
+// ---------------------------------------------------------------- frag_min_extend for every MIN hit (:1031-1066, :1335-1343), cluster-wise
+// For every MIN hit m and every seed with more than min_n hits, the first hit (ascending) of that seed that is match-class
+// colinear with m joins the MIN pass.  Colinear hits share a cluster (cluster_reach), so m only has to be compared with
+// the MULTI hits of its own cluster -- min_extend_all compares it with every hit of the read.  The hits are walked in
+// the order of C.csrt (cluster by cluster, ascending hit index inside a cluster: the hits of one seed inside one cluster
+// are consecutive and ascending), 64 MIN candidates per outer step against the 64-hit chunks that overlap their
+// clusters; "first within its seed" is a segmented ballot over runs of equal (cluster, seed), carried across chunks.
+HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_csrt = (const HP_G int32_t *)C.csrt, *g_lo = (const HP_G int32_t *)C.cl_lo_r;
+    const EdgeK K = edge_consts(r.cx.P);
+    const int H = r.H;
+    const size_t mark_ = arena_mark(r.cx.tmp);
+    uint8_t *mk = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
+    if (!mk) return;
+    HP_G uint8_t *gmk = (HP_G uint8_t *)mk;
+    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { if (b0 + l < H) gmk[b0 + l] = 0; } }
+    wv::sync();
+    for (int mbase = 0; mbase < H; mbase += 64) {
+        // the MIN hits of this chunk of the cluster order, one per lane; hits that are alone in their cluster have no partner
+        wv::Lane<int> Ma0, Ma1, Ma2, Ma3, Mb0, ism, mcl;
+        WAVE_FOR(l) {
+            const int p = mbase + l, pp = p < H ? p : H - 1;
+            const int id = g_csrt[pp];
+            int a[4], b[4];
+            hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
+            Ma0[l] = a[0]; Ma1[l] = a[1]; Ma2[l] = a[2]; Ma3[l] = a[3]; Mb0[l] = b[0];
+            const int cl = g_lo[pp];
+            const bool lone = cl == pp && (pp + 1 >= H || g_lo[pp + 1] == pp + 1);
+            mcl[l] = cl;
+            ism[l] = p < H && !lone && (int)(int8_t)(b[1] & 0xff) == MIN_FLAG;
+        }
+        const unsigned long long mset = wv::ballot(ism);
+        if (!mset) continue;
+        const int cl_first = wv::bcast(mcl, __builtin_ctzll(mset)), cl_last = wv::bcast(mcl, 63 - __builtin_clzll(mset));
+        unsigned long long carry = 0;                     // bit j: MIN hit j already found its hit in the run (carry_cl, carry_seed)
+        int carry_seed = -1, carry_cl = -1;
+        for (int base = cl_first; base < H; base += 64) {
+            wv::Lane<int> sd, qcl, elig, hit, qsid, qld, idl;
+            wv::Lane<long long> qdiag;          // position minus the seed's offset on the read: colinear hits share it
+            WAVE_FOR(l) {
+                const int p = base + l, pp = p < H ? p : H - 1;
+                const int id = g_csrt[pp];
+                int a[4], b[4];
+                hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
+                sd[l] = p < H ? (a[3] >> 14) : -1; qcl[l] = p < H ? g_lo[pp] : 0x7fffffff; idl[l] = id;
+                elig[l] = p < H && (int)(int8_t)(b[1] & 0xff) == MULTI_FLAG;
+                hit[l] = 0;
+                const int sid_ = (int)(int16_t)(b[0] & 0xffff), st_ = (int)(int8_t)((b[0] >> 16) & 0xff);
+                qsid[l] = sid_; qld[l] = (int)(int8_t)((b[0] >> 24) & 0xff);
+                qdiag[l] = (long long)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]) - (long long)(st_ * sid_ * K.seed_step);
+            }
+            if (wv::bcast(qcl, 0) > cl_last) break;                             // past the clusters of this chunk's MIN hits
+            // runs of equal (cluster, seed): the lane where this lane's run starts inside the chunk
+            wv::Lane<int> psd = sd, pcl = qcl, rs, seg;
+            wv::shr1(psd, -2); wv::shr1(pcl, -2);
+            WAVE_FOR(l) rs[l] = psd[l] != sd[l] || pcl[l] != qcl[l];
+            const unsigned long long rsm = wv::ballot(rs) | 1ull;
+            WAVE_FOR(l) seg[l] = 63 - __builtin_clzll(rsm & ((2ull << l) - 1));
+            const int last = H - 1 - base < 63 ? H - 1 - base : 63;
+            r.n_pairs += (long long)__builtin_popcountll(mset) * (last + 1);
+            const int s_last = wv::bcast(sd, last), c_last = wv::bcast(qcl, last), st_last = wv::bcast(seg, last);
+            unsigned long long next_carry = 0;
+            for (unsigned long long mm = mset; mm; mm &= mm - 1) {
+                const int j = __builtin_ctzll(mm);
+                const int ma0 = wv::bcast(Ma0, j), ma1 = wv::bcast(Ma1, j), ma3 = wv::bcast(Ma3, j), mb0 = wv::bcast(Mb0, j), mc = wv::bcast(mcl, j);
+                const int msid = (int)(int16_t)(mb0 & 0xffff), mst = (int)(int8_t)((mb0 >> 16) & 0xff), mld = (int)(int8_t)((mb0 >> 24) & 0xff);
+                const int xm = ma3 >> 14;
+                const long long mdiag = (long long)(((unsigned long long)(unsigned)ma1 << 32) | (unsigned)ma0) - (long long)(mst * msid * K.seed_step);
+                wv::Lane<int> q;
+                WAVE_FOR(l) {
+                    int v = 0;
+                    if (elig[l] && qcl[l] == mc && sd[l] != xm) {                 // same cluster: same contig and strand
+                        const bool q_first = sd[l] < xm;                     // the hit of the earlier seed is `pre`
+                        const int did = iabs(qsid[l] - msid);
+                        const long long D = q_first ? mdiag - qdiag[l] : qdiag[l] - mdiag;     // act - exp
+                        const int ld = mst > 0 ? (q_first ? qld[l] : mld) : (q_first ? mld : qld[l]);
+                        const long long dis = (long long)mst * D - (long long)ld;
+                        const int mat_dis = K.match_dis * (K.high_err ? did : 1);
+                        v = did * K.seed_step >= K.seed_len && dis <= mat_dis && dis >= -mat_dis;
+                    }
+                    q[l] = v;
+                }
+                const unsigned long long qb = wv::ballot(q);
+                const bool cj = (carry >> j) & 1, run_on = carry_seed == s_last && carry_cl == c_last;
+                if (!qb) { if (run_on && cj) next_carry |= 1ull << j; continue; }
+                WAVE_FOR(l) {
+                    if (q[l]) {
+                        const unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
+                        if (earlier == 0 && !(sd[l] == carry_seed && qcl[l] == carry_cl && cj)) hit[l] = 1;
+                    }
+                }
+                if ((qb >> st_last) != 0 || (run_on && cj)) next_carry |= 1ull << j;
+            }
+            WAVE_FOR(l) { if (hit[l]) gmk[idl[l]] = 1; }
+            carry = next_carry; carry_seed = s_last; carry_cl = c_last;
+        }
+    }
+    wv::sync();
+    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { const int k = b0 + l; if (k < H && gmk[k]) gd[k].dp_flag = MIN_FLAG; } }
+    wv::sync();
+    arena_release(r.cx.tmp, mark_);
+}
+
 // ---------------------------------------------------------------- the cluster in LDS
-// five arrays of HP_CL_CAP words: W0 position relative to the cluster's first hit | W1 slot:14 j:14 dp_flag:4 |
+// five arrays of `cap` words: W0 position relative to the cluster's first hit | W1 slot:14 j:14 dp_flag:4 |
 // W2 sid:15 len_dif:8 son_flag:5 match_flag:4 | W3 score:16 NM:16 | W4 (predecessor's index in the cluster + 1):16 node_n:16
 struct ClLds { HP_L int32_t *w0, *w1, *w2, *w3, *w4; };
-HP_INL ClLds cl_lds(HP_L int32_t *lds) { ClLds c; c.w0 = lds; c.w1 = lds + HP_CL_CAP; c.w2 = lds + 2 * HP_CL_CAP; c.w3 = lds + 3 * HP_CL_CAP; c.w4 = lds + 4 * HP_CL_CAP; return c; }
+HP_INL ClLds cl_lds(HP_L int32_t *lds, int cap) { ClLds c; c.w0 = lds; c.w1 = lds + cap; c.w2 = lds + 2 * cap; c.w3 = lds + 3 * cap; c.w4 = lds + 4 * cap; return c; }
 
 HP_INL NodeS cl_unpack(int w0, int w1, int w2, int w3, int chr, int strand)
 {
@@ -125,7 +233,7 @@ HP_INL NodeS cl_unpack(int w0, int w1, int w2, int w3, int chr, int strand)
     return q;
 }
 
-// One cluster [lo, lo + n) (ranks), n <= HP_CL_CAP: frag_dp_update (:701-764) for its MIN hits, out of LDS.
+// One cluster [lo, lo + n) (ranks), n <= lds_words / 5: frag_dp_update (:701-764) for its MIN hits, out of LDS.
 // Returns false when the cluster cannot be packed (span or NM beyond the field widths): the caller marks it big.
 HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
 {
@@ -134,7 +242,7 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk, *g_csrt = (const HP_G int32_t *)C.csrt;
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
-    const ClLds L = cl_lds(r.cx.lds);
+    const ClLds L = cl_lds(r.cx.lds, r.cx.lds_words / 5);
     const EdgeK K = edge_consts(r.cx.P);
     const int dp_flag = MIN_FLAG;
     // ---- load + pack

@@ -31,10 +31,14 @@ HP_INL void arena_release(Arena &a, size_t m) { a.top = m; }
 #define HP_LDS_Z_BYTES 5120
 #endif
 #define HP_LDS_WORDS (2 * HP_LDS_CELLS + HP_LDS_CELLS / 4 + HP_LDS_Z_BYTES / 4)
+#ifndef HP_CHAIN_LDS_WORDS
+#define HP_CHAIN_LDS_WORDS HP_LDS_WORDS      // LDS words of a wave of the chaining kernels (>= HP_SORT_BLOCK * 2 for the hit sort)
+#endif
 
 struct Ctx {
     const lamsa_hp_para *P;   // parameters (kernel argument copy)
-    HP_L int32_t *lds;        // HP_LDS_WORDS words of LDS owned by this wave
+    HP_L int32_t *lds;        // the LDS owned by this wave: at least HP_LDS_WORDS words (the DP rows of hp_ksw.h need those)
+    int lds_words;            // its size (the chaining kernels give a wave more: a cluster's node state lives there, hp_cluster.h)
     Arena tmp;                // scratch slab of this wave
     int status;               // ST_* bits for the unit (read / job) being processed
     long long n_cells;        // DP cells updated (accounting: GCUPS)

@@ -137,13 +137,13 @@ HP_INL void pers_bind(ReadCtx &r, const PhaseArgs &a, int rd)
 #define PH_TMID(k, v) do { } while (0)
 #endif
 
-HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds)
+HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_LDS_WORDS)
 {
 #ifdef HP_PROF
     long long ph_t_ = wv::clock();
 #endif
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, lds_words);
     pers_bind(r, a, rd);
     Ctx &cx = r.cx;
     const int H = r.H, c = H + 1;
@@ -153,7 +153,7 @@ HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32
     if (nm && sort_work) {
         int32_t *sidx = a.g_sidx + 2 * (r.hb + rd);
         { HP_T0(t_sort_);
-        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
+        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, lds_words / 2, a.sort_pb, a.sort_cb);
         HP_TADD(cx, 46, t_sort_); }
         arena_release(cx.tmp, sort_mark);
         aux_bind(r, nm);
@@ -233,13 +233,13 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
 }
 
 // ---------------------------------------------------------------- chain2: one read
-HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds)
+HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_LDS_WORDS)
 {
     RdMeta &M = a.meta[rd];
     if (M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
     PH_T0();
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, lds_words);
     pers_bind(r, a, rd);
     Ctx &cx = r.cx;
     const int H = r.H, c = H + 1;

@@ -236,7 +236,7 @@ static void parse_gem_hits(Batch &B, const Index &ix, const char *s, const char 
 void Batch::clear()
 {
     reads.clear(); read_off.assign(1, 0); read_seq.clear(); seed_all.clear(); last_len.clear(); seed_off.assign(1, 0); seed_id.clear(); hit_off.assign(1, 0);
-    h_pos.clear(); h_chr.clear(); h_strand.clear(); h_nm.clear(); h_len_dif.clear(); h_cig_off.clear(); h_cig_n.clear(); cig.clear();
+    h_pos.clear(); h_chr.clear(); h_strand.clear(); h_nm.clear(); h_len_dif.clear(); h_cig_off.clear(); h_cig_n.clear(); cig.clear(); cig8.clear(); cig_wide = false;
 }
 
 static const uint8_t *nt4_table()
@@ -352,7 +352,8 @@ static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
     B.read_off.resize(r0[np] + 1); B.seed_off.resize(r0[np] + 1); B.seed_all.resize(r0[np]); B.last_len.resize(r0[np]); B.read_seq.resize(b0[np]);
     B.seed_id.resize(s0[np]); B.hit_off.resize(s0[np] + 1);
     B.h_pos.resize(h0[np]); B.h_chr.resize(h0[np]); B.h_strand.resize(h0[np]); B.h_nm.resize(h0[np]); B.h_len_dif.resize(h0[np]); B.h_cig_n.resize(h0[np]); B.h_cig_off.resize(h0[np]);
-    B.cig.resize(c0[np]);
+    B.cig.resize(c0[np]); B.cig8.resize(c0[np]);
+    std::atomic<int> wide(0);
     B.read_off[0] = 0; B.seed_off[0] = 0; B.hit_off[0] = 0;
     auto copy_parts = [&](int i0, int i1) {
         for (int i = i0; i < i1; ++i) {
@@ -372,13 +373,20 @@ static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
             std::copy(p.h_cig_n.begin(), p.h_cig_n.end(), B.h_cig_n.begin() + (long)h0[i]);
             for (size_t k = 0; k < p.h_cig_off.size(); ++k) B.h_cig_off[h0[i] + k] = (int32_t)(p.h_cig_off[k] + (int64_t)c0[i]);
             std::copy(p.cig.begin(), p.cig.end(), B.cig.begin() + (long)c0[i]);
+            {   // the same CIGARs one byte per element (they lie back to back in hit order: no offsets needed on the way to the GPU)
+                int w = 0;
+                uint8_t *o8 = B.cig8.data() + c0[i];
+                for (size_t k = 0; k < p.cig.size(); ++k) { const int32_t x = p.cig[k]; w |= (x >> 4) > 63 || (x & 0xf) > 2; o8[k] = (uint8_t)(((x & 3) << 6) | ((x >> 4) & 63)); }
+                if (w) wide = 1;
+            }
             p.clear();
         }
     };
-    if (threads < 2 || h0[np] < 4096) { copy_parts(0, (int)np); return; }
+    if (threads < 2 || h0[np] < 4096) { copy_parts(0, (int)np); B.cig_wide = wide.load() != 0; return; }
     std::vector<std::thread> th;                             // one thread per part
     for (size_t i = 0; i < np; ++i) if (!parts[i].seed_all.empty()) th.emplace_back(copy_parts, (int)i, (int)i + 1);
     for (auto &x : th) x.join();
+    B.cig_wide = wide.load() != 0;
 }
 
 // ------------------------------------------------------------------ result stream -> records
@@ -615,9 +623,10 @@ int run_seeding(const Options &opt, const lamsa_hp_para &P)
 // filtering options) maps the file and uploads straight from the page cache -- no seeding, no text, no parse.  Native
 // byte order; the header pins the options that shape the arrays (-T, -l, -i, -p).
 namespace {
-const char HITS_MAGIC[8] = {'L', 'A', 'M', 'S', 'A', 'H', 'P', '1'};
+const char HITS_MAGIC[8] = {'L', 'A', 'M', 'S', 'A', 'H', 'P', '2'};
 struct HitsHeader { char magic[8]; int32_t read_type, seed_len, seed_step, per_aln_m; int64_t reserved[2]; };
-struct HitsChunkHeader { int64_t n_reads, n_bases, n_slots, n_hits, n_cig, bytes; };      // bytes: of the arrays that follow (each padded to 64)
+struct HitsChunkHeader { int64_t n_reads, n_bases, n_slots, n_hits, n_cig, bytes, cig_elem; };   // bytes: of the arrays that follow (each padded to 64);
+                                                                                              // cig_elem 1: cig8, no offsets; 4: cig words + 32-bit offsets
 inline size_t pad64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct HitsWriter {
@@ -638,11 +647,13 @@ struct HitsWriter {
     }
     bool write(const lamsa::Batch &B) {
         const size_t n = B.reads.size(), nb = B.read_seq.size(), ns = B.seed_id.size(), nh = B.h_pos.size(), nc = B.cig.size();
-        HitsChunkHeader c; c.n_reads = (int64_t)n; c.n_bases = (int64_t)nb; c.n_slots = (int64_t)ns; c.n_hits = (int64_t)nh; c.n_cig = (int64_t)nc;
-        c.bytes = (int64_t)(pad64(8 * (n + 1)) * 2 + pad64(nb) + pad64(4 * n) * 2 + pad64(4 * ns) + pad64(8 * (ns + 1)) + pad64(8 * nh) + pad64(4 * nh) * 2 + pad64(nh) * 2 + pad64(2 * nh) * 2 + pad64(4 * nc));
+        HitsChunkHeader c; c.n_reads = (int64_t)n; c.n_bases = (int64_t)nb; c.n_slots = (int64_t)ns; c.n_hits = (int64_t)nh; c.n_cig = (int64_t)nc; c.cig_elem = B.cig_wide ? 4 : 1;
+        c.bytes = (int64_t)(pad64(8 * (n + 1)) * 2 + pad64(nb) + pad64(4 * n) * 2 + pad64(4 * ns) + pad64(8 * (ns + 1)) + pad64(8 * nh) + pad64(4 * nh) + pad64(nh) * 2 + pad64(2 * nh) * 2 +
+                            (B.cig_wide ? pad64(4 * nh) + pad64(4 * nc) : pad64(nc)));
         if (fwrite(&c, sizeof c, 1, fp) != 1) return false;
         return put(B.read_off, n + 1) && put(B.read_seq, nb) && put(B.seed_all, n) && put(B.last_len, n) && put(B.seed_off, n + 1) && put(B.seed_id, ns) && put(B.hit_off, ns + 1) &&
-               put(B.h_pos, nh) && put(B.h_chr, nh) && put(B.h_strand, nh) && put(B.h_nm, nh) && put(B.h_len_dif, nh) && put(B.h_cig_off, nh) && put(B.h_cig_n, nh) && put(B.cig, nc);
+               put(B.h_pos, nh) && put(B.h_chr, nh) && put(B.h_strand, nh) && put(B.h_nm, nh) && put(B.h_len_dif, nh) && put(B.h_cig_n, nh) &&
+               (B.cig_wide ? put(B.h_cig_off, nh) && put(B.cig, nc) : put(B.cig8, nc));
     }
     void close() { if (fp) fclose(fp); fp = nullptr; }
 };
@@ -726,7 +737,9 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             hb.read_off = (const int64_t *)take(8 * (n + 1)); hb.read_seq = (const uint8_t *)take(nb); hb.seed_all = (const int32_t *)take(4 * n); hb.last_len = (const int32_t *)take(4 * n);
             hb.seed_off = (const int64_t *)take(8 * (n + 1)); hb.seed_id = (const int32_t *)take(4 * ns); hb.hit_off = (const int64_t *)take(8 * (ns + 1));
             hb.h_pos = (const int64_t *)take(8 * nh); hb.h_chr = (const int32_t *)take(4 * nh); hb.h_strand = (const int8_t *)take(nh); hb.h_nm = (const int16_t *)take(2 * nh);
-            hb.h_len_dif = (const int16_t *)take(2 * nh); hb.h_cig_off = (const int32_t *)take(4 * nh); hb.h_cig_n = (const uint8_t *)take(nh); hb.cig = (const int32_t *)take(4 * nc);
+            hb.h_len_dif = (const int16_t *)take(2 * nh); hb.h_cig_n = (const uint8_t *)take(nh);
+            if (ch.cig_elem == 4) { hb.h_cig_off = (const int32_t *)take(4 * nh); hb.cig = (const int32_t *)take(4 * nc); hb.cig8 = nullptr; }
+            else { hb.h_cig_off = nullptr; hb.cig = nullptr; hb.cig8 = (const uint8_t *)take(nc); }
             if ((size_t)(a - (hitsf.p + hitsf.pos + sizeof ch)) != (size_t)ch.bytes) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
             hitsf.pos += sizeof ch + (size_t)ch.bytes;
             for (size_t r = 0; r < n; ++r) {
@@ -779,11 +792,14 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         else {
         hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
         hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
-        hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_off = B.h_cig_off.data(); hb.h_cig_n = B.h_cig_n.data(); hb.cig = B.cig.data(); hb.n_cig = (int64_t)B.cig.size();
+        hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_n = B.h_cig_n.data(); hb.n_cig = (int64_t)B.cig.size();
+        if (B.cig_wide) { hb.h_cig_off = B.h_cig_off.data(); hb.cig = B.cig.data(); hb.cig8 = nullptr; }
+        else { hb.h_cig_off = nullptr; hb.cig = nullptr; hb.cig8 = B.cig8.data(); }                 // compact form: a quarter of the CIGAR bytes, no offsets
         static const int32_t zero32 = 0; static const uint8_t zero8 = 0; static const int64_t zero64 = 0; static const int16_t zero16 = 0; static const int8_t zeroi8 = 0;
         if (!hb.seed_id) hb.seed_id = &zero32;
-        if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_off = &zero32; hb.h_cig_n = &zero8; }
-        if (!hb.cig) hb.cig = &zero32;
+        if (!hb.h_pos) { hb.h_pos = &zero64; hb.h_chr = &zero32; hb.h_strand = &zeroi8; hb.h_nm = &zero16; hb.h_len_dif = &zero16; hb.h_cig_n = &zero8; }
+        if (B.cig_wide && !hb.cig) hb.cig = &zero32;
+        if (!B.cig_wide && !hb.cig8) hb.cig8 = &zero8;
         if (!hb.read_seq) hb.read_seq = &zero8;
         }
         const double t0 = now_s();

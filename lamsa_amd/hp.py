@@ -45,7 +45,7 @@ class HpBatch(C.Structure):
     """struct lamsa_hp_batch"""
     _fields_ = [("n_reads", C.c_int32)] + [(n, C.c_void_p) for n in (
         "read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
-        "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig")] + [("n_cig", C.c_int64)]
+        "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig")] + [("n_cig", C.c_int64), ("cig8", C.c_void_p)]
 
 
 class HpResult(C.Structure):
@@ -201,9 +201,13 @@ class LamsaHp:
         b.n_reads = batch.n_reads
         self._keep_batch = []
         for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
-                     "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
-            a = np.ascontiguousarray(getattr(batch, name)); self._keep_batch.append(a); setattr(b, name, a.ctypes.data)
-        b.n_cig = len(batch.cig)
+                     "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig", "cig8"):
+            v = getattr(batch, name, None)
+            if v is None:                                   # optional: h_cig_off (CIGARs back to back), cig / cig8 (one of them)
+                setattr(b, name, None)
+                continue
+            a = np.ascontiguousarray(v); self._keep_batch.append(a); setattr(b, name, a.ctypes.data)
+        b.n_cig = len(batch.cig8) if getattr(batch, "cig8", None) is not None else len(batch.cig)
         return b
 
     def _result(self, R, n):
@@ -298,6 +302,33 @@ class LamsaHp:
         return self._result(R, n)
 
 
+def compact_batch(batch):
+    """The compact form of the boundary for a batch whose seed CIGARs lie back to back in hit order: one byte per CIGAR
+    element (cig8) and no offsets at all (h_cig_off = NULL) -- a quarter of the CIGAR bytes and 4 bytes per hit less over
+    PCIe, and no 2^31 limit on the elements of a batch.  Raises when the batch is not laid out that way or an element is
+    longer than 63."""
+    nh = int(batch.hit_off[-1]) if len(batch.hit_off) else 0
+    cn = np.asarray(batch.h_cig_n[:nh], np.int64)
+    n_cig = int(cn.sum())
+    # (with more than 2^31-1 elements the 32-bit offsets of the word form cannot say anything any more)
+    if nh and n_cig <= 0x7fffffff and not np.array_equal(np.asarray(batch.h_cig_off[:nh], np.int64), np.concatenate([[0], np.cumsum(cn)[:-1]])):
+        raise ValueError("seed CIGARs are not back to back in hit order")
+    w = np.asarray(batch.cig[:n_cig])
+    if n_cig and (int((w >> 4).max()) > 63 or int((w & 0xf).max()) > 2):
+        raise ValueError("a seed CIGAR element does not fit one byte")
+
+    class Compact:
+        pass
+    out = Compact()
+    for k, v in vars(batch).items():
+        setattr(out, k, v)
+    out.h_cig_off = None; out.cig = None
+    out.cig8 = (((w & 0xf) << 6) | (w >> 4)).astype(np.uint8) if n_cig else np.zeros(4, np.uint8)
+    if n_cig == 0:
+        out.cig8 = out.cig8[:0]
+    return out
+
+
 def pinned_batch(batch):
     """Copy of `batch` (any object with the lamsa_hp_batch arrays) whose arrays live in page-locked host memory
     (lamsa_hp_host_alloc): uploads from it run at the PCIe rate.  Keep the returned object alive while it is in use;
@@ -308,7 +339,10 @@ def pinned_batch(batch):
         pass
     out = Pinned(); out._ptrs = []; out.n_reads = batch.n_reads
     for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
-                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig", "cig8"):
+        if getattr(batch, name, None) is None:
+            setattr(out, name, None)
+            continue
         a = np.ascontiguousarray(getattr(batch, name))
         p = L.lamsa_hp_host_alloc(max(a.nbytes, 1))
         if not p:

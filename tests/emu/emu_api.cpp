@@ -5,7 +5,7 @@
 #include <string.h>
 #include <vector>
 int g_emu_cl_cap = 1 << 30;            // tests: clusters larger than this take the HBM path of the main chaining pass (hp_cluster.h)
-#define HP_CL_CAP_RT (g_emu_cl_cap < HP_CL_CAP ? g_emu_cl_cap : HP_CL_CAP)
+#define HP_CL_CAP_RT(cap) (g_emu_cl_cap < (cap) ? g_emu_cl_cap : (cap))
 #include "hp_dp_batch.h"
 
 using namespace hp;
@@ -77,7 +77,7 @@ extern "C" int64_t emu_sort_check(int n_reads, const int64_t *seed_off, const in
 // 1 (default): scale-1 batches take the phased path of hp_phase.h, like the product's main pass; 0: the one-kernel path
 static int g_emu_phased = 1, g_emu_unit_cap = 0;
 extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
-extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : 1 << 30; }
+extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
 
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,
@@ -88,7 +88,12 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.ref.pac = ref->pac; a.ref.l_pac = ref->l_pac; a.ref.n_seqs = ref->n_seqs; a.ref.seq_off = ref->seq_offset; a.ref.seq_len = ref->seq_len;
     a.in.n_reads = B->n_reads; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
     a.in.seed_off = B->seed_off; a.in.seed_id = B->seed_id; a.in.hit_off = B->hit_off; a.in.h_pos = B->h_pos; a.in.h_chr = B->h_chr;
-    a.in.h_cig_off = B->h_cig_off; a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig;
+    // the boundary's two CIGAR forms -> what the kernels read (words, 64-bit offsets), as the product does on the device
+    const int64_t n_hits_all = B->n_reads ? B->hit_off[B->seed_off[B->n_reads]] : 0;
+    std::vector<int64_t> off64((size_t)n_hits_all + 1, 0); std::vector<int32_t> words;
+    { int64_t run = 0; for (int64_t k = 0; k < n_hits_all; ++k) { off64[k] = B->h_cig_off ? (int64_t)B->h_cig_off[k] : run; run += B->h_cig_n[k]; } }
+    if (B->cig8) { words.resize((size_t)B->n_cig + 1); for (int64_t i = 0; i < B->n_cig; ++i) words[i] = ((B->cig8[i] & 63) << 4) | (B->cig8[i] >> 6); }
+    a.in.h_cig_off = off64.data(); a.in.h_nm = B->h_nm; a.in.h_len_dif = B->h_len_dif; a.in.h_strand = B->h_strand; a.in.h_cig_n = B->h_cig_n; a.in.cig = B->cig8 ? words.data() : B->cig;
     emu_sort_widths(a.in, B->n_reads, a.sort_pb, a.sort_cb);
     unsigned long long cursor = 0;
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;

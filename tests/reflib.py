@@ -346,7 +346,7 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     E = emu()
     E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap))
     n = batch.n_reads
-    hb = batch.c_hp_batch(HpBatch) if hasattr(batch, "c_hp_batch") else hp_batch_struct(batch, HpBatch)
+    hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
     cap = 4096 + 64 * n + 16 * int(batch.read_off[-1]) * scale
     stream = np.zeros(cap, np.int32); nw = C.c_int64(0)
@@ -360,7 +360,10 @@ def hp_batch_struct(batch, HpBatch):
     b = HpBatch()
     b.n_reads = batch.n_reads
     for name in ("read_off", "read_seq", "seed_all", "last_len", "seed_off", "seed_id", "hit_off", "h_pos", "h_chr", "h_strand",
-                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig"):
+                 "h_nm", "h_len_dif", "h_cig_off", "h_cig_n", "cig", "cig8"):
+        if getattr(batch, name, None) is None:              # the compact form of the boundary (lamsa_amd.hp.compact_batch)
+            setattr(b, name, None)
+            continue
         a = np.ascontiguousarray(getattr(batch, name)); setattr(batch, name, a); setattr(b, name, a.ctypes.data)
-    b.n_cig = len(batch.cig)
+    b.n_cig = len(batch.cig8) if getattr(batch, "cig8", None) is not None else len(batch.cig)
     return b

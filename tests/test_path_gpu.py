@@ -80,6 +80,29 @@ def test_hip_rejects_malformed_batches(tmp_path):
     h.close()
 
 
+def test_hip_compact_cigar_form(tmp_path):
+    """The compact boundary form (cig8: one byte per seed-CIGAR element, h_cig_off = NULL: offsets summed up on the device
+    from the lengths) gives the streams of the word form; a length table that does not add up is refused."""
+    from lamsa_amd import hp
+    ref, reads, args, _ = goldenlib.stage_scenario("c3_ont", str(tmp_path))
+    rt, over = goldenlib.para_from_args(args)
+    lp = reflib.lo_para(rt, **over)
+    B = reflib.Batch(ref, reads, lp)
+    want = reflib.oracle_streams(B, lp)
+    h = _handle(B, rt, over)
+    Bc = hp.compact_batch(B)
+    got, st = h.align_batch(Bc)
+    assert got == want and (st == 0).all()
+    Bp = hp.pinned_batch(Bc)
+    got, st = h.align_batch(Bp)
+    Bp.release()
+    assert got == want and (st == 0).all()
+    bad = hp.compact_batch(B); bad.cig8 = bad.cig8[:-3]
+    with pytest.raises(RuntimeError, match="add up"):
+        h.align_batch(bad)
+    h.close()
+
+
 def test_hip_rejects_a_megabase_read():
     """A read with more than 32767 seeds (1.2 Mbp at the 25-bp step) is refused with LAMSA_HP_EINVAL and a message: the
     device keeps seed ids in 16 bits, and wrapped ids would chain into wrong alignments with status 0."""
@@ -88,8 +111,8 @@ def test_hip_rejects_a_megabase_read():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import simbatch
     from lamsa_amd import hp
-    ref = simbatch.SimRef(4_000_000, n_contigs=2, seed=3, threads=4)
-    B = simbatch.SimBatch(ref, 1, 1_200_000, "ont2d", seed=5, threads=4)
+    ref = simbatch.SimRef(8_000_000, n_contigs=1, seed=3, threads=4)         # the simulator wants a contig of more than twice the read length
+    B = simbatch.SimBatch(ref, 1, 1_200_000, "ont2d", seed=5, threads=1)
     h = hp.LamsaHp(hp.make_para("ont2d"), ref=(ref.pac, ref.l_pac, ref.seq_off, ref.seq_len), device=0)
     with pytest.raises(RuntimeError, match="32767 seeds|16383 seeds"):
         h.align_batch(B)

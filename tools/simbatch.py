@@ -106,9 +106,9 @@ class SimBatch:
                 return np.zeros(4, dt)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), (cnt,)).copy()
         self.n_reads = n
-        if b.n_cig > 0x7fffffff:
-            L.sim_batch_free(bp)
-            raise ValueError("%d seed CIGAR words do not fit one batch (32-bit offsets): simulate fewer reads per batch" % b.n_cig)
+        # more than 2^31-1 seed CIGAR elements: h_cig_off (int32) wraps, such a batch goes through the boundary's compact form only
+        # (lamsa_amd.hp.compact_batch rebuilds the offsets from the lengths)
+        self.n_cig = int(b.n_cig)
         self.read_off = arr(b.read_off, n + 1, np.int64); self.read_seq = arr(b.read_seq, self.read_off[n], np.uint8)
         self.seed_all = arr(b.seed_all, n, np.int32); self.last_len = arr(b.last_len, n, np.int32)
         self.seed_off = arr(b.seed_off, n + 1, np.int64); self.seed_id = arr(b.seed_id, ns, np.int32); self.hit_off = arr(b.hit_off, ns + 1, np.int64)
