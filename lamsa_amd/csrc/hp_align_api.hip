@@ -87,6 +87,26 @@ __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const Phase
     }
     drain_stamp(a, 1 + 2 * round);
 }
+#ifndef HP_FILLDP_WAVES_PER_SIMD
+#define HP_FILLDP_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64, HP_FILLDP_WAVES_PER_SIMD) void k_filldp(const PhaseArgs *ap, int round)
+{
+    const PhaseArgs &a = *ap;
+    int n = 0;
+    for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
+    n = wv::uni(n);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[5 + round], 1);
+        g = wv::uni(g);
+        if (g >= n) break;
+        int b = 0;
+        while (b < PH_NBUCKET - 1 && g >= a.ctl->bucket_n[round][b]) { g -= a.ctl->bucket_n[round][b]; ++b; }
+        const int u = wv::uni(a.bucket_q[((size_t)round * PH_NBUCKET + b) * a.unit_cap + g]);
+        phase_filldp(a, round, u, blockIdx.x, (HP_L int32_t *)nullptr);
+    }
+}
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;
@@ -154,6 +174,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *src, int64_t 
 
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
+static const bool g_nolane = getenv("LAMSA_HP_NO_LANE_DP") != nullptr;  // diagnostics: skip the lane-per-job DP launches (the fill then runs every DP itself, one job per wave)
 static const bool g_mono = getenv("LAMSA_HP_ONE_KERNEL") != nullptr;  // diagnostics: the main pass through k_align_batch (the retry pass's kernel) instead of the phased launches
 
 struct HostBuf {                  // page-locked host memory, mapped into the device's address space
@@ -199,7 +220,7 @@ struct OutDev {
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
     DevBuf bin, misc, slab, pers, prof; OutDev out1;
-    hipEvent_t ep[4] = {nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass
+    hipEvent_t ep[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass (ep[4]: after the lane DP of round 1)
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
@@ -244,7 +265,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3]}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3], T.ep[4]}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
 }
@@ -428,23 +449,25 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     const int64_t n_hits = T.n_hits;
     size_t slab_per_wave = slab_bytes_for(h->para, T.max_L, T.max_H, 1);
     if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
-    int pc = 0, pf = 0;
+    int pc = 0, pf = 0, pd = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
-    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf;
-    int n_waves = std::max(w_chain, w_fill);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp, 64, 0) != hipSuccess || pd < 1) pd = 4;
+    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd;
+    int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves);
+    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves);
     // state between the launches (hp_phase.h): per-hit arrays indexed by global hit index + read index, the fragment and
     // line arenas, the fill units and their cost-class queues
     const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
     const int unit_cap = 8 * n + 1024;
-    const int64_t fl_cap = 2 * (int64_t)n_hits + 512 * (int64_t)n + 4096, line_cap = O.stream_cap + 64 * (int64_t)unit_cap;
+    const int64_t fl_cap = 4 * (int64_t)n_hits + 2048 * (int64_t)n + 4096, line_cap = O.stream_cap + 64 * (int64_t)unit_cap;
+    const int64_t job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + T.n_bases);        // CIGARs of the small DP jobs (~ 0.2 words per read base)
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
     const size_t o_args = place(sizeof(PhaseArgs)), o_ctl = place(sizeof(PhaseCtl)), o_meta = place(sizeof(RdMeta) * ((size_t)n + 1)), o_nd = place(sizeof(NodeS) * n_ent), o_ns = place(4 * n_ent),
                  o_sx = place(8 * n_ent), o_un = place(sizeof(UnitRec) * 2 * (size_t)unit_cap), o_bq = place(4 * 2 * (size_t)PH_NBUCKET * unit_cap),
-                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap);
+                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap), o_jb = place(4 * (size_t)job_cap);
     if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)Ln.pers.p;
     PhaseArgs a;
@@ -463,6 +486,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.g_nd = (NodeS *)(d + o_nd); a.g_nseed = (int32_t *)(d + o_ns); a.g_sidx = (int32_t *)(d + o_sx); a.meta = (RdMeta *)(d + o_meta);
     a.units = (UnitRec *)(d + o_un); a.unit_cap = unit_cap; a.bucket_q = (int32_t *)(d + o_bq);
     a.fl_base = (int32_t *)(d + o_fl); a.fl_cap = fl_cap; a.line_base = (int32_t *)(d + o_ln); a.line_cap = line_cap; a.ctl = (PhaseCtl *)(d + o_ctl);
+    a.job_base = (int32_t *)(d + o_jb); a.job_cap = job_cap;
     hipStream_t s = Ln.cs;
     HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemsetAsync(d + o_ctl, 0, (o_meta - o_ctl) + sizeof(RdMeta) * ((size_t)n + 1), s), LAMSA_HP_EKERNEL);      // counters + per-read state
@@ -471,10 +495,13 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
+    if (!g_nolane) hipLaunchKernelGGL(k_filldp, dim3(w_dp), dim3(64), 0, s, da, 0);
+    HIPCHK(h, hipEventRecord(Ln.ep[4], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
     HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
+    if (!g_nolane) hipLaunchKernelGGL(k_filldp, dim3(w_dp), dim3(64), 0, s, da, 1);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 1);
     HIPCHK(h, hipEventRecord(Ln.ep[3], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_publish, dim3(std::min(h->n_cu * 8, n)), dim3(64), 0, s, da);
@@ -571,6 +598,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
         const unsigned long long *dg = Ln.out1.h_diag(n);          // drain of the four long launches: first wave out -> last wave out (100 MHz ticks)
         for (int k = 0; k < 4; ++k) h->kernel_ms[7 + k] = dg[2 * k + 1] >= dg[2 * k] && dg[2 * k + 1] ? (float)((double)(dg[2 * k + 1] - dg[2 * k]) * 1e-5) : 0.f;
         h->kernel_ms[11] = (float)dg[8]; h->kernel_ms[12] = (float)dg[9];                // fill units of the two rounds
+        hipEventElapsedTime(&h->kernel_ms[13], Ln.ep[0], Ln.ep[4]);                         // of "fill1" (kernel_ms[3]): the lane-per-job DP launch
 #ifdef HP_PROF
         prof_report(T, (const long long *)Ln.prof.p, n);
 #endif

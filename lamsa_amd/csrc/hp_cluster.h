@@ -245,90 +245,121 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
     const ClLds L = cl_lds(r.cx.lds, r.cx.lds_words / 5);
     const EdgeK K = edge_consts(r.cx.P);
     const int dp_flag = MIN_FLAG;
-    // ---- load + pack
+    if ((long long)(r.seed_id[r.seed_out - 1] - r.seed_id[0] + 1) * K.seed_step > 0x3fffffffll) return false;     // 32-bit geometry below
+    // ---- load + pack; lane b of `bmin` keeps the smallest seed slot of block b (64 consecutive ranks)
     const NodeS first = node_load(ns + g_srt[lo]);
-    const int64_t pos0 = first.pos; const int chr = first.chr, strand = first.strand;
+    const int64_t pos0 = first.pos; const int strand = first.strand;
     int nm_sum = 0; int bad = 0;
+    wv::Lane<int> bmin;
+    WAVE_FOR(l) bmin[l] = 0x7fffffff;
     wv::sync();                                                    // whatever used this LDS before is done
     for (int i0 = 0; i0 < n; i0 += 64) {
-        wv::Lane<int> nml, badl;
+        wv::Lane<int> nml, badl, nsl;
         WAVE_FOR(l) {
             const int i = i0 + l;
-            int nmv = 0, bv = 0;
+            int nmv = 0, bv = 0, sv = -0x7fffffff;
             if (i < n) {
                 const int id = g_srt[lo + i];
                 const NodeS q = node_load(ns + id);
                 const int64_t rel = q.pos - pos0;
-                bv = rel < 0 || rel > 0x7fffffffll || q.score < -32768 || q.score > 32767 || q.NM < 0 || q.NM > 65535 || (q.slot_j & 16383) > 16383;
-                nmv = g_hnm[id];
+                bv = rel < 0 || rel > 0x7ffffff0ll || q.score < -30000 || q.score > 30000 || q.NM < 0 || q.NM > 65535 || q.sid < 0;
+                nmv = g_hnm[id]; sv = 0 - (q.slot_j >> 14);
                 L.w0[i] = (int)(unsigned)rel;
                 L.w1[i] = (int)(((unsigned)q.slot_j << 4) | ((unsigned)q.dp_flag & 15u));
                 L.w2[i] = (int)(((unsigned)(unsigned short)q.sid << 17) | (((unsigned)q.len_dif8 & 255u) << 9) | (((unsigned)q.son_flag & 31u) << 4) | ((unsigned)q.match_flag & 15u));
                 L.w3[i] = (int)(((unsigned)q.score << 16) | ((unsigned)q.NM & 0xffffu));
                 L.w4[i] = 1;                                       // from = START, node_n = 1 (fnode_set has just run for every hit)
             }
-            nml[l] = nmv; badl[l] = bv;
+            nml[l] = nmv; badl[l] = bv; nsl[l] = sv;
         }
         nm_sum += wv::reduce_sum(nml);
         if (wv::ballot(badl) != 0) bad = 1;
+        const int mn = 0 - wv::reduce_max(nsl);
+        WAVE_FOR(l) { if (l == (i0 >> 6)) bmin[l] = mn; }
     }
-    if (bad || nm_sum > 65535) return false;                       // a chain's NM is at most the sum over the cluster: 16 bits suffice
+    if (bad || nm_sum > 65535 || n > 64 * 64) return false;       // a chain's NM is at most the sum over the cluster: 16 bits suffice
     wv::sync();
-    // ---- targets in ascending hit order (C.csrt), 64 at a time: their places in the cluster
+    const int sp = strand, POSMAX = (1 << 28) - 1, NEG = -0x7fffffff;
+    // ---- targets in ascending hit order (C.csrt), 64 at a time: their places in the cluster and their records.  A target's
+    // record is still what was loaded when its turn comes: only later targets (higher hit index) can choose it as their
+    // predecessor and touch its son_flag.
     for (int o0 = 0; o0 < n; o0 += 64) {
-        wv::Lane<int> tloc;
-        WAVE_FOR(l) { const int o = o0 + l; tloc[l] = o < n ? g_rnk[g_csrt[lo + o]] - lo : 0; }
+        wv::Lane<int> tloc, T0, T1, T2, T3;
+        WAVE_FOR(l) {
+            const int o = o0 + l; const int tl = o < n ? g_rnk[g_csrt[lo + o]] - lo : 0;
+            tloc[l] = tl; T0[l] = L.w0[tl]; T1[l] = L.w1[tl]; T2[l] = L.w2[tl]; T3[l] = L.w3[tl];
+        }
         const int cnt = n - o0 < 64 ? n - o0 : 64;
         for (int q = 0; q < cnt; ++q) {
-            const int ct = wv::bcast(tloc, q);
-            const int t1 = wv::uni(L.w1[ct]);
+            const int t1 = wv::bcast(T1, q);
             if ((int)((unsigned)t1 << 28) >> 28 != dp_flag) continue;
-            ScanT S;
-            S.T = cl_unpack(wv::uni(L.w0[ct]), t1, wv::uni(L.w2[ct]), wv::uni(L.w3[ct]), chr, strand);
-            S.x = S.T.slot_j >> 14; S.t_NM = S.T.NM; S.tkey = chr * 2 + (strand > 0 ? 1 : 0); S.Rw = 0x7fffffffffffll;
-            if (S.x == 0) continue;                                // a hit of the first seed slot has no predecessor
-            wv::Lane<long long> key;
-            wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl;
-            WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; }
-            r.n_pairs += n;
+            const int x = (int)((unsigned)t1 >> 18);
+            if (x == 0) continue;                                  // a hit of the first seed slot has no predecessor
+            const int ct = wv::bcast(tloc, q), t0 = wv::bcast(T0, q), t2 = wv::bcast(T2, q), t3 = wv::bcast(T3, q);
+            const int tsid = (int)((unsigned)t2 >> 17), tld = (int)(int8_t)((t2 >> 9) & 0xff), t_score = t3 >> 16, t_NM = t3 & 0xffff;
+            wv::Lane<int> bhi, blo, bi, bf, negp, n_i, n_f, n_hi, okl;
+            WAVE_FOR(l) { bhi[l] = NEG; blo[l] = -1; bi[l] = 0; bf[l] = 0; negp[l] = NEG; n_i[l] = 0; n_f[l] = 0; n_hi[l] = 0; okl[l] = 0; }
             for (int i0 = 0; i0 < n; i0 += 64) {
+                if (wv::bcast(bmin, i0 >> 6) >= x) continue;       // no hit of an earlier seed in this block
+                r.n_pairs += n - i0 < 64 ? n - i0 : 64;
                 WAVE_FOR(l) {
                     const int i = i0 + l, ii = i < n ? i : 0;
-                    const NodeS Q = cl_unpack(L.w0[ii], L.w1[ii], L.w2[ii], L.w3[ii], chr, strand);
-                    int ow, oka = 0;
-                    scan_eval(K, S, Q, i, i < n, 0, dp_flag, key[l], bp[l], bf[l], negp[l], n_p[l], n_f[l], n_c[l], n_n[l], ow, oka);
-                    okl[l] |= oka;
+                    const int q0 = L.w0[ii], q1 = L.w1[ii], q2 = L.w2[ii], q3 = L.w3[ii];
+                    const int qslot = (int)((unsigned)q1 >> 18), qdpf = (int)((unsigned)q1 << 28) >> 28;
+                    const int dsid = tsid - (int)((unsigned)q2 >> 17);
+                    const int span = dsid * K.seed_step;
+                    const int qld = (int)(int8_t)((q2 >> 9) & 0xff);
+                    const int dis = sp * (t0 - q0) - span - (sp > 0 ? qld : tld);               // get_fseed_dis :607-619 for a predecessor of an earlier seed
+                    const int mat_dis = K.match_dis * (K.high_err ? dsid : 1);
+                    int flag = F_UNCONNECT;
+                    if (span >= K.seed_len) {
+                        if (dis <= mat_dis && dis >= -mat_dis) flag = dsid == 1 ? F_MATCH : (dsid <= K.mis3 ? F_MISMATCH : F_LONG_MISMATCH);
+                        else if (dis > mat_dis && dis < K.sv_len) flag = F_DELETE;
+                        else if ((dis < -mat_dis && dis >= 0 - (span - K.seed_len)) || (dis < -K.half_split && dis >= -K.sv_len)) flag = F_INSERT;
+                    }
+                    const int ok = (i < n) & (qslot < x) & (qdpf == dp_flag) & !((sp == 1) & (((q2 >> 4) & 31) <= F_MATCH_THD)) & (flag != F_UNCONNECT);
+                    const int pos = ((x - 1 - qslot) << 14) | ((q1 >> 4) & 16383);                  // scan order: seeds descending, hits ascending
+                    const int cand = (q3 >> 16) + 1 + score_table(flag);
+                    const int hi = ok ? (int)(((unsigned)cand << 16) | (unsigned)(65535 - ((q3 & 0xffff) + t_NM))) : NEG;   // score desc, then NM asc
+                    const int lo_ = POSMAX - pos;
+                    const bool better = hi > bhi[l] || (hi == bhi[l] && ok && lo_ > blo[l]);
+                    bhi[l] = better ? hi : bhi[l]; blo[l] = better ? lo_ : blo[l]; bi[l] = better ? i : bi[l]; bf[l] = better ? flag : bf[l];
+                    const int np = (ok & (sp == -1) & (flag <= F_MATCH_THD)) ? -pos : NEG;          // '-': first match precursor wins, :726-733
+                    const bool nb = np > negp[l];
+                    negp[l] = nb ? np : negp[l]; n_i[l] = nb ? i : n_i[l]; n_f[l] = nb ? flag : n_f[l]; n_hi[l] = nb ? hi : n_hi[l];
+                    okl[l] |= ok;
                 }
             }
             if (wv::ballot(okl) == 0) continue;                    // no connectable predecessor: the node keeps its state
-            int max_from = -1, max_score = S.T.score, max_NM = S.t_NM, max_flag = 0;
+            int max_from = -1, max_score = t_score, max_NM = t_NM, max_flag = 0;
             bool changed = false;
             const int npos = wv::reduce_max(negp);
-            if (npos != -0x7fffffff) {                             // '-' strand: the first match precursor in scan order, :726-733
+            if (npos != NEG) {
                 wv::Lane<int> w;
                 WAVE_FOR(l) w[l] = negp[l] == npos;
                 const int wl = __builtin_ctzll(wv::ballot(w));
-                max_from = wv::bcast(n_p, wl); max_flag = wv::bcast(n_f, wl); max_score = wv::bcast(n_c, wl); max_NM = wv::bcast(n_n, wl);
+                const int hi = wv::bcast(n_hi, wl);
+                max_from = wv::bcast(n_i, wl); max_flag = wv::bcast(n_f, wl); max_score = hi >> 16; max_NM = 65535 - (hi & 0xffff);
                 changed = true;
             } else {
-                const long long best_key = wv::reduce_max64(key);
-                if (best_key >= 0) {
-                    const int nm = 524287 - (int)((best_key >> 28) & 524287);
-                    const int cand = (int)(best_key >> 47) - 32768;
+                const int mh = wv::reduce_max(bhi);
+                if (mh != NEG) {
+                    const int cand = mh >> 16, nm = 65535 - (mh & 0xffff);
                     if (cand > max_score || (cand == max_score && nm < max_NM)) {
+                        wv::Lane<int> l2;
+                        WAVE_FOR(l) l2[l] = bhi[l] == mh ? blo[l] : -1;
+                        const int ml = wv::reduce_max(l2);
                         wv::Lane<int> w;
-                        WAVE_FOR(l) w[l] = key[l] == best_key;
+                        WAVE_FOR(l) w[l] = bhi[l] == mh && blo[l] == ml;
                         const int wl = __builtin_ctzll(wv::ballot(w));
-                        max_from = wv::bcast(bp, wl); max_flag = wv::bcast(bf, wl); max_score = cand; max_NM = nm;
+                        max_from = wv::bcast(bi, wl); max_flag = wv::bcast(bf, wl); max_score = cand; max_NM = nm;
                         changed = true;
                     }
                 }
             }
             if (changed) {                                         // :753-761; the LDS copy is the node state until the write-back
                 const int f2 = wv::uni(L.w2[max_from]), f4 = wv::uni(L.w4[max_from]);
-                wv::sync();
                 L.w2[max_from] = (f2 & ~(31 << 4)) | ((max_flag & 31) << 4);
-                const int t2 = wv::uni(L.w2[ct]);
                 L.w2[ct] = (t2 & ~15) | (max_flag & 15);
                 L.w3[ct] = (int)(((unsigned)max_score << 16) | ((unsigned)max_NM & 0xffffu));
                 L.w4[ct] = ((max_from + 1) << 16) | (((f4 & 0xffff) + 1) & 0xffff);

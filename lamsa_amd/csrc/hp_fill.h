@@ -184,6 +184,15 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
     for (i += step; i >= 0 && i < seed_n && ok; i += step) {
         const int s = seed[i];
         const size_t m2 = arena_mark(cx.tmp);
+        {   const int32_t *gt = F.gt ? F.gt + 4 * (F.fr_seed_off[frag] + i) : nullptr;
+            if (gt && gt[3] && F.jarena) {                                      // the gap's CIGAR was computed ahead (hp_lanedp.h)
+                const uint8_t *qp0; const int len1p = read_gap(r, last, s, &qp0);
+                ok = merge_cigar(r, fc, &ref_end, &re, chr, F.jarena + gt[0], gt[1], gt[2], len1p) &&
+                     merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len);
+                last = s;
+                continue;
+            }
+        }
         // get_ref_intv, :98
         const int64_t start = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
         int32_t len2 = (int32_t)(r.h_pos[s] - 1 - start);
@@ -224,6 +233,7 @@ HP_INL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
 // Geometry of the junction between two fragments (:424-470), computed once and handed to whichever branch applies.
 struct SplitGeo {
     const uint8_t *qp; int64_t at1_off, at2_off; int at1_ld, at1_chr, at2_chr, did, s_qlen, dis, match_dis;
+    const int32_t *jt; const int32_t *jarena;        // this junction's slot of FLines::jt (or nullptr) and the arena its offset refers to
 };
 
 // DEL / INS / DUP branches (:475-546): the structural-variant cases, rare on ordinary reads
@@ -295,6 +305,9 @@ HP_NOINL bool split_mismatch(ReadCtx &r, const SplitGeo &g, Rec &res)
     const lamsa_hp_para *P = cx.P;
     int s_tlen = g.s_qlen + g.dis;
     if (s_tlen < 0) { cx.status |= ST_REFEXIT; return false; }                 // ksw_extend_core exit(-1), ksw.c:672
+    if (g.jt && g.jt[3] && g.jarena) {                                          // its CIGAR was computed ahead (hp_lanedp.h)
+        return merge_cigar(r, res.cig, &res.refend, &res.readend, g.at1_chr, g.jarena + g.jt[0], g.jt[1], g.jt[2], g.s_qlen) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+    }
     const size_t mark = arena_mark(cx.tmp);
     int32_t tl = s_tlen;
     CigV sc;
@@ -328,6 +341,7 @@ HP_INL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &res)
     const int64_t exp = g.at1_off + g.at1_ld + (int64_t)(g.did * P->seed_step);
     g.dis = (int)(g.at2_off - exp);
     g.match_dis = P->match_dis * ((P->aln_mode & 2) ? g.did : 1);
+    g.jt = F.jt ? F.jt + 4 * (f1 < f2 ? f1 : f2) : nullptr; g.jarena = F.jarena;
     if (g.dis > g.match_dis || g.dis < -g.match_dis) return split_sv(r, g, res);
     if (g.s_qlen > 0) return split_mismatch(r, g, res);
     // Mismatch class with no read base between the seeds (neighbouring seeds overlap by design, so this is most

@@ -18,6 +18,7 @@
 // A read that overflows a buffer in any phase is re-run by the one-kernel path with larger buffers (hp_align_api.hip).
 #pragma once
 #include "hp_align.h"
+#include "hp_lanedp.h"
 
 namespace hp {
 
@@ -43,7 +44,7 @@ struct PhaseCtl {                // counters of one launch sequence, zeroed befo
     int32_t q_head[8];           // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish
     int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
     int32_t bucket_n[2][PH_NBUCKET];
-    unsigned long long fl_cursor, line_cursor;
+    unsigned long long fl_cursor, line_cursor, job_cursor;
     // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
     // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
     // draining, i.e. with idle wave slots
@@ -67,6 +68,7 @@ struct PhaseArgs {
     int32_t *bucket_q;                           // [2][PH_NBUCKET][unit_cap] unit indices by cost class, costliest class first
     int32_t *fl_base; int64_t fl_cap;            // fragment arena (words)
     int32_t *line_base; int64_t line_cap;        // line arena (words)
+    int32_t *job_base; int64_t job_cap;          // CIGARs of the lane-per-job DPs (words, < 2^31)
     PhaseCtl *ctl;
 };
 
@@ -184,6 +186,7 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
     FLines F;
     F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
     flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
+    F.jarena = a.job_base;
     const int cur_cap = 2 * r.L + 512;
     const int out_cap = 64 + 12 * r.L + PH_REG_WORDS * HP_REC_MAX;
     OutBuf o; o.n = 0; o.cap = out_cap;
@@ -229,6 +232,153 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
         } else cx.status |= ST_OVERFLOW;
     }
     PH_TADD(round == 0 ? 2 : 4);
+    meta_flag(a, rd, r);
+}
+
+
+// ---------------------------------------------------------------- fill, step 1: the small DP jobs of one line, one job per lane
+// (hp_lanedp.h).  Lists the line's junctions of the mismatch class with read bases in between (split_mapping, frag_check.c:547-559)
+// and the gaps between neighbouring seeds of its fragments (frag_extend, :360-400) with the geometry the fill would compute,
+// runs them 64 at a time and leaves the CIGARs in the job arena, their slots in FLines::jt / gt.
+struct LjRec { int32_t type, qoff, qlen, tlen, slot; int32_t pad; int64_t tk; };       // type 1: ksw_bi_extend(100, 100), 2: ksw_global2
+
+HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, HP_L int32_t *lds)
+{
+    UnitRec &U = a.units[(size_t)round * a.unit_cap + u];
+    const int rd = U.read, line = U.line;
+    RdMeta &M = a.meta[rd];
+    if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
+    ReadCtx r;
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    pers_bind(r, a, rd);
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    FLines F;
+    F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
+    flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
+    const int f0 = F.frag_off[line], nfr = F.frag_off[line + 1] - f0;
+    const int p0 = F.fr_seed_off[f0], np = F.fr_seed_off[f0 + nfr] - p0;       // the line's seeds in fr_seed
+    const int strand = r.h_strand[F.fr_seed[p0]];
+    const int n_cand = (nfr - 1) + np;
+    // scratch of this wave: the reverse complement (a '-' line aligns it, frag_check.c:922-926), the job list, per lane three
+    // CIGAR buffers, the lane-interleaved direction matrices
+    r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
+    LjRec *jobs = (LjRec *)arena_alloc(cx, sizeof(LjRec) * (size_t)(n_cand + 64));
+    cig_t *cbuf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * 3 * HP_LJ_CIG * 64);
+    uint8_t *zbuf = (uint8_t *)arena_alloc(cx, (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
+    if (!r.rc_read || !jobs || !cbuf || !zbuf) return;                         // no room: the fill computes everything itself
+    if (strand != 1) {
+        for (int b = 0; b < r.L; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < r.L) { const int c = r.read[r.L - 1 - i]; r.rc_read[i] = c < 4 ? 3 - c : 4; } } }
+        wv::sync();
+        r.rc_ready = true; r.cur_read = r.rc_read; r.flip = true;
+    }
+    // ---- list the jobs
+    int n_jobs = 0;
+    for (int c0 = 0; c0 < n_cand; c0 += 64) {
+        wv::Lane<int> ty, qo, ql, tl, sl; wv::Lane<long long> tk;
+        WAVE_FOR(l) {
+            const int c = c0 + l;
+            int type = 0, qoff = 0, qlen = 0, tlen = 0, slot = 0; long long k0 = 0;
+            if (c < nfr - 1) {                                                  // junction between fragments jf and jf + 1, split_mapping :416-470
+                const int jf = f0 + c;
+                const int f1 = strand == 1 ? jf + 1 : jf, f2 = strand == 1 ? jf : jf + 1;
+                const int32_t *sd1 = F.fr_seed + F.fr_seed_off[f1], *sd2 = F.fr_seed + F.fr_seed_off[f2];
+                const int n1 = F.fr_seed_off[f1 + 1] - F.fr_seed_off[f1], n2 = F.fr_seed_off[f2 + 1] - F.fr_seed_off[f2];
+                int s1, s2;
+                if (r.h_strand[sd1[0]] == 1) { s1 = sd1[0]; s2 = sd2[n2 - 1]; } else { s1 = sd1[n1 - 1]; s2 = sd2[0]; }
+                const int64_t at1_off = r.h_pos[s1], at2_off = r.h_pos[s2];
+                const int at1_ld = r.h_len_dif[s1], at1_chr = r.h_chr[s1];
+                const int id1 = sid(r, r.n_seed[s1]), did = sid(r, r.n_seed[s2]) - id1;
+                const int s_qlen = did * P->seed_step - P->seed_len;
+                const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
+                const int dis = (int)(at2_off - exp);
+                const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
+                if (s_qlen > 0 && s_qlen <= HP_LJ_QCAP && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
+                    const int64_t start0 = at1_off + P->seed_len + at1_ld - 1;
+                    const int32_t clen = r.ref.seq_len[at1_chr - 1];
+                    if (start0 <= clen && start0 >= 0) {                        // pac2fa_core, bntseq.c:469-474
+                        int tl_ = s_qlen + dis;
+                        if (start0 + tl_ > clen) tl_ = (int)(clen - start0);
+                        if (tl_ <= HP_LJ_TCAP) {
+                            type = 1; qlen = s_qlen; tlen = tl_; slot = jf; k0 = r.ref.seq_off[at1_chr - 1] + start0;
+                            qoff = (strand == 1 ? 0 : r.last_len) + id1 * P->seed_step - P->seed_inv;      // get_read_intv, :116
+                        }
+                    }
+                }
+            } else if (c < n_cand) {                                            // gap in front of the seed at position p, frag_extend :360-385
+                const int p = p0 + (c - (nfr - 1));
+                int lo = f0, hi = f0 + nfr;                                     // its fragment: the last one starting at or before p
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.fr_seed_off[mid] <= p) lo = mid; else hi = mid; }
+                const int fb = F.fr_seed_off[lo], fe = F.fr_seed_off[lo + 1], i = p - fb, seed_n = fe - fb;
+                const int ip = strand == 1 ? i + 1 : i - 1;                     // the seed walked before it
+                if (seed_n > 1 && ip >= 0 && ip < seed_n) {
+                    const int s = F.fr_seed[p], last = F.fr_seed[fb + ip];
+                    const int64_t start = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
+                    int len2 = (int)(r.h_pos[s] - 1 - start);
+                    bool ok = true;
+                    const int32_t clen = r.ref.seq_len[r.h_chr[last] - 1];
+                    if (len2 <= 0) len2 = 0;
+                    else if (start > clen || start < 0) ok = false;
+                    else if (start + len2 > clen) len2 = (int)(clen - start);
+                    const int idl = sid(r, r.n_seed[last]), ids = sid(r, r.n_seed[s]);
+                    const int qi = (strand == 1 ? 0 : r.last_len) + idl * P->seed_step - P->seed_inv, qe = (strand == 1 ? 0 : r.last_len) + (ids - 1) * P->seed_step;
+                    const int len1 = qe > qi ? qe - qi : 0;
+                    if (ok && len1 <= HP_LJ_QCAP && len2 <= HP_LJ_TCAP) {
+                        type = 2; qlen = len1; tlen = len2; slot = -1 - p; qoff = qi; k0 = r.ref.seq_off[r.h_chr[last] - 1] + start;
+                    }
+                }
+            }
+            ty[l] = type; qo[l] = qoff; ql[l] = qlen; tl[l] = tlen; sl[l] = slot; tk[l] = k0;
+        }
+        wv::Lane<int> has;
+        WAVE_FOR(l) has[l] = ty[l] != 0;
+        const unsigned long long m = wv::ballot(has);
+        WAVE_FOR(l) {
+            if (ty[l]) { LjRec &J = jobs[n_jobs + __builtin_popcountll(m & ((1ull << l) - 1))]; J.type = ty[l]; J.qoff = qo[l]; J.qlen = ql[l]; J.tlen = tl[l]; J.slot = sl[l]; J.pad = 0; J.tk = tk[l]; }
+        }
+        n_jobs += __builtin_popcountll(m);
+    }
+    wv::sync();
+    // ---- run them, 64 at a time
+    long long tb = 0, cells = 0;
+    for (int j0 = 0; j0 < n_jobs; j0 += 64) {
+        wv::Lane<int> nw, tbl, cel;
+        WAVE_FOR(l) {
+            nw[l] = 0; tbl[l] = 0; cel[l] = 0;
+            if (j0 + l < n_jobs) {
+                const LjRec R = jobs[j0 + l];
+                LaneJob J;
+                J.q = r.cur_read + R.qoff; J.qs = 1; J.qlen = R.qlen; J.pac = r.ref.pac; J.tk = R.tk; J.ts = 1; J.tlen = R.tlen; J.z = zbuf; J.zl = l; J.cells = 0;
+                LCig out, Lc, Rc;
+                out.c = cbuf + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
+                if (R.type == 1) lj_bi_extend(P, J, 100, 100, Lc, Rc, out);
+                else lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
+                nw[l] = out.n; tbl[l] = R.tlen; cel[l] = (int)J.cells;
+            }
+        }
+        // publish: one reservation in the job arena per group
+        wv::Lane<int> pre = nw;
+        wv::scan_add_excl(pre);
+        const int total = wv::reduce_sum(nw);
+        unsigned long long base = 0;
+        if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)total);
+        base = (unsigned long long)wv::uni64((long long)base);
+        if ((int64_t)(base + (unsigned long long)total) > a.job_cap) break;    // arena full: the rest stays with the fill
+        WAVE_FOR(l) {
+            if (j0 + l < n_jobs) {
+                const LjRec R = jobs[j0 + l];
+                const cig_t *src = cbuf + (size_t)l * 3 * HP_LJ_CIG;
+                int32_t *dst = a.job_base + base + pre[l];
+                for (int k = 0; k < nw[l]; ++k) dst[k] = src[k];
+                int32_t *slot = R.slot >= 0 ? F.jt + 4 * R.slot : F.gt + 4 * (-1 - R.slot);
+                slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = R.tlen; slot[3] = 1;
+            }
+        }
+        tb += wv::reduce_sum(tbl); cells += wv::reduce_sum(cel);
+    }
+    wv::sync();
+    r.t_bases = tb; cx.n_cells = cells;
+    r.flip = false;
     meta_flag(a, rd, r);
 }
 

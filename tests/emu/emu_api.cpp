@@ -75,7 +75,10 @@ extern "C" int64_t emu_sort_check(int n_reads, const int64_t *seed_off, const in
 }
 
 // 1 (default): scale-1 batches take the phased path of hp_phase.h, like the product's main pass; 0: the one-kernel path
-static int g_emu_phased = 1, g_emu_unit_cap = 0;
+static int g_emu_phased = 1, g_emu_unit_cap = 0, g_emu_lane_dp = 1;
+static long long g_emu_job_words = 0;
+extern "C" long long emu_last_job_words() { return g_emu_job_words; }      // CIGAR words the lane-per-job DP left for the fill in the last batch
+extern "C" void emu_set_lane_dp(int on) { g_emu_lane_dp = on; }           // 0: the fill runs every DP itself (one job per wave)
 extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
@@ -112,12 +115,18 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
         p.unit_cap = g_emu_unit_cap > 0 ? g_emu_unit_cap : 8 * n + 64;
         std::vector<UnitRec> units(2 * (size_t)p.unit_cap); std::vector<int32_t> bq(2 * (size_t)PH_NBUCKET * p.unit_cap);
         p.fl_cap = 16 * (n_hits + n) + 1024 * (int64_t)n + 1024; p.line_cap = stream_cap + 16 * 2 * (int64_t)p.unit_cap;
-        std::vector<int32_t> fl((size_t)p.fl_cap), lines((size_t)p.line_cap);
+        p.fl_cap = 32 * (n_hits + n) + 4096 * (int64_t)n + 4096;
+        p.job_cap = g_emu_lane_dp ? 4096 + 1024 * (int64_t)n + 8 * n_bases : 0;
+        std::vector<int32_t> fl((size_t)p.fl_cap), lines((size_t)p.line_cap), jobsv((size_t)p.job_cap + 4);
+        p.job_base = jobsv.data();
         PhaseCtl ctl; memset(&ctl, 0, sizeof ctl);
         p.g_nd = nd.data(); p.g_nseed = nseed.data(); p.g_sidx = sidx.data(); p.meta = meta.data(); p.units = units.data(); p.bucket_q = bq.data();
         p.fl_base = fl.data(); p.line_base = lines.data(); p.ctl = &ctl;
         (void)n_bases;
         auto fill_all = [&](int round) {
+            if (g_emu_lane_dp)
+                for (int b = 0; b < PH_NBUCKET; ++b)
+                    for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filldp(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
             for (int b = 0; b < PH_NBUCKET; ++b)
                 for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
         };
@@ -126,11 +135,41 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
         for (int r = 0; r < n; ++r) phase_chain2(p, r, 0, lds);
         fill_all(1);
         for (int r = 0; r < n; ++r) phase_publish(p, r);
+        g_emu_job_words = (long long)ctl.job_cursor;
         *n_words = (int64_t)cursor;
         return 0;
     }
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
     for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0, lds);
     *n_words = (int64_t)cursor;
+    return 0;
+}
+
+// ---------------------------------------------------------------- the lane-per-job DP routines (hp_lanedp.h) on explicit jobs
+// kind 0: ksw_global2(w), 1: ksw_extend_core(w, h0), 2: ksw_bi_extend(h0, h0).  Targets are packed 2 bits per base first, as the
+// lanes read them from the reference; 64 jobs per group like the kernel.
+extern "C" int emu_lane_dp(const lamsa_hp_para *P, int n, const uint8_t *seq, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,
+                           int kind, int w, int h0, int32_t *score, int32_t *qle, int32_t *tle, int32_t *cig_n, int32_t *cig /* n * HP_LJ_CIG words */)
+{
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += tlen[i];
+    std::vector<uint8_t> pac((size_t)tot / 4 + 8, 0); std::vector<int64_t> tk((size_t)n + 1, 0);
+    { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } }
+    std::vector<uint8_t> z((size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
+    std::vector<cig_t> cb((size_t)3 * HP_LJ_CIG * 64);
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        for (int l = 0; l < 64 && j0 + l < n; ++l) {
+            const int i = j0 + l;
+            if (qlen[i] > HP_LJ_QCAP || tlen[i] > HP_LJ_TCAP) return -1;
+            LaneJob J; J.q = seq + q_off[i]; J.qs = 1; J.qlen = qlen[i]; J.pac = pac.data(); J.tk = tk[i]; J.ts = 1; J.tlen = tlen[i]; J.z = z.data(); J.zl = l; J.cells = 0;
+            LCig out, Lc, Rc; out.c = cb.data() + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
+            int a = 0, b = 0;
+            if (kind == 0) score[i] = lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, w, &out);
+            else if (kind == 1) score[i] = lj_extend(P, J, w, h0, &a, &b, &out);
+            else score[i] = lj_bi_extend(P, J, h0, h0, Lc, Rc, out);
+            qle[i] = a; tle[i] = b; cig_n[i] = out.n;
+            memcpy(cig + (size_t)i * HP_LJ_CIG, out.c, sizeof(cig_t) * (size_t)out.n);
+        }
+    }
     return 0;
 }

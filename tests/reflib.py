@@ -338,13 +338,28 @@ def oracle_streams(batch, P, n_threads=4):
     return split_streams(stream, off[:n], ln[:n])
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0):
+def emu_lane_dp(jobs, hp_para, kind, w, h0):
+    """DP jobs through the lane-per-job routines of hp_lanedp.h (what k_filldp runs), CPU lane emulation."""
+    from lamsa_amd.hp import pack_jobs
+    E = emu()
+    n = len(jobs)
+    seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
+    CIG = 96 + 192 + 8
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(n * CIG + 4, np.int32)
+    p = lambda a: a.ctypes.data
+    E.emu_lane_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5
+    rc = E.emu_lane_dp(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), int(kind), int(w), int(h0), p(score), p(qle), p(tle), p(cn), p(cig))
+    assert rc == 0
+    return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
+
+
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True):
     """Per-read result streams from the device sources compiled with the CPU lane emulation.
     phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
     cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h)."""
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
-    E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap))
+    E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap)); E.emu_set_lane_dp(1 if lane_dp else 0)
     n = batch.n_reads
     hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)

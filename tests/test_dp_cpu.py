@@ -127,3 +127,21 @@ def test_cabi_library_exports_declared_symbols():
         a, b = hp.make_para(rt), reflib.lo_para(rt)
         for name, _ in hp.HpPara._fields_:
             assert getattr(a, name) == getattr(b, name), (rt, name)
+
+
+@pytest.mark.parametrize("preset", ["default", "pacbio", "ont2d"])
+def test_lane_per_job_dp_matches_oracle(preset):
+    """hp_lanedp.h (one small DP job per lane, what the k_filldp launch runs for the junctions of a line) against the oracle:
+    ksw_global2, ksw_extend_core and ksw_bi_extend on ragged jobs up to the lane buffers' capacity, targets read 2 bits per base."""
+    from lamsa_amd.hp import HpPara
+    lp = reflib.lo_para(preset)
+    P = HpPara()
+    for n, _ in HpPara._fields_:
+        setattr(P, n, getattr(lp, n))
+    jobs = [(q, t) for q, t in dpjobs.make_jobs(4242, 700, 90, (0.05, 0.05, 0.05)) if len(q) <= 96 and len(t) <= 192 and (len(t) == 0 or t.max() < 4)]
+    assert len(jobs) > 400
+    for kind, w, h0 in ((0, lp.band_w, 0), (0, 7, 0), (1, lp.band_w, 50), (1, 12, 8), (2, 0, 100), (2, 0, 10)):
+        want = reflib.oracle_dp(jobs, lp, kind, w, max(h0, 1))
+        got = reflib.emu_lane_dp(jobs, P, kind, w, max(h0, 1))
+        bad = goldenlib.same_dp(want, got, kind)
+        assert bad == [], (kind, w, h0, bad[:5])
