@@ -184,7 +184,7 @@ def main():
 
         def note():
             ms.append(h.last_kernel_ms(0) + h.last_kernel_ms(1))
-            phase_ms.append([h.last_kernel_ms(i) for i in range(1, 13)])
+            phase_ms.append([h.last_kernel_ms(i) for i in range(1, 14)])
         if a.sequential or k < 2:
             for _ in range(k):
                 raw = h.run_uploaded(fetch=True, raw=True)      # kernels + download of the result streams into host memory
@@ -280,7 +280,7 @@ def main():
             "pcie_inclusive_reads_per_s": None if a.bare else round(a.reads / t_pcie, 2),
             "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": r_stream, "pinned_host_arrays": r_stream_pinned, "chunks": a.stream_chunks},
             "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
-            "launch_ms": dict(zip(["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2"],
+            "launch_ms": dict(zip(["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2", "lane_dp1_within_fill1"],
                                   [round(float(x), 3) for x in np.mean(np.array(phase_ms), axis=0)])),
             "roofline": roof, "cpu_baseline": cpu,
         }

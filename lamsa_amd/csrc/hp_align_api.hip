@@ -88,9 +88,9 @@ __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const Phase
     drain_stamp(a, 1 + 2 * round);
 }
 #ifndef HP_FILLDP_WAVES_PER_SIMD
-#define HP_FILLDP_WAVES_PER_SIMD 4
+#define HP_FILLDP_WAVES_PER_SIMD 2
 #endif
-__global__ __launch_bounds__(64, HP_FILLDP_WAVES_PER_SIMD) void k_filldp(const PhaseArgs *ap, int round)
+__global__ __launch_bounds__(64, 4) void k_filllist(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
     int n = 0;
@@ -98,14 +98,42 @@ __global__ __launch_bounds__(64, HP_FILLDP_WAVES_PER_SIMD) void k_filldp(const P
     n = wv::uni(n);
     for (;;) {
         int g = 0;
-        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[5 + round], 1);
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[5], 1);
         g = wv::uni(g);
         if (g >= n) break;
         int b = 0;
         while (b < PH_NBUCKET - 1 && g >= a.ctl->bucket_n[round][b]) { g -= a.ctl->bucket_n[round][b]; ++b; }
         const int u = wv::uni(a.bucket_q[((size_t)round * PH_NBUCKET + b) * a.unit_cap + g]);
-        phase_filldp(a, round, u, blockIdx.x, (HP_L int32_t *)nullptr);
+        phase_filllist(a, round, u, blockIdx.x, (HP_L int32_t *)nullptr);
     }
+}
+// the lane-per-job DP over the queues [b0, b1) of the round: the short jobs with HP_LJ_QSMALL-cell rows (a third of the LDS,
+// three times the waves), the long ones with HP_LJ_QCAP-cell rows
+template <int QCAP, int B0, int B1, int HEAD>
+__device__ __forceinline__ void filldp_loop(const PhaseArgs &a, int round, HP_L int32_t *lds)
+{
+    int n = 0;
+    for (int b = B0; b < B1; ++b) n += (a.ctl->lj_bucket_n[round][b] + 63) >> 6;
+    n = wv::uni(n);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[HEAD], 1);
+        g = wv::uni(g);
+        if (g >= n) break;
+        int b = B0;
+        for (; b < B1 - 1; ++b) { const int gb = (a.ctl->lj_bucket_n[round][b] + 63) >> 6; if (g < gb) break; g -= gb; }
+        phase_filldp(a, round, b, g * 64, blockIdx.x, lds, QCAP);
+    }
+}
+__global__ __launch_bounds__(64, 2) void k_filldp_small(const PhaseArgs *ap, int round)
+{
+    __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QSMALL)];
+    filldp_loop<HP_LJ_QSMALL, LJ_NBIG, LJ_NBUCKET, 6>(*ap, round, (HP_L int32_t *)lds);
+}
+__global__ __launch_bounds__(64, 1) void k_filldp_big(const PhaseArgs *ap, int round)
+{
+    __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+    filldp_loop<HP_LJ_QCAP, 0, LJ_NBIG, 7>(*ap, round, (HP_L int32_t *)lds);
 }
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
 {
@@ -452,22 +480,26 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     int pc = 0, pf = 0, pd = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp, 64, 0) != hipSuccess || pd < 1) pd = 4;
-    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd;
+    int pdb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pdb, k_filldp_big, 64, 0) != hipSuccess || pdb < 1) pdb = 2;
+    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb;
     int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
-    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves);
+    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves);
     // state between the launches (hp_phase.h): per-hit arrays indexed by global hit index + read index, the fragment and
     // line arenas, the fill units and their cost-class queues
     const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
     const int unit_cap = 8 * n + 1024;
     const int64_t fl_cap = 4 * (int64_t)n_hits + 2048 * (int64_t)n + 4096, line_cap = O.stream_cap + 64 * (int64_t)unit_cap;
     const int64_t job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + T.n_bases);        // CIGARs of the small DP jobs (~ 0.2 words per read base)
+    const int lj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 16 * (int64_t)n + T.n_bases / 100);  // small DP jobs of a round (~ one per 150 read bases)
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
     const size_t o_args = place(sizeof(PhaseArgs)), o_ctl = place(sizeof(PhaseCtl)), o_meta = place(sizeof(RdMeta) * ((size_t)n + 1)), o_nd = place(sizeof(NodeS) * n_ent), o_ns = place(4 * n_ent),
                  o_sx = place(8 * n_ent), o_un = place(sizeof(UnitRec) * 2 * (size_t)unit_cap), o_bq = place(4 * 2 * (size_t)PH_NBUCKET * unit_cap),
-                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap), o_jb = place(4 * (size_t)job_cap);
+                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap), o_jb = place(4 * (size_t)job_cap),
+                 o_lj = place(sizeof(LjRec) * (size_t)lj_cap), o_lq = place(4 * (size_t)LJ_NBUCKET * lj_cap);
     if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)Ln.pers.p;
     PhaseArgs a;
@@ -487,6 +519,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.units = (UnitRec *)(d + o_un); a.unit_cap = unit_cap; a.bucket_q = (int32_t *)(d + o_bq);
     a.fl_base = (int32_t *)(d + o_fl); a.fl_cap = fl_cap; a.line_base = (int32_t *)(d + o_ln); a.line_cap = line_cap; a.ctl = (PhaseCtl *)(d + o_ctl);
     a.job_base = (int32_t *)(d + o_jb); a.job_cap = job_cap;
+    a.ljobs = (LjRec *)(d + o_lj); a.lj_bucket = (int32_t *)(d + o_lq); a.lj_cap = lj_cap;
     hipStream_t s = Ln.cs;
     HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemsetAsync(d + o_ctl, 0, (o_meta - o_ctl) + sizeof(RdMeta) * ((size_t)n + 1), s), LAMSA_HP_EKERNEL);      // counters + per-read state
@@ -495,13 +528,16 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
-    if (!g_nolane) hipLaunchKernelGGL(k_filldp, dim3(w_dp), dim3(64), 0, s, da, 0);
+    if (!g_nolane) { hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 0); if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 0); hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 0); }
     HIPCHK(h, hipEventRecord(Ln.ep[4], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
     HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
-    if (!g_nolane) hipLaunchKernelGGL(k_filldp, dim3(w_dp), dim3(64), 0, s, da, 1);
+    if (!g_nolane) {
+        HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 12, s), LAMSA_HP_EKERNEL);          // the three queue heads of the lane DP launches
+        hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 1); if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 1); hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);
+    }
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 1);
     HIPCHK(h, hipEventRecord(Ln.ep[3], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_publish, dim3(std::min(h->n_cu * 8, n)), dim3(64), 0, s, da);

@@ -1531,6 +1531,7 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F, FlStore *
 
 }  // namespace hp
 #include "hp_cluster.h"
+#include "hp_gaps.h"
 namespace hp {
 
 // ---------------------------------------------------------------- round 1: frag_line_BCC, :1305-1445
@@ -1639,37 +1640,9 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
         if (max_node < 0) break;
         // pool never overflows: every node joins at most one line (TRACKED), plus one slack slot per line
         int32_t *ln = L.pool + next_start;
-        int node_i = 0, mini_len, last_n, right, left;
         T.off[l_i] = T.used; T.cnt[l_i] = 0;
-        if (r.n_seed[max_node] < seed_out - 1) {                      // beyond the chain end
-            mini_len = mini_line(r, max_node, -1, seed_out, _line, &line_score, &line_NM, 1, 0);
-            for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.nd[_line[k]].dp_flag = TRACKED_FLAG; }
-            ln[node_i] = max_node;
-            last_n = ln[0];
-            for (int k = mini_len - 1; k >= 0; --k) {
-                if (nx(r, last_n) - nx(r, ln[node_i - k]) > 2) HP_TRIG_PUSH(ln[node_i - k], last_n);
-                last_n = ln[node_i - k];
-            }
-        }
-        right = max_node;
-        while (right >= 0) {                                          // gaps between anchors
-            ln[node_i++] = right;
-            left = r.n_from[right];
-            if (nx(r, left) < r.n_seed[right] - 1) {
-                mini_len = mini_line(r, left, right, r.n_seed[right], _line, &line_score, &line_NM, 1, 1);
-                for (int k = mini_len - 1; k >= 0; --k) { ln[node_i++] = _line[k]; r.nd[_line[k]].dp_flag = TRACKED_FLAG; }
-                ln[node_i] = left;
-                last_n = right;
-                for (int k = mini_len; k >= 0; --k) {
-                    if (nx(r, last_n) - nx(r, ln[node_i - k]) > 2) {
-                        if (ln[node_i - k] < 0) continue;
-                        HP_TRIG_PUSH(ln[node_i - k], last_n);
-                    }
-                    last_n = ln[node_i - k];
-                }
-            }
-            right = left;
-        }
+        const int node_i = line_build(r, max_node, ln, _line, &line_score, &line_NM, T, l_i);       // anchors, mini DPs of the gaps, triggers (hp_gaps.h)
+        if (node_i < 0) return false;
         for (int k = 0; k < node_i / 2; ++k) { int t = ln[k]; ln[k] = ln[node_i - k - 1]; ln[node_i - k - 1] = t; }
         L.start[l_i] = next_start; L.len[l_i] = node_i; L.ls[l_i] = L.bs[l_i] = line_score; L.nm[l_i] = line_NM;
         L.mf[l_i] = 0; L.mh[l_i] = 0; L.lb[l_i] = L.rb[l_i] = 0;

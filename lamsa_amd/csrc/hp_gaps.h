@@ -1,0 +1,326 @@
+// hp_gaps.h -- frag_mini_dp_line (src/lamsa_dp_con.c:1068-1150) for all gaps of one line at once, ONE GAP PER LANE.
+// Included by hp_chain.h.
+//
+// After the main pass a line is a chain of MIN anchors (n_from links from its end node).  Wherever two consecutive anchors
+// are more than one seed slot apart -- and beyond the end node -- frag_line_BCC (:1370-1432) runs a small DP over the hits
+// of the repetitive (MULTI) seeds in between: initialised from the left anchor (frag_dp_per_init :766), updated in seed order
+// (frag_dp_update :701), closed by a forced update of the right anchor (or by the best end node) and walked back.  A 10-kbp
+// noisy read has ~300 such gaps, nearly all with a handful of hits that can be connected to the left anchor at all.  The
+// wave-wide routine (mini_line_sets) spends ~1500 wave instructions and 6-8 dependent memory round trips per gap; but the
+// gaps of a line do not depend on each other -- their seed ranges are disjoint, and what a pass leaves behind outside its own
+// result (scores, predecessors, son flags of the hits it touched) is reset by fnode_set / frag_dp_per_init before anything reads
+// it again -- so here every lane takes one gap: it scans the gap's hit range, keeps the (at most HP_GAP_MCAP) hits that
+// frag_dp_per_init would activate in its own strip of LDS, runs the same recurrence with the same tie rules over them and
+// returns the nodes of the mini line, their edge classes, the score / NM deltas and the right anchor's new state.  Gaps
+// with a longer range or more active hits, and passes that start from START, go through mini_line as before.
+#pragma once
+
+namespace hp {
+
+#define HP_GAP_MCAP 6             // active hits of a gap a lane can hold (six words each in LDS)
+#define HP_GAP_RANGE 96           // hits in the seed range of a gap a lane will scan
+
+struct GapOut {                   // per lane
+    int n;                        // nodes of the mini line (ascending), or -1: not handled here (fallback), -2: the reference's BUG exit
+    int ids[HP_GAP_MCAP], mfs[HP_GAP_MCAP];
+    int d_score, d_NM;
+    int r_from, r_score, r_NM, r_nn, r_mf;     // the right anchor after the forced update (_tail == 1)
+};
+
+HP_INL int gap_edge(const EdgeK &K, int sp, int qpos, int qsid, int qld, int tpos, int tsid, int tld)
+{   // get_fseed_dis (:596-634) for two hits of the same contig and strand, the first of an earlier seed (cf. dp_cluster_lds)
+    const int dsid = tsid - qsid, span = dsid * K.seed_step;
+    if (span < K.seed_len) return F_UNCONNECT;
+    const int dis = sp * (tpos - qpos) - span - (sp > 0 ? qld : tld);
+    const int mat_dis = K.match_dis * (K.high_err ? dsid : 1);
+    if (dis <= mat_dis && dis >= -mat_dis) return dsid == 1 ? F_MATCH : (dsid <= K.mis3 ? F_MISMATCH : F_LONG_MISMATCH);
+    if (dis > mat_dis && dis < K.sv_len) return F_DELETE;
+    if ((dis < -mat_dis && dis >= 0 - (span - K.seed_len)) || (dis < -K.half_split && dis >= -K.sv_len)) return F_INSERT;
+    return F_UNCONNECT;
+}
+
+// One gap on one lane.  left >= 0 (the head), right >= 0 when tail, right_x = right's slot (or seed_out).  LDS strip: word w of
+// entry e at strip[(e * 6 + w) * 64].
+HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int left, int right, int left_x, int right_x, int tail, GapOut &O)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
+    const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
+    O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = left; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
+    const int k_lo = (int)(g_hoff[left_x + 1] - r.hb), k_hi = (int)(g_hoff[right_x] - r.hb), k_t0 = (int)(g_hoff[left_x + 2] - r.hb);
+    if (k_hi - k_lo > HP_GAP_RANGE) return;
+    const NodeS Fh = node_load(ns + left);
+    const int head_nm = g_hnm[left], sp = Fh.strand;
+    if ((long long)(r.seed_id[r.seed_out - 1] - r.seed_id[0] + 1) * K.seed_step > 0x3fffffffll) return;
+#define GW(e, w) strip[((e) * 6 + (w)) * 64]
+    // ---- frag_dp_per_init over the range (:766-784, :1086-1091): the hits the head can be connected to
+    int m = 0;
+    for (int k = k_lo; k < k_hi; ++k) {
+        const NodeS Q = node_load(ns + k);
+        const int df = Q.dp_flag;
+        if (df != MULTI_FLAG && df != 0 - MULTI_FLAG) continue;
+        if (Q.chr != Fh.chr || Q.strand != sp) continue;
+        const long long rel = Q.pos - Fh.pos;
+        if (rel > 0x3fffffffll || rel < -0x3fffffffll) continue;                       // far beyond any connectable distance
+        const int flag = gap_edge(K, sp, 0, Fh.sid, Fh.len_dif8, (int)rel, Q.sid, Q.len_dif8);
+        if (flag == F_UNCONNECT) continue;
+        if (m >= HP_GAP_MCAP) return;                                                  // too many for a lane
+        GW(m, 0) = (int)rel; GW(m, 1) = Q.slot_j; GW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
+        GW(m, 3) = (int)(((unsigned)(2 + score_table(flag)) << 16) | (unsigned)((g_hnm[k] + head_nm) & 0xffff));
+        GW(m, 4) = k; GW(m, 5) = (0xff << 24) | (1 << 16) | (F_INIT << 8) | flag;       // from (0xff = the head) | node_n | son_flag | match_flag
+        ++m;
+    }
+    // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
+    for (int a = 0; a < m; ++a) {
+        const int tid = GW(a, 4);
+        if (tid < k_t0) continue;
+        const int tpos = GW(a, 0), tsj = GW(a, 1), t2 = GW(a, 2), t3 = GW(a, 3);
+        const int tslot = tsj >> 14, tsid = (int)(short)(t2 & 0xffff), tld = (int)(int8_t)((t2 >> 16) & 0xff);
+        const int t_score = t3 >> 16, t_NM = t3 & 0xffff;
+        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
+        for (int b = 0; b < a; ++b) {
+            const int qsj = GW(b, 1), qslot = qsj >> 14;
+            if (qslot >= tslot) continue;
+            const int q5 = GW(b, 5);
+            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;                 // '+': the candidate already has a match son, :718-720
+            const int q2 = GW(b, 2), q3 = GW(b, 3);
+            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), tpos, tsid, tld);
+            if (flag == F_UNCONNECT) continue;
+            const int pos = ((tslot - 1 - qslot) << 14) | (qsj & 16383);                // scan order: seeds descending, hits ascending
+            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + t_NM;
+            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
+            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
+            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }   // '-': first match precursor, :726-733
+        }
+        int w_b = -1, w_f = 0, w_score = t_score, w_nm = t_NM;
+        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
+        else if (best_b >= 0) {
+            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
+            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
+        }
+        if (w_b >= 0) {                                                                  // :753-761
+            const int q5 = GW(w_b, 5);
+            GW(a, 3) = (int)(((unsigned)w_score << 16) | (unsigned)(w_nm & 0xffff));
+            GW(a, 5) = (w_b << 24) | ((((q5 >> 16) & 0xff) + 1) << 16) | (GW(a, 5) & 0xff00) | w_f;
+            GW(w_b, 5) = (q5 & ~0xff00) | (w_f << 8);
+        }
+    }
+    // ---- the end of the line
+    int max_c = -1, max_n = 0, max_score, max_NM = 0, old_score, old_NM;
+    const int left_NM = head_nm;
+    if (!tail) {                                                                         // best end node, :1105-1123
+        old_score = 1; old_NM = left_NM;
+        max_score = old_score;
+        int bh = -0x7fffffff, bl = -1, bb = -1;
+        for (int b = 0; b < m; ++b) {
+            const int q3 = GW(b, 3), qsj = GW(b, 1);
+            const int pos = ((right_x - 1 - (qsj >> 14)) << 14) | (qsj & 16383);
+            const int hi = (int)(((unsigned)(q3 >> 16) << 16) | (unsigned)(65535 - (q3 & 0xffff))), lo = (1 << 28) - 1 - pos;
+            if (hi > bh || (hi == bh && lo > bl)) { bh = hi; bl = lo; bb = b; }
+        }
+        if (bb >= 0) {
+            const int sc = bh >> 16, nm = 65535 - (bh & 0xffff);
+            if (sc > max_score || (sc == max_score && nm < max_NM)) { max_c = bb; max_score = sc; max_NM = nm; max_n = (GW(bb, 5) >> 16) & 0xff; }
+        }
+    } else {                                                                             // forced update of the right anchor, :1125-1134
+        const NodeS Rt = node_load(ns + right);
+        const int right_nm = g_hnm[right];
+        old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm;
+        const long long rrel = Rt.pos - Fh.pos;
+        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
+        const bool r_ok = Rt.chr == Fh.chr && Rt.strand == sp && rrel <= 0x3fffffffll && rrel >= -0x3fffffffll;
+        for (int b = 0; b < m && r_ok; ++b) {
+            const int qsj = GW(b, 1), qslot = qsj >> 14, q5 = GW(b, 5);
+            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;
+            const int q2 = GW(b, 2), q3 = GW(b, 3);
+            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), (int)rrel, Rt.sid, Rt.len_dif8);
+            if (flag == F_UNCONNECT) continue;
+            const int pos = ((right_x - 1 - qslot) << 14) | (qsj & 16383);
+            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + old_NM;
+            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
+            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
+            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }
+        }
+        int w_b = -1, w_f = 0, w_score = old_score, w_nm = old_NM;
+        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
+        else if (best_b >= 0) {
+            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
+            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
+        }
+        O.r_mf = Rt.match_flag;
+        if (w_b >= 0) { O.r_from = GW(w_b, 4); O.r_nn = ((GW(w_b, 5) >> 16) & 0xff) + 1; O.r_mf = w_f; max_c = w_b; }
+        O.r_score = w_score; O.r_NM = w_nm;
+        max_score = w_score; max_NM = w_nm; max_n = O.r_nn - 1;
+    }
+    // ---- walk back to the head (:1136-1147)
+    {
+        int c = max_c, node_i = max_n - 1;
+        bool bad = max_n > HP_GAP_MCAP;
+        while (c >= 0 && !bad) {
+            if (node_i < 0) { bad = true; break; }
+            O.ids[node_i] = GW(c, 4); O.mfs[node_i] = GW(c, 5) & 0xff; --node_i;
+            const int f = (GW(c, 5) >> 24) & 0xff;
+            c = f == 0xff ? -1 : f;
+        }
+        if (node_i >= 0) bad = true;
+        if (bad) { O.n = -2; return; }
+    }
+#undef GW
+    O.n = max_n; O.d_score = max_score - old_score; O.d_NM = max_NM - old_NM;
+}
+
+// ---------------------------------------------------------------- one line of frag_line_BCC's loop (:1370-1432)
+// The anchors of the line from its end node `max_node` back to START, the mini DPs of all its gaps (one per lane where
+// possible, mini_line otherwise), the nodes in read order in ln[], the inter-line triggers (:1384-1386, :1404-1414).  Returns the
+// number of nodes, or -1 (status flagged).  `_line`: scratch of H + 2 words for mini_line.
+HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i)
+{
+    Ctx &cx = r.cx;
+    const int H = r.H, seed_out = r.seed_out;
+    const EdgeK K = edge_consts(cx.P);
+    const size_t mark = arena_mark(cx.tmp);
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
+    const HP_G int32_t *g_seed = (const HP_G int32_t *)r.n_seed;
+    // ---- the anchors, end node first (the chain the main pass and branch tracking left in n_from)
+    int32_t *anc = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)(H + 2));
+    if (!anc) { arena_release(cx.tmp, mark); return -1; }
+    int32_t *anc_x = anc + (H + 2);
+    int A = 0;
+    for (int right = max_node; right >= 0 && A <= H; right = g_from[right]) anc[A++] = right;
+    HP_G int32_t *g_anc = (HP_G int32_t *)anc, *g_ancx = (HP_G int32_t *)anc_x;
+    for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ancx[i0 + l] = g_seed[g_anc[i0 + l]]; } }
+    wv::sync();
+    // ---- the gaps: [0] beyond the end node (when it is not of the last seed slot), then after anchor i when the next anchor (or
+    // START) is more than one slot below.  Per gap: left, right, left_x, right_x, tail, the anchor it follows (-1: the first kind)
+    const int GA = A + 2;
+    int32_t *gp = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 16 * (size_t)GA);
+    int32_t *pool = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)(H + 8));    // mini-line nodes of all gaps (ids, then edge classes)
+    int32_t *posx = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * (size_t)(H + A + 8));  // per position of ln: slot, "pair with the position before is checked"
+    if (!gp || !pool || !posx) { arena_release(cx.tmp, mark); return -1; }
+    int32_t *g_left = gp, *g_right = gp + GA, *g_lx = gp + 2 * GA, *g_rx = gp + 3 * GA, *g_tail = gp + 4 * GA, *g_after = gp + 5 * GA,
+            *o_n = gp + 6 * GA, *o_off = gp + 7 * GA, *o_ds = gp + 8 * GA, *o_dn = gp + 9 * GA, *o_rf = gp + 10 * GA, *o_rs = gp + 11 * GA, *o_rn = gp + 12 * GA,
+            *o_rnn = gp + 13 * GA, *o_rmf = gp + 14 * GA, *o_lane = gp + 15 * GA;
+    int32_t *pool_mf = pool + (H + 8);
+    int G = 0;
+    if (anc_x[0] < seed_out - 1) { g_left[0] = max_node; g_right[0] = -1; g_lx[0] = anc_x[0]; g_rx[0] = seed_out; g_tail[0] = 0; g_after[0] = -1; G = 1; }
+    for (int i0 = 0; i0 < A; i0 += 64) {
+        wv::Lane<int> ex, lf, lx;
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            int e = 0, left = -1, left_x = -1;
+            if (i < A) { if (i + 1 < A) { left = g_anc[i + 1]; left_x = g_ancx[i + 1]; } e = left_x < g_ancx[i] - 1; }
+            ex[l] = e; lf[l] = left; lx[l] = left_x;
+        }
+        const unsigned long long m = wv::ballot(ex);
+        WAVE_FOR(l) {
+            if (ex[l]) {
+                const int g = G + __builtin_popcountll(m & ((1ull << l) - 1)), i = i0 + l;
+                g_left[g] = lf[l]; g_right[g] = g_anc[i]; g_lx[g] = lx[l]; g_rx[g] = g_ancx[i]; g_tail[g] = 1; g_after[g] = i;
+            }
+        }
+        G += __builtin_popcountll(m);
+    }
+    wv::sync();
+    // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
+    int pool_n = 0, d_score = 0, d_NM = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        wv::Lane<int> nn, ds, dn;
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            GapOut O; O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
+            if (g < G && g_left[g] >= 0 && HP_CL_CAP_RT(1) > 0) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
+            nn[l] = g < G ? O.n : 0; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0;
+            if (g < G) {
+                o_n[g] = O.n; o_ds[g] = O.d_score; o_dn[g] = O.d_NM; o_rf[g] = O.r_from; o_rs[g] = O.r_score; o_rn[g] = O.r_NM; o_rnn[g] = O.r_nn; o_rmf[g] = O.r_mf; o_lane[g] = O.n >= 0;
+            }
+            // the nodes of the lane's mini line, staged in its strip until the pool offsets of the group are known
+            for (int k = 0; k < HP_GAP_MCAP; ++k) { if (g < G && k < O.n) { cx.lds[(k * 6 + 0) * 64 + l] = O.ids[k]; cx.lds[(k * 6 + 1) * 64 + l] = O.mfs[k]; } }
+        }
+        wv::Lane<int> bad, cntl;
+        WAVE_FOR(l) { bad[l] = nn[l] == -2; cntl[l] = nn[l] > 0 ? nn[l] : 0; }
+        if (wv::ballot(bad) != 0) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); return -1; }    // "[frag mini dp] BUG" exit, :1140
+        wv::Lane<int> pre = cntl;
+        wv::scan_add_excl(pre);
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            if (g < G && nn[l] >= 0) {
+                o_off[g] = pool_n + pre[l];
+                for (int k = 0; k < nn[l]; ++k) { pool[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 0) * 64 + l]; pool_mf[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 1) * 64 + l]; }
+            }
+        }
+        pool_n += wv::reduce_sum(cntl);
+        d_score += wv::reduce_sum(ds); d_NM += wv::reduce_sum(dn);
+        wv::sync();
+    }
+    // right anchors and line nodes of the gaps the lanes have done
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            if (g < G && o_lane[g]) {
+                if (g_tail[g]) {
+                    const int right = g_right[g];
+                    g_from[right] = o_rf[g]; gd[right].score = o_rs[g]; gd[right].NM = o_rn[g]; g_node_n[right] = o_rnn[g]; gd[right].match_flag = (uint8_t)o_rmf[g];
+                }
+                for (int k = 0; k < o_n[g]; ++k) gd[pool[o_off[g] + k]].match_flag = (uint8_t)pool_mf[o_off[g] + k];
+            }
+        }
+    }
+    wv::sync();
+    for (int g = 0; g < G; ++g) {                                                       // the others, one at a time
+        if (o_lane[g]) continue;
+        int ds = 0, dn = 0;
+        const int n = mini_line(r, g_left[g], g_right[g], g_rx[g], _line, &ds, &dn, 1, g_tail[g]);
+        if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); return -1; }
+        if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return -1; }
+        o_n[g] = n; o_off[g] = pool_n;
+        for (int k = 0; k < n; ++k) pool[pool_n + k] = _line[k];
+        pool_n += n; d_score += ds; d_NM += dn;
+        wv::sync();
+    }
+    *line_score += d_score; *line_NM += d_NM;
+    // ---- the line, end node first: [nodes beyond the end node], anchor 0, [nodes of the gap after it], anchor 1, ...
+    int node_i = 0;
+    {
+        int gi = 0;
+        HP_G int32_t *g_ln = (HP_G int32_t *)ln; HP_G int32_t *g_seg = (HP_G int32_t *)(posx + (H + A + 8));
+        if (G > 0 && g_after[0] == -1) {
+            const int n = o_n[0], off = o_off[0];
+            for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < n) { g_ln[node_i + k] = pool[off + n - 1 - k]; g_seg[node_i + k] = k > 0; } } }
+            node_i += n; gi = 1;
+            g_seg[node_i] = n > 0;                                                       // pair (last node beyond the end, end node)
+        } else g_seg[0] = 0;
+        for (int i = 0; i < A; ++i) {
+            ln[node_i++] = anc[i];
+            if (gi < G && g_after[gi] == i) {
+                const int n = o_n[gi], off = o_off[gi];
+                for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < n) { g_ln[node_i + k] = pool[off + n - 1 - k]; g_seg[node_i + k] = 1; } } }
+                node_i += n;
+                g_seg[node_i] = 1;                                                       // pair (last node of the gap or the anchor itself, next anchor)
+                ++gi;
+            } else g_seg[node_i] = 0;
+        }
+        wv::sync();
+        // every node that came out of a mini DP is tracked now (:1376, :1398)
+        for (int k0 = 0; k0 < pool_n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < pool_n) gd[pool[k0 + l]].dp_flag = TRACKED_FLAG; } }
+        // inter-line triggers: consecutive nodes of a gap's stretch more than two slots apart (:1384-1386, :1404-1414)
+        HP_G int32_t *g_px = (HP_G int32_t *)posx;
+        for (int q0 = 0; q0 < node_i; q0 += 64) { WAVE_FOR(l) { if (q0 + l < node_i) g_px[q0 + l] = g_seed[g_ln[q0 + l]]; } }
+        wv::sync();
+        for (int q0 = 1; q0 < node_i; q0 += 64) {
+            wv::Lane<int> push;
+            WAVE_FOR(l) { const int q = q0 + l; push[l] = q < node_i && g_seg[q] && g_px[q - 1] - g_px[q] > 2; }
+            const unsigned long long m = wv::ballot(push);
+            const int cnt = __builtin_popcountll(m);
+            if (!cnt) continue;
+            if (T.used + cnt > T.cap) { cx.status |= ST_OVERFLOW; break; }
+            WAVE_FOR(l) { if (push[l]) { const int at = T.used + __builtin_popcountll(m & ((1ull << l) - 1)); T.n1[at] = g_ln[q0 + l]; T.n2[at] = g_ln[q0 + l - 1]; } }
+            T.used += cnt; T.cnt[l_i] += cnt;
+        }
+        wv::sync();
+    }
+    arena_release(cx.tmp, mark);
+    return node_i;
+}
+
+}  // namespace hp

@@ -45,12 +45,14 @@ struct PhaseCtl {                // counters of one launch sequence, zeroed befo
     int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
     int32_t bucket_n[2][PH_NBUCKET];
     unsigned long long fl_cursor, line_cursor, job_cursor;
+    int32_t lj_n[2], lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (size group x kind x query-length class; LJ_NBUCKET <= 24)
     // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
     // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
     // draining, i.e. with idle wave slots
     unsigned long long t_first_inv[4], t_last[4];
 };
 
+struct LjRec;
 struct PhaseArgs {
     lamsa_hp_para P;
     RefView ref;
@@ -69,6 +71,7 @@ struct PhaseArgs {
     int32_t *fl_base; int64_t fl_cap;            // fragment arena (words)
     int32_t *line_base; int64_t line_cap;        // line arena (words)
     int32_t *job_base; int64_t job_cap;          // CIGARs of the lane-per-job DPs (words, < 2^31)
+    struct LjRec *ljobs; int32_t *lj_bucket; int32_t lj_cap;     // [lj_cap] job records and [LJ_NBUCKET][lj_cap] queues of job indices of the round being filled
     PhaseCtl *ctl;
 };
 
@@ -236,13 +239,33 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
 }
 
 
-// ---------------------------------------------------------------- fill, step 1: the small DP jobs of one line, one job per lane
-// (hp_lanedp.h).  Lists the line's junctions of the mismatch class with read bases in between (split_mapping, frag_check.c:547-559)
-// and the gaps between neighbouring seeds of its fragments (frag_extend, :360-400) with the geometry the fill would compute,
-// runs them 64 at a time and leaves the CIGARs in the job arena, their slots in FLines::jt / gt.
-struct LjRec { int32_t type, qoff, qlen, tlen, slot; int32_t pad; int64_t tk; };       // type 1: ksw_bi_extend(100, 100), 2: ksw_global2
+// ---------------------------------------------------------------- fill, step 1: the small DP jobs of the lines, one job per lane
+// (hp_lanedp.h).  phase_filllist (one line per wave) lists the line's junctions of the mismatch class with read bases in between
+// (split_mapping, frag_check.c:547-559) and the gaps between neighbouring seeds of its fragments (frag_extend, :360-400), with
+// the geometry the fill would compute, into job queues of the whole batch by kind and query length; phase_filldp (64 jobs per
+// wave, longest queries first, so that the lanes of a wave run alike) leaves the CIGARs in the job arena and their slots in
+// FLines::jt / gt, where the fill finds them.
+// Which jobs are listed for the lanes.  Measured on the MI355X (profiles/r02_*): jobs with queries of up to 64 bases are cheaper one per
+// lane than one per wave; longer ones (rows of 160 cells need 52 KB of LDS per wave, three waves per CU) are not, and stay with the
+// wave-per-job routines unless HP_LJ_BIG is set.
+#ifdef HP_LJ_BIG
+#define HP_LJ_QLIST HP_LJ_QCAP
+#define HP_LJ_TLIST HP_LJ_TCAP
+#else
+#define HP_LJ_QLIST HP_LJ_QSMALL
+#define HP_LJ_TLIST HP_LJ_TSMALL
+#endif
+struct LjRec { int64_t qaddr, tk, slot; int32_t rd; uint16_t tlen; uint8_t qlen; int8_t type_comp; };      // type_comp: type (1: ksw_bi_extend(100, 100), 2: ksw_global2) | complement << 4
+// queues: [big jobs (query > HP_LJ_QSMALL): kind 1 longest first, kind 2 longest first][short jobs: the same]; LJ_NBIG queues are "big"
+enum { LJ_NCLS_BIG = (HP_LJ_QCAP - HP_LJ_QSMALL) / 16, LJ_NCLS_SMALL = HP_LJ_QSMALL / 16, LJ_NBIG = 2 * LJ_NCLS_BIG, LJ_NBUCKET = 2 * (LJ_NCLS_BIG + LJ_NCLS_SMALL) };
+HP_INL int lj_bucket_of(int type, int qlen, int tlen)
+{
+    const int cls = (qlen > 0 ? qlen - 1 : 0) >> 4;                            // 0 .. HP_LJ_QCAP / 16 - 1
+    if (qlen > HP_LJ_QSMALL || tlen > HP_LJ_TSMALL) { const int c = cls < LJ_NCLS_SMALL ? LJ_NCLS_SMALL : cls; return (type == 1 ? 0 : LJ_NCLS_BIG) + (LJ_NCLS_BIG - 1 - (c - LJ_NCLS_SMALL)); }
+    return LJ_NBIG + (type == 1 ? 0 : LJ_NCLS_SMALL) + (LJ_NCLS_SMALL - 1 - cls);
+}
 
-HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, HP_L int32_t *lds)
+HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot, HP_L int32_t *lds)
 {
     UnitRec &U = a.units[(size_t)round * a.unit_cap + u];
     const int rd = U.read, line = U.line;
@@ -251,8 +274,8 @@ HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, 
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
     pers_bind(r, a, rd);
-    Ctx &cx = r.cx;
-    const lamsa_hp_para *P = cx.P;
+    const lamsa_hp_para *P = r.cx.P;
+    if (!lj_params_ok(P)) return;
     FLines F;
     F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
     flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
@@ -260,25 +283,14 @@ HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, 
     const int p0 = F.fr_seed_off[f0], np = F.fr_seed_off[f0 + nfr] - p0;       // the line's seeds in fr_seed
     const int strand = r.h_strand[F.fr_seed[p0]];
     const int n_cand = (nfr - 1) + np;
-    // scratch of this wave: the reverse complement (a '-' line aligns it, frag_check.c:922-926), the job list, per lane three
-    // CIGAR buffers, the lane-interleaved direction matrices
-    r.rc_read = (uint8_t *)arena_alloc(cx, (size_t)r.L + 16);
-    LjRec *jobs = (LjRec *)arena_alloc(cx, sizeof(LjRec) * (size_t)(n_cand + 64));
-    cig_t *cbuf = (cig_t *)arena_alloc(cx, sizeof(cig_t) * 3 * HP_LJ_CIG * 64);
-    uint8_t *zbuf = (uint8_t *)arena_alloc(cx, (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
-    if (!r.rc_read || !jobs || !cbuf || !zbuf) return;                         // no room: the fill computes everything itself
-    if (strand != 1) {
-        for (int b = 0; b < r.L; b += 64) { WAVE_FOR(l) { const int i = b + l; if (i < r.L) { const int c = r.read[r.L - 1 - i]; r.rc_read[i] = c < 4 ? 3 - c : 4; } } }
-        wv::sync();
-        r.rc_ready = true; r.cur_read = r.rc_read; r.flip = true;
-    }
-    // ---- list the jobs
-    int n_jobs = 0;
+    r.flip = strand != 1;                                                      // seed ids as a '-' line sees them (frag_check.c:926)
+    const int64_t rbase = a.in.read_off[rd];
+    long long tb = 0;
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
-        wv::Lane<int> ty, qo, ql, tl, sl; wv::Lane<long long> tk;
+        wv::Lane<int> ty, qo, ql, tl; wv::Lane<long long> tk, sl;
         WAVE_FOR(l) {
             const int c = c0 + l;
-            int type = 0, qoff = 0, qlen = 0, tlen = 0, slot = 0; long long k0 = 0;
+            int type = 0, qoff = 0, qlen = 0, tlen = 0; long long k0 = 0, slot = 0;
             if (c < nfr - 1) {                                                  // junction between fragments jf and jf + 1, split_mapping :416-470
                 const int jf = f0 + c;
                 const int f1 = strand == 1 ? jf + 1 : jf, f2 = strand == 1 ? jf : jf + 1;
@@ -293,14 +305,14 @@ HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, 
                 const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
                 const int dis = (int)(at2_off - exp);
                 const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
-                if (s_qlen > 0 && s_qlen <= HP_LJ_QCAP && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
+                if (s_qlen > 0 && s_qlen <= HP_LJ_QLIST && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
                     const int64_t start0 = at1_off + P->seed_len + at1_ld - 1;
                     const int32_t clen = r.ref.seq_len[at1_chr - 1];
                     if (start0 <= clen && start0 >= 0) {                        // pac2fa_core, bntseq.c:469-474
                         int tl_ = s_qlen + dis;
                         if (start0 + tl_ > clen) tl_ = (int)(clen - start0);
-                        if (tl_ <= HP_LJ_TCAP) {
-                            type = 1; qlen = s_qlen; tlen = tl_; slot = jf; k0 = r.ref.seq_off[at1_chr - 1] + start0;
+                        if (tl_ <= HP_LJ_TLIST) {
+                            type = 1; qlen = s_qlen; tlen = tl_; slot = (F.jt + 4 * jf) - a.fl_base; k0 = r.ref.seq_off[at1_chr - 1] + start0;
                             qoff = (strand == 1 ? 0 : r.last_len) + id1 * P->seed_step - P->seed_inv;      // get_read_intv, :116
                         }
                     }
@@ -323,8 +335,8 @@ HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, 
                     const int idl = sid(r, r.n_seed[last]), ids = sid(r, r.n_seed[s]);
                     const int qi = (strand == 1 ? 0 : r.last_len) + idl * P->seed_step - P->seed_inv, qe = (strand == 1 ? 0 : r.last_len) + (ids - 1) * P->seed_step;
                     const int len1 = qe > qi ? qe - qi : 0;
-                    if (ok && len1 <= HP_LJ_QCAP && len2 <= HP_LJ_TCAP) {
-                        type = 2; qlen = len1; tlen = len2; slot = -1 - p; qoff = qi; k0 = r.ref.seq_off[r.h_chr[last] - 1] + start;
+                    if (ok && len1 <= HP_LJ_QLIST && len2 <= HP_LJ_TLIST) {
+                        type = 2; qlen = len1; tlen = len2; slot = (F.gt + 4 * p) - a.fl_base; qoff = qi; k0 = r.ref.seq_off[r.h_chr[last] - 1] + start;
                     }
                 }
             }
@@ -333,53 +345,86 @@ HP_NOINL void phase_filldp(const PhaseArgs &a, int round, int u, int wave_slot, 
         wv::Lane<int> has;
         WAVE_FOR(l) has[l] = ty[l] != 0;
         const unsigned long long m = wv::ballot(has);
+        if (!m) continue;
+        const int cnt = __builtin_popcountll(m);
+        int base = 0;
+        if (wv::leader()) base = atomicAdd(&a.ctl->lj_n[round], cnt);
+        base = wv::uni(base);
+        if (base + cnt > a.lj_cap) continue;                                    // queue full: these stay with the fill
+        wv::Lane<int> at, tbl;
         WAVE_FOR(l) {
-            if (ty[l]) { LjRec &J = jobs[n_jobs + __builtin_popcountll(m & ((1ull << l) - 1))]; J.type = ty[l]; J.qoff = qo[l]; J.qlen = ql[l]; J.tlen = tl[l]; J.slot = sl[l]; J.pad = 0; J.tk = tk[l]; }
-        }
-        n_jobs += __builtin_popcountll(m);
-    }
-    wv::sync();
-    // ---- run them, 64 at a time
-    long long tb = 0, cells = 0;
-    for (int j0 = 0; j0 < n_jobs; j0 += 64) {
-        wv::Lane<int> nw, tbl, cel;
-        WAVE_FOR(l) {
-            nw[l] = 0; tbl[l] = 0; cel[l] = 0;
-            if (j0 + l < n_jobs) {
-                const LjRec R = jobs[j0 + l];
-                LaneJob J;
-                J.q = r.cur_read + R.qoff; J.qs = 1; J.qlen = R.qlen; J.pac = r.ref.pac; J.tk = R.tk; J.ts = 1; J.tlen = R.tlen; J.z = zbuf; J.zl = l; J.cells = 0;
-                LCig out, Lc, Rc;
-                out.c = cbuf + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
-                if (R.type == 1) lj_bi_extend(P, J, 100, 100, Lc, Rc, out);
-                else lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
-                nw[l] = out.n; tbl[l] = R.tlen; cel[l] = (int)J.cells;
+            at[l] = base + __builtin_popcountll(m & ((1ull << l) - 1)); tbl[l] = ty[l] ? tl[l] : 0;
+            if (ty[l]) {
+                LjRec &J = a.ljobs[at[l]];
+                // the query in the read as stored: a '-' line reads the reverse complement, base j of it is the complement of base L-1-j
+                J.qaddr = strand == 1 ? rbase + qo[l] : rbase + (r.L - 1 - qo[l]);
+                J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = (uint8_t)ql[l]; J.tlen = (uint16_t)tl[l]; J.type_comp = (int8_t)(ty[l] | (strand == 1 ? 0 : 16));
             }
         }
-        // publish: one reservation in the job arena per group
-        wv::Lane<int> pre = nw;
-        wv::scan_add_excl(pre);
-        const int total = wv::reduce_sum(nw);
-        unsigned long long base = 0;
-        if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)total);
-        base = (unsigned long long)wv::uni64((long long)base);
-        if ((int64_t)(base + (unsigned long long)total) > a.job_cap) break;    // arena full: the rest stays with the fill
-        WAVE_FOR(l) {
-            if (j0 + l < n_jobs) {
-                const LjRec R = jobs[j0 + l];
-                const cig_t *src = cbuf + (size_t)l * 3 * HP_LJ_CIG;
-                int32_t *dst = a.job_base + base + pre[l];
-                for (int k = 0; k < nw[l]; ++k) dst[k] = src[k];
-                int32_t *slot = R.slot >= 0 ? F.jt + 4 * R.slot : F.gt + 4 * (-1 - R.slot);
-                slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = R.tlen; slot[3] = 1;
-            }
+        tb += wv::reduce_sum(tbl);
+        for (int b = 0; b < LJ_NBUCKET; ++b) {                                  // into the queue of its kind and length class
+            wv::Lane<int> inb;
+            WAVE_FOR(l) inb[l] = ty[l] && lj_bucket_of(ty[l], ql[l], tl[l]) == b;
+            const unsigned long long mb = wv::ballot(inb);
+            if (!mb) continue;
+            int bb = 0;
+            if (wv::leader()) bb = atomicAdd(&a.ctl->lj_bucket_n[round][b], __builtin_popcountll(mb));
+            bb = wv::uni(bb);
+            WAVE_FOR(l) { if (inb[l]) a.lj_bucket[(size_t)b * a.lj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
         }
-        tb += wv::reduce_sum(tbl); cells += wv::reduce_sum(cel);
     }
-    wv::sync();
-    r.t_bases = tb; cx.n_cells = cells;
     r.flip = false;
+    r.t_bases = tb;
     meta_flag(a, rd, r);
+}
+
+// group g of 64 jobs of the round's queues (the caller maps g to a queue and an offset)
+HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int wave_slot, HP_L int32_t *lds, int qcap)
+{
+    const lamsa_hp_para *P = &a.P;
+    const int cnt = a.ctl->lj_bucket_n[round][bucket] - off < 64 ? a.ctl->lj_bucket_n[round][bucket] - off : 64;
+    char *slab = a.slab + (size_t)wave_slot * a.slab_per_wave;
+    cig_t *cbuf = (cig_t *)slab;                                               // per lane three CIGAR buffers
+    uint8_t *zbuf = (uint8_t *)(slab + sizeof(cig_t) * 3 * HP_LJ_CIG * 64);     // the lane-interleaved direction matrices
+    if (sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 > a.slab_per_wave) return;
+    const int32_t *bq = a.lj_bucket + (size_t)bucket * a.lj_cap + off;
+    wv::Lane<int> nw, rdl, cel; wv::Lane<long long> slotl;
+    wv::sync();
+    WAVE_FOR(l) {
+        nw[l] = 0; rdl[l] = -1; cel[l] = 0; slotl[l] = 0;
+        if (l < cnt) {
+            const LjRec R = a.ljobs[bq[l]];
+            LaneJob J;
+            const int comp = (R.type_comp >> 4) & 1, type = R.type_comp & 15;
+            J.q = (const HP_G uint8_t *)(a.in.read_seq + R.qaddr); J.qs = comp ? -1 : 1; J.qcomp = comp; J.qlen = R.qlen; J.pac = (const HP_G uint8_t *)a.ref.pac; J.tk = R.tk; J.ts = 1; J.tlen = R.tlen;
+            J.z = (HP_G uint8_t *)zbuf; J.zl = l; J.zs = qcap; J.cells = 0; J.row = lds + l; J.qrow = (HP_L uint8_t *)(lds + (qcap + 2) * 64) + l; J.rev = 0;
+            lj_stage_query(J);
+            LCig out, Lc, Rc;
+            out.c = cbuf + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
+            if (type == 1) lj_bi_extend(P, J, 100, 100, Lc, Rc, out);
+            else lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
+            nw[l] = out.n; rdl[l] = R.rd; cel[l] = (int)J.cells; slotl[l] = R.slot | ((long long)R.tlen << 48);
+        }
+    }
+    // publish: one reservation in the job arena per group
+    wv::Lane<int> pre = nw;
+    wv::scan_add_excl(pre);
+    const int total = wv::reduce_sum(nw);
+    unsigned long long base = 0;
+    if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)total);
+    base = (unsigned long long)wv::uni64((long long)base);
+    if ((int64_t)(base + (unsigned long long)total) > a.job_cap) return;       // arena full: these stay with the fill
+    WAVE_FOR(l) {
+        if (l < cnt) {
+            const cig_t *src = cbuf + (size_t)l * 3 * HP_LJ_CIG;
+            int32_t *dst = a.job_base + base + pre[l];
+            for (int k = 0; k < nw[l]; ++k) dst[k] = src[k];
+            int32_t *slot = a.fl_base + (slotl[l] & 0xffffffffffffll);
+            slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = (int32_t)(slotl[l] >> 48); slot[3] = 1;
+            if (cel[l] > 0) atomicAdd(&a.meta[rdl[l]].cells, cel[l]);
+        }
+    }
+    wv::sync();
 }
 
 // ---------------------------------------------------------------- chain2: one read

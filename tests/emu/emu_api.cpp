@@ -119,14 +119,21 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
         p.job_cap = g_emu_lane_dp ? 4096 + 1024 * (int64_t)n + 8 * n_bases : 0;
         std::vector<int32_t> fl((size_t)p.fl_cap), lines((size_t)p.line_cap), jobsv((size_t)p.job_cap + 4);
         p.job_base = jobsv.data();
+        p.lj_cap = g_emu_lane_dp ? (int)(1024 + 64 * (int64_t)n + n_bases / 8) : 0;
+        std::vector<LjRec> ljv((size_t)p.lj_cap + 1); std::vector<int32_t> ljq((size_t)LJ_NBUCKET * p.lj_cap + 1);
+        p.ljobs = ljv.data(); p.lj_bucket = ljq.data();
+        static int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
         PhaseCtl ctl; memset(&ctl, 0, sizeof ctl);
         p.g_nd = nd.data(); p.g_nseed = nseed.data(); p.g_sidx = sidx.data(); p.meta = meta.data(); p.units = units.data(); p.bucket_q = bq.data();
         p.fl_base = fl.data(); p.line_base = lines.data(); p.ctl = &ctl;
         (void)n_bases;
         auto fill_all = [&](int round) {
-            if (g_emu_lane_dp)
+            if (g_emu_lane_dp) {
                 for (int b = 0; b < PH_NBUCKET; ++b)
-                    for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filldp(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
+                    for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filllist(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
+                for (int b = 0; b < LJ_NBUCKET; ++b)
+                    for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 64) phase_filldp(p, round, b, off, 0, lds_lj, b < LJ_NBIG ? HP_LJ_QCAP : HP_LJ_QSMALL);
+            }
             for (int b = 0; b < PH_NBUCKET; ++b)
                 for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
         };
@@ -157,11 +164,15 @@ extern "C" int emu_lane_dp(const lamsa_hp_para *P, int n, const uint8_t *seq, co
     { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } }
     std::vector<uint8_t> z((size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
     std::vector<cig_t> cb((size_t)3 * HP_LJ_CIG * 64);
+    static int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+    if (!lj_params_ok(P)) return -2;
     for (int j0 = 0; j0 < n; j0 += 64) {
         for (int l = 0; l < 64 && j0 + l < n; ++l) {
             const int i = j0 + l;
             if (qlen[i] > HP_LJ_QCAP || tlen[i] > HP_LJ_TCAP) return -1;
-            LaneJob J; J.q = seq + q_off[i]; J.qs = 1; J.qlen = qlen[i]; J.pac = pac.data(); J.tk = tk[i]; J.ts = 1; J.tlen = tlen[i]; J.z = z.data(); J.zl = l; J.cells = 0;
+            LaneJob J; J.q = seq + q_off[i]; J.qs = 1; J.qcomp = 0; J.qlen = qlen[i]; J.pac = pac.data(); J.tk = tk[i]; J.ts = 1; J.tlen = tlen[i]; J.z = z.data(); J.zl = l; J.zs = HP_LJ_QCAP; J.cells = 0;
+            J.row = lds_lj + l; J.qrow = (uint8_t *)(lds_lj + (HP_LJ_QCAP + 2) * 64) + l; J.rev = 0;
+            lj_stage_query(J);
             LCig out, Lc, Rc; out.c = cb.data() + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
             int a = 0, b = 0;
             if (kind == 0) score[i] = lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, w, &out);

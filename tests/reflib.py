@@ -170,7 +170,10 @@ def ref_dp(jobs, P, kind, w, h0):
 
 
 _emu = None
-EMU_DIR = os.path.join(ROOT, "tests", "_build")
+# LAMSA_EMU_COVERAGE=1 (tools/device_coverage.sh): the emulation build instrumented for gcov, in its own directory
+EMU_COV = bool(os.environ.get("LAMSA_EMU_COVERAGE"))
+EMU_DIR = os.path.join(ROOT, "tests", "_build_cov" if EMU_COV else "_build")
+EMU_FLAGS = ["-O0", "--coverage"] if EMU_COV else ["-O1"]
 
 
 def emu():
@@ -183,9 +186,9 @@ def emu():
         deps = srcs + [os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
             [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]
         if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-            subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+            subprocess.run(["g++"] + EMU_FLAGS + ["-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                             "-I", os.path.join(ROOT, "tests", "emu"), "-I", os.path.join(ROOT, "lamsa_amd", "csrc"),
-                            "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", out] + srcs, check=True)
+                            "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", out] + srcs, check=True, cwd=EMU_DIR)
         _emu = C.CDLL(out)
     return _emu
 
@@ -201,8 +204,8 @@ def emu_cli():
     deps = srcs + [os.path.join(host, "lamsa_host.h"), os.path.join(host, "rescue.h"), os.path.join(ROOT, "include", "lamsa_hp.h"), os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
         [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "emu"),
-                        "-I", os.path.join(ROOT, "lamsa_amd", "csrc"), "-o", out] + srcs + ["-lz", "-lpthread"], check=True)
+        subprocess.run(["g++"] + EMU_FLAGS + ["-g", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "emu"),
+                        "-I", os.path.join(ROOT, "lamsa_amd", "csrc"), "-o", out] + srcs + ["-lz", "-lpthread"], check=True, cwd=EMU_DIR)
     return out
 
 
@@ -344,7 +347,7 @@ def emu_lane_dp(jobs, hp_para, kind, w, h0):
     E = emu()
     n = len(jobs)
     seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
-    CIG = 96 + 192 + 8
+    CIG = 160 + 256 + 8
     score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(n * CIG + 4, np.int32)
     p = lambda a: a.ctypes.data
     E.emu_lane_dp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5

@@ -138,7 +138,7 @@ def test_lane_per_job_dp_matches_oracle(preset):
     P = HpPara()
     for n, _ in HpPara._fields_:
         setattr(P, n, getattr(lp, n))
-    jobs = [(q, t) for q, t in dpjobs.make_jobs(4242, 700, 90, (0.05, 0.05, 0.05)) if len(q) <= 96 and len(t) <= 192 and (len(t) == 0 or t.max() < 4)]
+    jobs = [(q, t) for q, t in dpjobs.make_jobs(4242, 900, 150, (0.05, 0.05, 0.05)) if len(q) <= 160 and len(t) <= 256 and (len(t) == 0 or t.max() < 4)]
     assert len(jobs) > 400
     for kind, w, h0 in ((0, lp.band_w, 0), (0, 7, 0), (1, lp.band_w, 50), (1, 12, 8), (2, 0, 100), (2, 0, 10)):
         want = reflib.oracle_dp(jobs, lp, kind, w, max(h0, 1))
