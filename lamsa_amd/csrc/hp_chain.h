@@ -1600,9 +1600,19 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
                 wv::Lane<int> csl;
                 WAVE_FOR(l) { const int c = c0 + l; csl[l] = c <= C.n_cl ? g_cs[c] : H; }
                 const int cn = C.n_cl - c0 < 63 ? C.n_cl - c0 : 63;
+                wv::Lane<int> csn = csl;                                                          // the next cluster's first rank
+                WAVE_FOR(l) { const int c = c0 + l + 1; csn[l] = c <= C.n_cl ? g_cs[c] : H; }
+                const bool geo32 = (long long)(r.seed_id[seed_out - 1] - r.seed_id[0] + 1) * P->seed_step <= 0x3fffffffll;
+                if (geo32 && HP_CL_CAP_RT(1 << 20) >= HP_CLL_MCAP) {                                   // clusters of two to six hits: one per lane
+                    const EdgeK K = edge_consts(P);
+                    wv::sync();
+                    WAVE_FOR(l) { const int n = csn[l] - csl[l]; if (l < cn && n >= 2 && n <= HP_CLL_MCAP) cluster_lane(r, K, C, r.cx.lds + l, csl[l], n); }
+                    wv::sync();
+                }
                 for (int q = 0; q < cn; ++q) {
                     const int lo = wv::bcast(csl, q), n = wv::bcast(csl, q + 1) - lo;
                     if (n < 2) continue;                                                          // a lone hit has no predecessor
+                    if (geo32 && HP_CL_CAP_RT(1 << 20) >= HP_CLL_MCAP && n <= HP_CLL_MCAP) continue;   // done above
                     if (n <= HP_CL_CAP_RT(r.cx.lds_words / 5) && dp_cluster_lds(r, C, lo, n)) continue;
                     for (int i0 = 0; i0 < n; i0 += 64) { WAVE_FOR(l) { if (i0 + l < n) g_big[g_srt[lo + i0 + l]] = 1; } }
                     any_big = true;

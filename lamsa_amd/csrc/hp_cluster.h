@@ -217,6 +217,91 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
     arena_release(r.cx.tmp, mark_);
 }
 
+
+// ---------------------------------------------------------------- small clusters, ONE CLUSTER PER LANE
+// Most clusters of a read against a repeat-rich genome are tiny: two to six hits at some other copy of a repeat (on the 10-kbp
+// ONT workload ~330 of the ~360 clusters with more than one hit).  Giving each of them the whole wave costs a gather, a sort-index
+// look-up and a write-back round trip per cluster for a handful of comparisons.  Here 64 such clusters are handled at once, one
+// per lane: the lane keeps the cluster's MIN hits (ascending hit order, from C.csrt) in its own strip of LDS -- six words each --
+// and runs frag_dp_update (:701-764) over them exactly as dp_cluster_lds does.
+#define HP_CLL_MCAP 6
+HP_INL int gap_edge(const EdgeK &K, int sp, int qpos, int qsid, int qld, int tpos, int tsid, int tld)
+{   // get_fseed_dis (:596-634) for two hits of the same contig and strand, the first of an earlier seed (cf. dp_cluster_lds)
+    const int dsid = tsid - qsid, span = dsid * K.seed_step;
+    if (span < K.seed_len) return F_UNCONNECT;
+    const int dis = sp * (tpos - qpos) - span - (sp > 0 ? qld : tld);
+    const int mat_dis = K.match_dis * (K.high_err ? dsid : 1);
+    if (dis <= mat_dis && dis >= -mat_dis) return dsid == 1 ? F_MATCH : (dsid <= K.mis3 ? F_MISMATCH : F_LONG_MISMATCH);
+    if (dis > mat_dis && dis < K.sv_len) return F_DELETE;
+    if ((dis < -mat_dis && dis >= 0 - (span - K.seed_len)) || (dis < -K.half_split && dis >= -K.sv_len)) return F_INSERT;
+    return F_UNCONNECT;
+}
+
+HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int32_t *strip, int lo, int n)
+{
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_csrt = (const HP_G int32_t *)C.csrt;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
+#define CW(e, w) strip[((e) * 6 + (w)) * 64]
+    int m = 0, sp = 0; int64_t pos0 = 0;
+    for (int i = 0; i < n; ++i) {                                                       // the cluster's MIN hits, ascending hit order
+        const int id = g_csrt[lo + i];
+        const NodeS Q = node_load(ns + id);
+        if (Q.dp_flag != MIN_FLAG) continue;
+        if (m == 0) { pos0 = Q.pos; sp = Q.strand; }
+        CW(m, 0) = (int)(Q.pos - pos0); CW(m, 1) = Q.slot_j; CW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
+        CW(m, 3) = (int)(((unsigned)Q.score << 16) | (unsigned)(Q.NM & 0xffff));
+        CW(m, 4) = id; CW(m, 5) = (0xff << 24) | (1 << 16) | ((int)Q.son_flag << 8) | Q.match_flag;     // from (0xff = START) | node_n | son_flag | match_flag
+        ++m;
+    }
+    bool any = false;
+    for (int a = 1; a < m; ++a) {
+        const int tpos = CW(a, 0), tsj = CW(a, 1), t2 = CW(a, 2), t3 = CW(a, 3);
+        const int tslot = tsj >> 14, tsid = (int)(short)(t2 & 0xffff), tld = (int)(int8_t)((t2 >> 16) & 0xff);
+        const int t_score = t3 >> 16, t_NM = t3 & 0xffff;
+        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
+        for (int b = 0; b < a; ++b) {
+            const int qsj = CW(b, 1), qslot = qsj >> 14;
+            if (qslot >= tslot) continue;
+            const int q5 = CW(b, 5);
+            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;                 // '+': the candidate already has a match son, :718-720
+            const int q2 = CW(b, 2), q3 = CW(b, 3);
+            const int flag = gap_edge(K, sp, CW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), tpos, tsid, tld);
+            if (flag == F_UNCONNECT) continue;
+            const int pos = ((tslot - 1 - qslot) << 14) | (qsj & 16383);                // scan order: seeds descending, hits ascending
+            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + t_NM;
+            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo_ = (1 << 28) - 1 - pos;
+            if (hi > best_hi || (hi == best_hi && lo_ > best_lo)) { best_hi = hi; best_lo = lo_; best_b = b; best_f = flag; }
+            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }   // '-': first match precursor, :726-733
+        }
+        int w_b = -1, w_f = 0, w_score = t_score, w_nm = t_NM;
+        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
+        else if (best_b >= 0) {
+            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
+            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
+        }
+        if (w_b >= 0) {                                                                  // :753-761
+            const int q5 = CW(w_b, 5);
+            CW(a, 3) = (int)(((unsigned)w_score << 16) | (unsigned)(w_nm & 0xffff));
+            CW(a, 5) = (w_b << 24) | ((((q5 >> 16) & 0xff) + 1) << 16) | (CW(a, 5) & 0xff00) | w_f;
+            CW(w_b, 5) = (q5 & ~0xff00) | (w_f << 8);
+            any = true;
+        }
+    }
+    if (any) {
+        for (int a = 0; a < m; ++a) {
+            const int id = CW(a, 4), w2 = CW(a, 2), w3 = CW(a, 3), w5 = CW(a, 5);
+            const int b0 = (w2 & 0xffff) | ((sp & 0xff) << 16) | (((w2 >> 16) & 0xff) << 24);
+            hp_store16((HP_G char *)(gd + id) + 16, b0, MIN_FLAG | (((w5 >> 8) & 0xff) << 8) | ((w5 & 0xff) << 16), w3 >> 16, w3 & 0xffff);
+            const int f = (w5 >> 24) & 0xff;
+            g_from[id] = f == 0xff ? -1 : CW(f, 4);
+            g_node_n[id] = (w5 >> 16) & 0xff;
+        }
+    }
+#undef CW
+}
+
 // ---------------------------------------------------------------- the cluster in LDS
 // five arrays of `cap` words: W0 position relative to the cluster's first hit | W1 slot:14 j:14 dp_flag:4 |
 // W2 sid:15 len_dif:8 son_flag:5 match_flag:4 | W3 score:16 NM:16 | W4 (predecessor's index in the cluster + 1):16 node_n:16

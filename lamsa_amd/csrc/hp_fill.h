@@ -369,6 +369,164 @@ HP_INL bool split_mapping(ReadCtx &r, const FLines &F, int f1, int f2, Rec &res)
     return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
 }
 
+
+// ---------------------------------------------------------------- the junctions and single-seed fragments of a line without a memory
+// round trip each.  frag_check (:886-955) alternates frag_extend (:332) and split_mapping (:416) along the line; on a noisy read
+// nearly every fragment is one seed (its CIGAR is appended as it is) and nearly every junction is either "neighbouring seeds, no
+// read base in between" (a deletion of the reference bases between them) or a small DP whose CIGAR the lane-per-job launch has
+// left in the job arena.  Each of these steps is a merge_cigar (:251) whose inputs -- which seed, which CIGAR, its first and
+// last element, how far it advances -- do not depend on the steps before it.  They are worked out for 64 steps at a time, one
+// step per lane (the dependent loads of 64 steps overlap), and the sequential part keeps the last element of the growing CIGAR in
+// a register: appending is then a store, never a load.  Everything else (fragments of several seeds, SV junctions, DPs that were
+// not computed ahead, the boundary repair of merge_cigar) goes through the general routines above.
+struct JGeo { int s1, s2, at1_ld, at1_chr, did, s_qlen, dis, match_dis, cls, tl; int64_t at1_off, start0; };   // cls 0: general routine, 1: mismatch class with read bases, 2: without
+HP_INL void junction_geo(const ReadCtx &r, const FLines &F, int f1, int f2, JGeo &G)
+{   // split_mapping :424-470 and the window of its mismatch branch (:547-559, pac2fa_core bntseq.c:469-474)
+    const lamsa_hp_para *P = r.cx.P;
+    const int32_t *sd1 = F.fr_seed + F.fr_seed_off[f1], *sd2 = F.fr_seed + F.fr_seed_off[f2];
+    const int n1 = F.fr_seed_off[f1 + 1] - F.fr_seed_off[f1], n2 = F.fr_seed_off[f2 + 1] - F.fr_seed_off[f2];
+    if (r.h_strand[sd1[0]] == 1) { G.s1 = sd1[0]; G.s2 = sd2[n2 - 1]; } else { G.s1 = sd1[n1 - 1]; G.s2 = sd2[0]; }
+    G.at1_off = r.h_pos[G.s1]; G.at1_ld = r.h_len_dif[G.s1]; G.at1_chr = r.h_chr[G.s1];
+    G.did = sid(r, r.n_seed[G.s2]) - sid(r, r.n_seed[G.s1]);
+    G.s_qlen = G.did * P->seed_step - P->seed_len;
+    const int64_t exp = G.at1_off + G.at1_ld + (int64_t)(G.did * P->seed_step);
+    G.dis = (int)(r.h_pos[G.s2] - exp);
+    G.match_dis = P->match_dis * ((P->aln_mode & 2) ? G.did : 1);
+    G.cls = 0; G.tl = 0; G.start0 = 0;
+    if (G.s_qlen < 0 || G.dis > G.match_dis || G.dis < -G.match_dis || G.s_qlen + G.dis < 0) return;
+    G.start0 = G.at1_off + P->seed_len + G.at1_ld - 1;
+    const int32_t clen = r.ref.seq_len[G.at1_chr - 1];
+    if (G.start0 > clen || G.start0 < 0) return;
+    G.tl = G.s_qlen + G.dis;
+    if (G.start0 + G.tl > clen) G.tl = (int)(clen - G.start0);
+    G.cls = G.s_qlen > 0 ? 1 : 2;
+}
+
+struct MergeSrc { const cig_t *p; int n, first, last, reflen, readlen; };       // p == nullptr: a one-element CIGAR, the element in `first`
+
+// merge_cigar (:251-328) with _push_cigar (frag_check.h:158-184); `tail` = c1's last element (valid when c1.n > 0)
+HP_INL bool merge_fast(ReadCtx &r, CigV &c1, int &tail, int64_t *c1_refend, int *c1_readend, int chr, const MergeSrc &S)
+{
+    if (S.n == 0) return true;
+    Ctx &cx = r.cx;
+    const int n1 = c1.n;
+    if (n1 > 1) {
+        const int top = tail & 0xf, hop = S.first & 0xf;
+        if ((((top == C_I || top == C_D) && (tail >> 4) <= 3) && hop != C_S && hop != C_H) ||
+            (((hop == C_I || hop == C_D) && (S.first >> 4) <= 3) && top != C_S && top != C_H)) {           // boundary repair: the general routine
+            wv::sync();
+            bool ok;
+            if (S.p) ok = merge_cigar_full(r, c1, c1_refend, c1_readend, chr, S.p, S.n, S.reflen, S.readlen);
+            else {
+                const size_t mark = arena_mark(cx.tmp);
+                cig_t *w = (cig_t *)arena_alloc(cx, sizeof(cig_t));
+                ok = w != nullptr;
+                if (ok) { ((HP_G cig_t *)w)[0] = S.first; wv::sync(); ok = merge_cigar_full(r, c1, c1_refend, c1_readend, chr, w, 1, S.reflen, S.readlen); }
+                arena_release(cx.tmp, mark);
+            }
+            wv::sync();
+            tail = c1.n > 0 ? (int)((const HP_G cig_t *)c1.c)[c1.n - 1] : 0;
+            return ok;
+        }
+    }
+    HP_G cig_t *dst = (HP_G cig_t *)c1.c;
+    int j = 0;
+    if (n1 > 0) {
+        if ((tail & 0xf) == (S.first & 0xf)) { tail = tail + ((S.first >> 4) << 4); dst[n1 - 1] = tail; j = 1; }
+        else if (((tail & 0xf) == C_I && (S.first & 0xf) == C_S) || ((tail & 0xf) == C_S && (S.first & 0xf) == C_I)) { tail = (((tail >> 4) + (S.first >> 4)) << 4) | C_S; dst[n1 - 1] = tail; j = 1; }
+    }
+    const int m = S.n - j;
+    if (n1 + m > c1.cap) cx.status |= ST_OVERFLOW;
+    else if (m > 0) {
+        if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < m; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < m) dst[n1 + i] = src[j + i]; } } }
+        else dst[n1] = S.first;
+        c1.n = n1 + m; tail = S.last;
+    }
+    *c1_refend += S.reflen;
+    *c1_readend += S.readlen;
+    return true;
+}
+
+// the fragments f0 .. f0 + nfr - 1 of a line in the order frag_check walks them, with the junctions between them
+HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int strand, Rec &res)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const size_t mark = arena_mark(cx.tmp);
+    int32_t *pl = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 16 * 64);
+    if (!pl) return false;
+    HP_G int32_t *g_pl = (HP_G int32_t *)pl;
+    wv::sync();
+    int tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
+    bool ok = true;
+    for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
+        // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
+        WAVE_FOR(l) {
+            const int t = t0 + l;
+            int v[16];
+            for (int k = 0; k < 16; ++k) v[k] = 0;
+            if (t < nfr) {
+                const int f = strand == 1 ? f0 + nfr - 1 - t : f0 + t;
+                const int o0 = F.fr_seed_off[f], o1 = F.fr_seed_off[f + 1];
+                v[0] = o1 - o0 == 1;
+                if (v[0]) {
+                    const int s = F.fr_seed[o0];
+                    const int64_t co = r.h_cig_off[s]; const int cn = r.h_cig_n[s];
+                    v[1] = (int)(co & 0xffffffffll); v[2] = (int)(co >> 32); v[3] = cn; v[6] = P->seed_len + r.h_len_dif[s]; v[7] = r.h_chr[s];
+                    if (cn > 0) { v[4] = r.cig[co]; v[5] = r.cig[co + cn - 1]; }
+                }
+                if (t < nfr - 1) {
+                    const int f2 = strand == 1 ? f - 1 : f + 1;
+                    JGeo G; junction_geo(r, F, f, f2, G);
+                    v[8] = 3; v[15] = G.at1_chr;                                   // 3: the general routine
+                    if (G.cls == 2) { v[8] = G.tl > 0 ? 1 : 0; v[10] = 1; v[11] = v[12] = (G.tl << 4) | C_D; v[13] = G.tl; v[14] = 0; }       // 1: deletion of the bases between the seeds, 0: nothing
+                    else if (G.cls == 1) {
+                        const int32_t *jt = F.jt ? F.jt + 4 * (f < f2 ? f : f2) : nullptr;
+                        if (jt && jt[3] && F.jarena) { v[8] = 2; v[9] = jt[0]; v[10] = jt[1]; v[13] = jt[2]; v[14] = G.s_qlen; if (jt[1] > 0) { v[11] = F.jarena[jt[0]]; v[12] = F.jarena[jt[0] + jt[1] - 1]; } }   // 2: computed ahead
+                    }
+                }
+            }
+            for (int k = 0; k < 16; ++k) g_pl[k * 64 + l] = v[k];
+        }
+        wv::sync();
+        wv::Lane<int> V[16];
+        WAVE_FOR(l) { for (int k = 0; k < 16; ++k) V[k][l] = g_pl[k * 64 + l]; }
+        const int cnt = nfr - t0 < 64 ? nfr - t0 : 64;
+        for (int q = 0; q < cnt && ok; ++q) {
+            const int t = t0 + q, f = strand == 1 ? f0 + nfr - 1 - t : f0 + t;
+            // frag_extend, :332-410
+            if (wv::bcast(V[0], q)) {
+                MergeSrc S;
+                S.p = r.cig + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
+                S.reflen = wv::bcast(V[6], q); S.readlen = P->seed_len;
+                ok = merge_fast(r, res.cig, tail, &res.refend, &res.readend, wv::bcast(V[7], q), S) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+            } else {
+                wv::sync();
+                ok = frag_extend_multi(r, F, f, res);
+                wv::sync();
+                tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
+            }
+            if (!ok || t == nfr - 1) continue;
+            // split_mapping, :416-564
+            const int kind = wv::bcast(V[8], q);
+            if (kind == 3) {
+                wv::sync();
+                ok = split_mapping(r, F, f, strand == 1 ? f - 1 : f + 1, res);
+                wv::sync();
+                tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
+            } else if (kind != 0) {
+                MergeSrc S;
+                S.p = kind == 2 ? F.jarena + wv::bcast(V[9], q) : nullptr; S.n = wv::bcast(V[10], q); S.first = wv::bcast(V[11], q); S.last = wv::bcast(V[12], q);
+                S.reflen = wv::bcast(V[13], q); S.readlen = wv::bcast(V[14], q);
+                ok = merge_fast(r, res.cig, tail, &res.refend, &res.readend, wv::bcast(V[15], q), S) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+            } else ok = !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+        }
+    }
+    wv::sync();
+    arena_release(cx.tmp, mark);
+    return ok;
+}
+
 // ---------------------------------------------------------------- frag_head_bound_fix, :576-654
 HP_NOINL bool head_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
 {
@@ -640,8 +798,7 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
         r.cur_read = r.read; r.flip = false;
         if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
         ok = HP_TIMED(32, head_fix(r, F, line, r0));
-        for (int i = nfr - 1; i > 0 && ok; --i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i - 1, r0));
-        ok = ok && HP_TIMED(34, frag_extend(r, F, f0, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
+        ok = ok && HP_TIMED(34, frags_merge(r, F, f0, nfr, strand, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
         if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = ((r.L - (F.right_bound[line] - 1) * P->seed_step) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
     } else {
         if (!r.rc_ready) {                                            // :922-925 (buffer reserved when the read was set up)
@@ -654,8 +811,7 @@ HP_NOINL bool fill_line(ReadCtx &r, FLines &F, int line, LineRes &la, cig_t *cur
         F.left_bound[line] = r.seed_all + 1 - F.right_bound[line]; F.right_bound[line] = r.seed_all + 1 - tmp;
         if (F.left_bound[line] > 0) { const cig_t w = ((F.left_bound[line] * P->seed_step - P->seed_inv + r.last_len) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
         ok = HP_TIMED(32, head_fix(r, F, line, r0));
-        for (int i = 0; i < nfr - 1 && ok; ++i) ok = HP_TIMED(34, frag_extend(r, F, f0 + i, r0)) && HP_TIMED(36, split_mapping(r, F, f0 + i, f0 + i + 1, r0));
-        ok = ok && HP_TIMED(34, frag_extend(r, F, f0 + nfr - 1, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
+        ok = ok && HP_TIMED(34, frags_merge(r, F, f0, nfr, strand, r0)) && HP_TIMED(38, tail_fix(r, F, line, r0));
         if (ok && F.right_bound[line] <= r.seed_all) { const cig_t w = (((r.seed_all - F.right_bound[line] + 1) * P->seed_step - P->seed_inv) << 4) | C_S; cig_push1(cx, r0.cig, w); r0.readend += (int)(w >> 4); }
     }
     ok = ok && HP_TIMED(40, res_split(r, la, rec_buf, rec_cap)) && HP_TIMED(42, res_aux(r, la));

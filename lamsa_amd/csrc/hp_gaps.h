@@ -27,18 +27,6 @@ struct GapOut {                   // per lane
     int r_from, r_score, r_NM, r_nn, r_mf;     // the right anchor after the forced update (_tail == 1)
 };
 
-HP_INL int gap_edge(const EdgeK &K, int sp, int qpos, int qsid, int qld, int tpos, int tsid, int tld)
-{   // get_fseed_dis (:596-634) for two hits of the same contig and strand, the first of an earlier seed (cf. dp_cluster_lds)
-    const int dsid = tsid - qsid, span = dsid * K.seed_step;
-    if (span < K.seed_len) return F_UNCONNECT;
-    const int dis = sp * (tpos - qpos) - span - (sp > 0 ? qld : tld);
-    const int mat_dis = K.match_dis * (K.high_err ? dsid : 1);
-    if (dis <= mat_dis && dis >= -mat_dis) return dsid == 1 ? F_MATCH : (dsid <= K.mis3 ? F_MISMATCH : F_LONG_MISMATCH);
-    if (dis > mat_dis && dis < K.sv_len) return F_DELETE;
-    if ((dis < -mat_dis && dis >= 0 - (span - K.seed_len)) || (dis < -K.half_split && dis >= -K.sv_len)) return F_INSERT;
-    return F_UNCONNECT;
-}
-
 // One gap on one lane.  left >= 0 (the head), right >= 0 when tail, right_x = right's slot (or seed_out).  LDS strip: word w of
 // entry e at strip[(e * 6 + w) * 64].
 HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int left, int right, int left_x, int right_x, int tail, GapOut &O)
