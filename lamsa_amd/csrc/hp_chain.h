@@ -809,9 +809,10 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
 HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_flag, NScore &ns)
 {
     const HP_G NodeS *ns_ = (const HP_G NodeS *)r.nd;
-    const HP_G int32_t *g_in_de = (const HP_G int32_t *)r.n_in_de;
+    const HP_G int32_t *g_in_de = (const HP_G int32_t *)r.n_in_de, *g_from = (const HP_G int32_t *)r.n_from, *g_son_n = (const HP_G int32_t *)r.n_son_n;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const int64_t hb = r.hb;
+    const bool skip_lone = ns.min_score_thd > 1;
     for (int i0 = last_slot; i0 >= first_slot; i0 -= 63) {
         // hit offsets of up to 63 seeds (i0-62 .. i0) and the end of the last one, one per lane
         wv::Lane<int> ho;
@@ -823,7 +824,12 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
                 WAVE_FOR(l) {
                     const int k = b + l;
                     int v = 0;
-                    if (k < h1) { int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0; }
+                    if (k < h1) {
+                        int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0;
+                        // A hit without predecessor and without sons is a path of its own with score 1: node_add_score (:786) drops it when the
+                        // threshold is above that, and nothing reads what branch_track_new would leave in its own fields
+                        if (v && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) v = 0;
+                    }
                     leaf[l] = v;
                 }
                 for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) branch_track(r, b + __builtin_ctzll(m), ns);
@@ -1241,14 +1247,27 @@ HP_INL int firstx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.po
 HP_INL int lastx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.pool[L.start[l] + L.len[l] - 1]]; }
 
 HP_FN void sort_endpos(ReadCtx &r, LSet &L, int ls, int len, int32_t *tmp_pos)
-{   // line_sort_endpos, :12 -- end slot descending, stable (insertion sort; the goldens come from glibc's merge sort)
-    for (int i = 0; i < len; ++i) { L.rank[ls + i] = ls + i; tmp_pos[i] = lastx(r, L, ls + i); }
-    for (int i = 1; i < len; ++i) {
-        int p = tmp_pos[i], li = L.rank[ls + i], k = i - 1;
-        while (k >= 0 && tmp_pos[k] < p) { tmp_pos[k + 1] = tmp_pos[k]; L.rank[ls + k + 1] = L.rank[ls + k]; --k; }
-        tmp_pos[k + 1] = p; L.rank[ls + k + 1] = li;
+{   // line_sort_endpos, :12 -- end slot descending, stable (the goldens come from glibc's merge sort).  Every line finds its own
+    // place: the number of lines that end later, or as late and come first -- one line per lane, the keys of all lines streamed past
+    const HP_G int32_t *g_pool = (const HP_G int32_t *)L.pool, *g_start = (const HP_G int32_t *)L.start, *g_len = (const HP_G int32_t *)L.len, *g_seed = (const HP_G int32_t *)r.n_seed;
+    HP_G int32_t *g_tmp = (HP_G int32_t *)tmp_pos, *g_rank = (HP_G int32_t *)L.rank, *g_sel = (HP_G int32_t *)L.sel;
+    for (int i0 = 0; i0 < len; i0 += 64) { WAVE_FOR(l) { const int i = i0 + l; if (i < len) g_tmp[i] = g_seed[g_pool[g_start[ls + i] + g_len[ls + i] - 1]]; } }
+    wv::sync();
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        wv::Lane<int> key, place;
+        WAVE_FOR(l) { const int i = i0 + l; key[l] = i < len ? g_tmp[i] : 0; place[l] = 0; }
+        for (int j0 = 0; j0 < len; j0 += 64) {
+            wv::Lane<int> kj;
+            WAVE_FOR(l) { const int j = j0 + l; kj[l] = j < len ? g_tmp[j] : -0x7fffffff; }
+            const int cnt = len - j0 < 64 ? len - j0 : 64;
+            for (int q = 0; q < cnt; ++q) {
+                const int k = wv::bcast(kj, q), j = j0 + q;
+                WAVE_FOR(l) { const int i = i0 + l; place[l] += (k > key[l]) || (k == key[l] && j < i); }
+            }
+        }
+        WAVE_FOR(l) { const int i = i0 + l; if (i < len) { g_rank[ls + place[l]] = ls + i; g_sel[ls + i] = ls + place[l]; } }
     }
-    for (int i = 0; i < len; ++i) L.sel[L.rank[ls + i]] = ls + i;
+    wv::sync();
 }
 
 HP_FN int line_merge(ReadCtx &r, LSet &L, int a, int b, float ovlp_r)

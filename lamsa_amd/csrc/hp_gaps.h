@@ -19,6 +19,9 @@ namespace hp {
 
 #define HP_GAP_MCAP 6             // active hits of a gap a lane can hold (six words each in LDS)
 #define HP_GAP_RANGE 96           // hits in the seed range of a gap a lane will scan
+#ifndef HP_GAP_MIN
+#define HP_GAP_MIN 6              // lines with fewer gaps run them through the wave-wide routine
+#endif
 
 struct GapOut {                   // per lane
     int n;                        // nodes of the mini line (ascending), or -1: not handled here (fallback), -2: the reference's BUG exit
@@ -211,13 +214,16 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     }
     wv::sync();
     // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
+    // (a lane walks the hit range of its gap by itself, one dependent load after the other: that pays when many gaps share the wait,
+    // not for the two or three gaps of a short line)
+    const bool use_lanes = HP_CL_CAP_RT(1) > 0 && G >= HP_GAP_MIN;
     int pool_n = 0, d_score = 0, d_NM = 0;
     for (int g0 = 0; g0 < G; g0 += 64) {
         wv::Lane<int> nn, ds, dn;
         WAVE_FOR(l) {
             const int g = g0 + l;
             GapOut O; O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
-            if (g < G && g_left[g] >= 0 && HP_CL_CAP_RT(1) > 0) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
+            if (g < G && g_left[g] >= 0 && use_lanes) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
             nn[l] = g < G ? O.n : 0; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0;
             if (g < G) {
                 o_n[g] = O.n; o_ds[g] = O.d_score; o_dn[g] = O.d_NM; o_rf[g] = O.r_from; o_rs[g] = O.r_score; o_rn[g] = O.r_NM; o_rnn[g] = O.r_nn; o_rmf[g] = O.r_mf; o_lane[g] = O.n >= 0;
