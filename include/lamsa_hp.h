@@ -177,6 +177,12 @@ int lamsa_hp_finish_uploaded(lamsa_hp_handle *h, lamsa_hp_result *res);
 int lamsa_hp_submit_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch);
 int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res);
 
+/* Optional: allocate now, for both batches that can be in flight, what batches within the given bounds will need on the device
+ * (scratch, inter-launch state, input and output buffers) instead of inside the first submit / align call, where allocations of
+ * tens of GB cost seconds.  A caller that knows its chunk size calls it once after lamsa_hp_create -- from a thread of its own if it
+ * has input to read meanwhile (the handle must not be used concurrently).  Batches beyond the bounds still work; they allocate. */
+int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_bases, int64_t n_hits, int64_t n_cig, int32_t max_read_len, int32_t max_hits_per_read);
+
 /* Page-locked host memory for the arrays of a lamsa_hp_batch: copies from it run at the full PCIe rate and need no
  * staging pass through the runtime's bounce buffers.  Optional -- ordinary memory works everywhere. */
 void *lamsa_hp_host_alloc(size_t bytes);

@@ -470,6 +470,27 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
 }
 #endif
 
+// state of a batch between the launches (hp_phase.h) in one device buffer: per-hit arrays indexed by global hit index + read index,
+// the fragment, line and job arenas, the fill units and their cost-class queues, the job queues of the lane DP
+struct PhasedLayout { size_t bytes, o[13]; int unit_cap, lj_cap; int64_t fl_cap, line_cap, job_cap; };
+static PhasedLayout phased_layout(int n, int64_t n_hits, int64_t n_bases, int64_t stream_cap)
+{
+    PhasedLayout Y;
+    const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
+    Y.unit_cap = 8 * n + 1024;
+    Y.fl_cap = 4 * n_hits + 2048 * (int64_t)n + 4096; Y.line_cap = stream_cap + 64 * (int64_t)Y.unit_cap;
+    Y.job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + n_bases);          // CIGARs of the small DP jobs (~ 0.2 words per read base)
+    Y.lj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 16 * (int64_t)n + n_bases / 100);   // small DP jobs of a round (~ one per 150 read bases)
+    size_t off = 0;
+    auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
+    const size_t sz[13] = {sizeof(PhaseArgs), sizeof(PhaseCtl), sizeof(RdMeta) * ((size_t)n + 1), sizeof(NodeS) * n_ent, 4 * n_ent, 8 * n_ent, sizeof(UnitRec) * 2 * (size_t)Y.unit_cap,
+                           4 * 2 * (size_t)PH_NBUCKET * Y.unit_cap, 4 * (size_t)Y.fl_cap, 4 * (size_t)Y.line_cap, 4 * (size_t)Y.job_cap, sizeof(LjRec) * (size_t)Y.lj_cap, 4 * (size_t)LJ_NBUCKET * Y.lj_cap};
+    for (int k = 0; k < 13; ++k) Y.o[k] = place(sz[k]);
+    Y.bytes = off;
+    return Y;
+}
+static int64_t main_stream_cap(int n, int64_t n_bases) { return 1024 + (int64_t)n * 256 + 4 * n_bases; }
+
 // The main pass of the batch in slot `T` as the five launches of hp_phase.h, with the launch resources of slot `Ln`.
 static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, hipEvent_t e0, hipEvent_t e1)
 {
@@ -487,19 +508,10 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
     w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves);
-    // state between the launches (hp_phase.h): per-hit arrays indexed by global hit index + read index, the fragment and
-    // line arenas, the fill units and their cost-class queues
-    const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
-    const int unit_cap = 8 * n + 1024;
-    const int64_t fl_cap = 4 * (int64_t)n_hits + 2048 * (int64_t)n + 4096, line_cap = O.stream_cap + 64 * (int64_t)unit_cap;
-    const int64_t job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + T.n_bases);        // CIGARs of the small DP jobs (~ 0.2 words per read base)
-    const int lj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 16 * (int64_t)n + T.n_bases / 100);  // small DP jobs of a round (~ one per 150 read bases)
-    size_t off = 0;
-    auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
-    const size_t o_args = place(sizeof(PhaseArgs)), o_ctl = place(sizeof(PhaseCtl)), o_meta = place(sizeof(RdMeta) * ((size_t)n + 1)), o_nd = place(sizeof(NodeS) * n_ent), o_ns = place(4 * n_ent),
-                 o_sx = place(8 * n_ent), o_un = place(sizeof(UnitRec) * 2 * (size_t)unit_cap), o_bq = place(4 * 2 * (size_t)PH_NBUCKET * unit_cap),
-                 o_fl = place(4 * (size_t)fl_cap), o_ln = place(4 * (size_t)line_cap), o_jb = place(4 * (size_t)job_cap),
-                 o_lj = place(sizeof(LjRec) * (size_t)lj_cap), o_lq = place(4 * (size_t)LJ_NBUCKET * lj_cap);
+    const PhasedLayout Y = phased_layout(n, n_hits, T.n_bases, O.stream_cap);
+    const int unit_cap = Y.unit_cap, lj_cap = Y.lj_cap; const int64_t fl_cap = Y.fl_cap, line_cap = Y.line_cap, job_cap = Y.job_cap;
+    const size_t off = Y.bytes, o_args = Y.o[0], o_ctl = Y.o[1], o_meta = Y.o[2], o_nd = Y.o[3], o_ns = Y.o[4], o_sx = Y.o[5], o_un = Y.o[6], o_bq = Y.o[7], o_fl = Y.o[8], o_ln = Y.o[9],
+                 o_jb = Y.o[10], o_lj = Y.o[11], o_lq = Y.o[12];
     if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)Ln.pers.p;
     PhaseArgs a;
@@ -604,7 +616,7 @@ static int start_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln)
     if (rc) return rc;
     const int n = T.n_reads;
     if (n == 0) return LAMSA_HP_OK;
-    if (Ln.out1.ensure(n, 1024 + (int64_t)n * 256 + 4 * T.n_bases)) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
+    if (Ln.out1.ensure(n, main_stream_cap(n, T.n_bases))) { h->err = "hipMalloc(out)"; return LAMSA_HP_ENOMEM; }
     Ln.phased = false;
     if (!g_mono) return launch_phased(h, S, T, Ln, Ln.out1, Ln.e0, Ln.e1);
     return launch_align(h, S, T, Ln, Ln.out1, T.d_order, n, 1, T.max_L, T.max_H, Ln.e0, Ln.e1, false);
@@ -782,6 +794,33 @@ extern "C" void *lamsa_hp_host_alloc(size_t bytes)
     return p;
 }
 extern "C" void lamsa_hp_host_free(void *p) { if (p) hipHostFree(p); }
+
+// Allocate, ahead of the first batch, what batches of up to n_reads reads / n_bases bases / n_hits hits / n_cig seed-CIGAR elements
+// with reads of up to max_read_len bases need on the device, for both batches that can be in flight: device allocations of tens of
+// GB take seconds, and without this call they happen inside the first submit / align call.  Later batches within these bounds
+// allocate nothing.
+extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_bases, int64_t n_hits, int64_t n_cig, int32_t max_read_len, int32_t max_hits_per_read)
+{
+    if (!h || n_reads < 0 || n_bases < 0 || n_hits < 0 || n_cig < 0) return LAMSA_HP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
+    AlignState *S = state_of(h);
+    if (S->n_fifo || S->n_res) { h->err = "batches are in flight"; return LAMSA_HP_EINVAL; }
+    size_t slab_per_wave = slab_bytes_for(h->para, max_read_len, max_hits_per_read, 1);
+    if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
+    int n_waves = h->n_cu * 16;
+    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    const int64_t cap = main_stream_cap(n_reads, n_bases);
+    const PhasedLayout Y = phased_layout(n_reads, n_hits, n_bases, cap);
+    // the packed input of a batch (upload_into): every array plus its 256-byte alignment, both CIGAR forms' staging included
+    const size_t in_bytes = (size_t)n_bases + 16 * (size_t)n_reads * 4 + 32 * ((size_t)n_hits + n_reads) + 8 * (size_t)n_hits + 5 * (size_t)n_cig + 64 * 256 + 4096;
+    for (Slot &T : S->slot) {
+        int rc = slot_events(h, T);
+        if (rc) return rc;
+        if (T.slab.ensure(slab_per_wave * (size_t)n_waves) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) { h->err = "hipMalloc(reserve)"; return LAMSA_HP_ENOMEM; }
+    }
+    if (S->stream.ensure(4 * (size_t)cap / 4 + 64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
+    return LAMSA_HP_OK;
+}
 
 extern "C" int lamsa_hp_set_scratch_limit(lamsa_hp_handle *h, size_t bytes)
 {

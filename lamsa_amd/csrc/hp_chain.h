@@ -233,12 +233,6 @@ HP_NOINL void nodes_per_init(ReadCtx &r, int k0, int k1, int from, int dp_flag, 
 // `sons`: maintain the son lists (fnode_add_son).  They are read only by branch tracking, which runs after the main
 // pass of the first round and after the pass of frag_mini_dp_multi_line; both start from nodes that fnode_set has just
 // reset, so the lists a frag_mini_dp_line pass would leave behind are never read and that pass skips them.
-#ifdef HP_EMU_STATS
-void hp_emu_stat_call(int range, int lo, int hi, bool force);
-void hp_emu_stat_due(int range, int due, int span);
-void hp_emu_stat_run(int n, int is_run);
-static int g_emu_act = 0;
-#endif
 struct ScanT { NodeS T; int tkey, x, t_NM; long long Rw; };
 
 HP_INL NodeS node_unpack(const int *a, const int *b)
@@ -333,10 +327,6 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             c[l] = due;
         }
         unsigned long long todo = force ? 1ull : wv::ballot(c);
-#ifdef HP_EMU_STATS
-        if (tb == k0) { int act_ = 0; for (int q_ = hoff(r, start_slot); q_ < k1; ++q_) act_ += r.nd[q_].dp_flag == dp_flag; g_emu_act = act_; hp_emu_stat_call(k1 - k0, hoff(r, start_slot) , k1, force); }
-        hp_emu_stat_due(k1 - k0, __builtin_popcountll(todo), g_emu_act);
-#endif
 #ifdef HP_PROF
         if (r.prof) { r.prof[17] += wv::clock() - tp0_; r.prof[22] += 1; }
 #endif
@@ -1092,9 +1082,6 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
     int rlo, rhi;
     reach_run(r, anchor, Rw, &rlo, &rhi);
     const int R = rhi - rlo + 1;
-#ifdef HP_EMU_STATS
-    hp_emu_stat_run(R, head < 0);
-#endif
     if (R > 2048) return -1;
     const size_t mark = arena_mark(r.cx.tmp);
     int32_t *list = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(R + 64));
@@ -1124,9 +1111,6 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
         }
         wv::sync();
     }
-#ifdef HP_EMU_STATS
-    hp_emu_stat_run(n, 2 + (head < 0));
-#endif
     int ret = -1;
     if (n <= 64) ret = mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);
     else if (n <= 64 * HP_MS_MAX_SETS) ret = mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);

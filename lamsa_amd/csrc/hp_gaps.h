@@ -182,6 +182,22 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     HP_G int32_t *g_anc = (HP_G int32_t *)anc, *g_ancx = (HP_G int32_t *)anc_x;
     for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ancx[i0 + l] = g_seed[g_anc[i0 + l]]; } }
     wv::sync();
+    // Most lines of a read against a repeat-rich genome are a few hits of neighbouring seed slots at some repeat copy: no gap at all.
+    {
+        int any_gap = anc_x[0] < seed_out - 1;
+        for (int i0 = 0; i0 < A && !any_gap; i0 += 64) {
+            wv::Lane<int> ex;
+            WAVE_FOR(l) { const int i = i0 + l; ex[l] = i < A && (i + 1 < A ? g_ancx[i + 1] : -1) < g_ancx[i] - 1; }
+            any_gap = wv::ballot(ex) != 0;
+        }
+        if (!any_gap) {
+            HP_G int32_t *g_ln0 = (HP_G int32_t *)ln;
+            for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ln0[i0 + l] = g_anc[i0 + l]; } }
+            wv::sync();
+            arena_release(cx.tmp, mark);
+            return A;
+        }
+    }
     // ---- the gaps: [0] beyond the end node (when it is not of the last seed slot), then after anchor i when the next anchor (or
     // START) is more than one slot below.  Per gap: left, right, left_x, right_x, tail, the anchor it follows (-1: the first kind)
     const int GA = A + 2;

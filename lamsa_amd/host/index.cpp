@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 #include <zlib.h>
+#include "lamsa_host.h"
 
 namespace lamsa {
 
@@ -177,7 +178,7 @@ int run_index(const std::string &fasta, const std::string &gem_dir, bool with_ge
     if (!probe) { fprintf(stderr, "[lamsa_index] gem-indexer not found at %s (it ships with the reference; give its directory with --gem-dir, or pass --no-gem)\n", indexer.c_str()); return 1; }
     fclose(probe);
     fprintf(stderr, "[lamsa_index] Executing gem-indexer ... ");
-    const std::string cmd = "PATH=\"$PATH:" + gem_dir + "\" '" + indexer + "' -i '" + fasta + "' -o '" + fasta + "' >/dev/null 2>/dev/null";
+    const std::string cmd = "PATH=\"$PATH\":" + lamsa::shell_quote(gem_dir) + " " + lamsa::shell_quote(indexer) + " -i " + lamsa::shell_quote(fasta) + " -o " + lamsa::shell_quote(fasta) + " >/dev/null 2>/dev/null";
     if (system(cmd.c_str()) != 0) { fprintf(stderr, "\n[lamsa_index] Indexing undone, gem-indexer exit abnormally.\n"); return 1; }
     remove((fasta + ".log").c_str());
     fprintf(stderr, "done!\n");

@@ -611,7 +611,7 @@ int run_seeding(const Options &opt, const lamsa_hp_para &P)
     char num[256];
     snprintf(num, sizeof num, " -m %f -e %f --min-matched-bases %f --max-big-indel-length 3 -d %d -D 0 -T %d %s", mis, ed, mat, P.per_aln_m, opt.n_thread > 0 ? opt.n_thread : 1,
              opt.fastest ? "--fast-mapping=0" : "--fast-mapping");
-    const std::string cmd = "'" + mapper + "' -I '" + idx + "' -i '" + seed_f + "' -o '" + outp + "'" + num + " 2>> '" + outp + ".log'";
+    const std::string cmd = shell_quote(mapper) + " -I " + shell_quote(idx) + " -i " + shell_quote(seed_f) + " -o " + shell_quote(outp) + num + " 2>> " + shell_quote(outp + ".log");
     fprintf(stderr, "[lamsa_aln] Executing gem-mapper ... \n");
     if (system(cmd.c_str()) != 0) { fprintf(stderr, "[lamsa_aln] Seeding undone, gem-mapper exit abnormally.\n"); return 1; }
     fprintf(stderr, "[lamsa_aln] gem-mapper done!\n");
@@ -762,6 +762,9 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         return c;
     };
     std::future<Chunk *> scanned = std::async(std::launch::async, scan);
+    // Device buffers (scratch slabs, inter-launch state, input / output: tens of GB) are allocated while the first chunk is being
+    // parsed, sized from that chunk, instead of inside the first submit.
+    std::thread reserver; double reserve_s = 0;
     auto prepare = [&]() -> Chunk * {
         const double t0 = now_s();
         Chunk *c = scanned.get();
@@ -769,6 +772,17 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         Batch &B = c->B;
         const int n = (int)B.reads.size();
         if (n == 0 || c->ret) return c;
+        if (n_scanned <= 2 && !reserver.joinable() && !opt.parse_only && !hs.empty()) {
+            int64_t nb = 0; int max_len = 0;
+            for (const Read &rd : B.reads) { nb += (int64_t)rd.seq.size(); max_len = std::max(max_len, (int)rd.seq.size()); }
+            const int32_t r_n = (int32_t)std::max(n, opt.chunk_reads > n ? std::min(opt.chunk_reads, 2 * n) : n);
+            const int64_t r_nb = nb + nb / 4 + 4096;
+            reserver = std::thread([&hs, &reserve_s, r_n, r_nb, max_len]() {
+                const double t = now_s();
+                for (lamsa_hp_handle *hh : hs) lamsa_hp_reserve(hh, r_n, r_nb, r_nb / 3, 3 * r_nb, 2 * max_len + 1024, 16384);
+                reserve_s = now_s() - t;
+            });
+        }
         if (c->mapped) { parse_s += now_s() - t0; return c; }
         const double t1 = now_s();
         // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
@@ -802,6 +816,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!B.cig_wide && !hb.cig8) hb.cig8 = &zero8;
         if (!hb.read_seq) hb.read_seq = &zero8;
         }
+        if (reserver.joinable()) reserver.join();
         const double t0 = now_s();
         ck.dev = (int)(n_submitted++ % G);
         const int e = lamsa_hp_submit_batch(hs[(size_t)ck.dev], &hb);
@@ -929,10 +944,11 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();
     saver.close();
+    if (reserver.joinable()) reserver.join();
     for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh);
     if (h_dp) lamsa_hp_destroy(h_dp);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
-                 stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; }
+                 stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; stats->reserve_s = reserve_s; }
     return ret;
 }
 

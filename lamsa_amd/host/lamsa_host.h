@@ -58,6 +58,9 @@ struct ReadResult { int status = 0; std::vector<Line> stage[3]; };   // aln_res[
 void parse_stream(const int32_t *s, int n_words, int read_len, ReadResult &R);
 void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P);
 
+// a path as one word of a POSIX shell command line: wrapped in single quotes, embedded ones spelled '\''
+inline std::string shell_quote(const std::string &p) { std::string o = "'"; for (char c : p) { if (c == '\'') o += "'\\''"; else o += c; } return o + "'"; }
+
 struct Options {
     std::string ref_prefix, reads, seed_result;
     int supp_soft = 0, comm = 0, device = 0, n_thread = 1;
@@ -72,7 +75,7 @@ struct Options {
     int chunk_reads = 16384; int64_t chunk_bases = 256ll << 20;     // reads per GPU batch (the reference's CHUNK_READ_N is 128 per thread pool)
 };
 struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
-               double wall_s = 0, load_s = 0, parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0; };   // where the chunk loop's time went
+               double wall_s = 0, load_s = 0, parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0, reserve_s = 0; };   // where the chunk loop's time went
 
 void sam_header(std::string &o, const Index &ix, const std::string &pg);
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);

@@ -46,7 +46,7 @@ int main(int argc, char *argv[])
     for (int i = 1; i < argc; ++i) { pg += " "; pg += argv[i]; }
     lamsa_hp_para P; lamsa_hp_para_init(&P);
     lamsa::Options opt;
-    { unsigned hw = std::thread::hardware_concurrency(); opt.n_thread = hw ? (int)(hw > 32 ? 32 : hw) : 1; }   // -t: host threads for parsing and SAM text (the reference defaults to 1)
+    opt.n_thread = 1;                                  // -t: host threads for parsing, stage (4) and SAM text; 1 unless given, like the reference (src/lamsa_aln.c:1293)
     FILE *out = stdout; char *p; int c;
     static const struct option lopt[] = {
         {"thread",1,0,'t'},{"seed-len",1,0,'l'},{"seed-inv",1,0,'i'},{"max-loci",1,0,'p'},{"SV-len",1,0,'V'},{"ovlp-rat",1,0,'v'},
@@ -118,8 +118,8 @@ int main(int argc, char *argv[])
     fprintf(stderr, "[lamsa_aln] Mapping reads to genome ...\n");
     int rc = lamsa::run_aln(opt, P, out, pg, &st);
     fprintf(stderr, "[lamsa_aln] Mapping done! %ld reads, %ld bases, GPU kernels %.1f ms%s\n", st.n_reads, st.n_bases, st.kernel_ms, st.n_bad ? " (some reads reported unmapped, see above)" : "");
-    fprintf(stderr, "[lamsa_aln] wall %.2f s: index load + device setup %.2f; in the chunk loop (overlapping): read + parse %.2f, check + upload %.2f, wait for the GPU %.2f, rank + SAM %.2f\n",
-            st.wall_s, st.load_s, st.parse_s, st.submit_s, st.wait_s, st.sam_s);
+    fprintf(stderr, "[lamsa_aln] wall %.2f s: index load + device setup %.2f; device buffers reserved in %.2f (beside the parse of the first chunk); in the chunk loop (overlapping): read + parse %.2f, check + upload %.2f, wait for the GPU %.2f, rank + SAM %.2f\n",
+            st.wall_s, st.load_s, st.reserve_s, st.parse_s, st.submit_s, st.wait_s, st.sam_s);
     if (out != stdout) fclose(out);
     return rc;
 }

@@ -58,7 +58,7 @@ EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lam
            "lamsa_hp_last_error", "lamsa_hp_dp_batch", "lamsa_hp_last_kernel_ms", "lamsa_hp_set_scratch_limit",
            "lamsa_hp_align_batch", "lamsa_hp_upload_batch", "lamsa_hp_run_uploaded",
            "lamsa_hp_submit_batch", "lamsa_hp_collect_batch", "lamsa_hp_host_alloc", "lamsa_hp_host_free",
-           "lamsa_hp_start_uploaded", "lamsa_hp_finish_uploaded")
+           "lamsa_hp_start_uploaded", "lamsa_hp_finish_uploaded", "lamsa_hp_reserve")
 
 _lib = None
 

@@ -93,6 +93,7 @@ extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
     res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(2 * h->tb.size() + 2, 0); res->read_work = h->work.data();
     return LAMSA_HP_OK;
 }
+extern "C" int lamsa_hp_reserve(lamsa_hp_handle *, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t) { return LAMSA_HP_OK; }
 extern "C" void *lamsa_hp_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 extern "C" void lamsa_hp_host_free(void *p) { free(p); }
 

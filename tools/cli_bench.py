@@ -25,7 +25,7 @@ print("files written in %.1f s: %d reads, %.0f hits/read, map %.1f MB" % (time.t
 batch = sys.argv[4] if len(sys.argv) > 4 else "2048"
 for rep, extra in enumerate((["--parse-only"], ["--save-hits", d + "/hits.bin"], [], ["--hits", d + "/hits.bin", "--parse-only"], ["--hits", d + "/hits.bin"], ["--hits", d + "/hits.bin"])):
     t = time.time()
-    p = subprocess.run([os.path.join(ROOT, "lamsa_amd", "bin", "lamsa"), "aln", "-N", "-T", "ont2d", "-R", "0", "--batch", batch, "-o", d + "/out.sam"] + extra + [d + "/ref.fa", d + "/reads.fa"],
+    p = subprocess.run([os.path.join(ROOT, "lamsa_amd", "bin", "lamsa"), "aln", "-N", "-T", "ont2d", "-R", "0", "-t", str(min(threads, 32)), "--batch", batch, "-o", d + "/out.sam"] + extra + [d + "/ref.fa", d + "/reads.fa"],
                        capture_output=True, text=True)
     dt = time.time() - t
     print("run %d %s: rc %d, %.2f s wall -> %.0f reads/s end to end" % (rep, " ".join(extra), p.returncode, dt, n / dt))
