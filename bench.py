@@ -69,6 +69,28 @@ def count_mapped_bases(B, streams):
     return tot
 
 
+LAUNCH_KEYS = ["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2", "lane_dp1_within_fill1"]
+
+
+def measured_profile(workload, reads):
+    """Per-kernel figures from the committed rocprofv3 passes of this workload and batch size (profiles/r*_<workload>_pmc.json, written
+    by tools/summarize_prof.py from separate --pmc passes of this same command): HBM bytes per step (FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md + WRITE_SIZE = upper bound), VALU issue fraction.  bench.py cannot collect counters itself; empty
+    when no profile of this workload and batch size is committed."""
+    import glob
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("reads_per_step") == reads and "kernels" in d:
+            out = {k: v for k, v in d["kernels"].items()}
+            out["_source"] = "profiles/" + os.path.basename(f)
+            out["_step_upper"] = d.get("hbm_bytes_per_step_upper"); out["_step_lower"] = d.get("hbm_bytes_per_step_lower")
+    return out
+
+
 def measured_traffic(workload, reads):
     """HBM bytes per launch of k_align_batch from the committed PMC passes (profiles/*_final_pmc.json: FETCH_SIZE doubled
     per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command).
@@ -221,12 +243,35 @@ def main():
 
     if rank == 0:
         alg_bytes, parts = algorithmic_bytes(B, streams, tbases)
+        lm = dict(zip(LAUNCH_KEYS, [float(x) for x in np.mean(np.array(phase_ms), axis=0)]))
+        work = np.array(h.last_work, dtype=np.int64).reshape(-1, 2) if len(h.last_work) else np.zeros((1, 2), np.int64)
+        cells, pairs = int(work[:, 0].sum()), int(work[:, 1].sum())
         k_ms = float(np.mean(kernel_ms))
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(a.workload, a.reads)
-        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_align_batch", "kernel_ms": round(k_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts}
+        # The hot path is a sequence of launches per step (hp_phase.h); algorithmic bytes split by what each reads and writes once:
+        # chaining reads the hit records (20 B per hit), the fill group (job listing, lane DP, fill) the read bases, the seed CIGARs,
+        # the 2-bit reference windows, and writes the records and their CIGARs.
+        fill_ms = lm["fill1"] + lm["fill2"]
+        groups = [("k_chain1+k_chain2", lm["chain1"] + lm["chain2"], 20 * parts["H"]),
+                  ("k_filllist+k_filldp_small+k_fill", fill_ms, alg_bytes - 20 * parts["H"])]
+        dom = max(groups, key=lambda g: g[1])
+        dom_kernel = "k_fill" if dom[0].startswith("k_fill") else "k_chain1"
+        dom_ms = (lm["fill1"] - lm["lane_dp1_within_fill1"]) if dom_kernel == "k_fill" else lm["chain1"]
+        dom_bytes = dom[2]
+        achieved = dom_bytes / max(dom_ms, 1e-6) / 1e6
+        prof = measured_profile(a.workload, a.reads)
+        roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
+                "traffic": prof.get(dom_kernel, {}).get("hbm_bytes_per_step_upper"), "traffic_source": prof.get("_source"),
+                "kernel": dom_kernel, "kernel_ms": round(dom_ms, 3), "algorithmic_bytes_per_launch": int(dom_bytes),
+                "note": "dominant launch of the step (HIP events on the launches' own stream%s); its algorithmic bytes = the terms of B_read its group touches" % (
+                        "; with steps queued two deep the launches of two steps share the GPU, so event intervals overlap" if not a.sequential else ""),
+                "whole_step": {"algorithmic_bytes": int(alg_bytes), "launch_ms_sum": round(k_ms, 3), "achieved_GBps": round(alg_bytes / max(k_ms, 1e-6) / 1e6, 3),
+                               "hbm_traffic_bytes_upper": prof.get("_step_upper"), "hbm_traffic_bytes_lower": prof.get("_step_lower")},
+                "launch_groups": [{"launches": g[0], "ms": round(g[1], 3), "algorithmic_bytes": int(g[2]), "achieved_GBps": round(g[2] / max(g[1], 1e-6) / 1e6, 3)} for g in groups],
+                "bytes_per_read": round(alg_bytes / a.reads, 1), "terms": parts,
+                # the compute side: DP cell updates and chaining edge classifications actually executed
+                "dp_cells_per_step": cells, "gcups": round(cells * a.steps * world / dt / 1e9, 3), "gcups_within_fill_launches": round(cells / max(fill_ms, 1e-6) / 1e6, 3),
+                "pair_evals_per_step": pairs, "pair_evals_per_s": round(pairs * a.steps * world / dt, 1), "pair_evals_per_s_within_chain_launches": round(pairs / max(lm["chain1"] + lm["chain2"], 1e-6) * 1e3, 1),
+                "valu_issue_frac": {k: v.get("valu_issue_frac") for k, v in prof.items() if isinstance(v, dict) and v.get("valu_issue_frac") is not None} or None}
         t_pcie = r_seq = float("nan")
         if not a.bare:
             # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`
@@ -280,8 +325,7 @@ def main():
             "pcie_inclusive_reads_per_s": None if a.bare else round(a.reads / t_pcie, 2),
             "pcie_inclusive_streamed_reads_per_s": {"pageable_host_arrays": r_stream, "pinned_host_arrays": r_stream_pinned, "chunks": a.stream_chunks},
             "setup_s": {"reference": round(t_ref, 1), "reads_and_hits": round(t_gen, 1)},
-            "launch_ms": dict(zip(["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2", "lane_dp1_within_fill1"],
-                                  [round(float(x), 3) for x in np.mean(np.array(phase_ms), axis=0)])),
+            "launch_ms": {k: round(v, 3) for k, v in lm.items()},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

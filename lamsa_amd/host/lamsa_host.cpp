@@ -20,7 +20,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <memory>
 #include <thread>
 #include <time.h>
@@ -711,14 +714,19 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
     // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
     // The chunk buffers are recycled.
-    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; int dev = 0; };
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; int dev = 0;
+                   int sub_rc = 0, col_rc = 0; lamsa_hp_result res; std::promise<void> collected; };
+    // One worker thread per device runs that device's submit / collect calls in the order they are queued (a handle is not
+    // thread-safe, and the copies of a submit block their caller): the uploads of different devices then run side by side.
+    struct DevQ { std::thread th; std::mutex m; std::condition_variable cv; std::deque<std::function<void()>> ops; bool stop = false; };
+    std::mutex stat_m;
     HitsWriter saver;
     if (!opt.save_hits.empty() && !from_hits && !saver.open(opt.save_hits, P)) { fprintf(stderr, "[lamsa_aln] Can't write hit stream %s\n", opt.save_hits.c_str()); return 1; }
-    std::vector<Chunk> pool((size_t)G + 6); int n_scanned = 0;      // scanning, parsing, submitted (G + 1), being written, slack
+    std::vector<Chunk> pool((size_t)2 * G + 6); int n_scanned = 0;  // scanning, parsing, submitted (2 per device), being written, slack
     std::vector<Batch> parts((size_t)threads);              // per-thread partial batches of the parse, recycled too
     const bool trace = getenv("LAMSA_TRACE") != nullptr;
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
-        Chunk *c = &pool[(size_t)(n_scanned++ % (G + 6))];
+        Chunk *c = &pool[(size_t)(n_scanned++ % (2 * G + 6))];
         Batch &B = c->B;
         B.clear(); c->ret = 0; c->span.clear(); c->mapped = false;
         if (eof) return c;
@@ -798,6 +806,20 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         parse_s += now_s() - t0;                            // one prepare() runs at a time
         return c;
     };
+    std::vector<std::unique_ptr<DevQ>> devq;
+    for (int g = 0; g < G; ++g) {
+        devq.emplace_back(new DevQ);
+        DevQ *q = devq.back().get();
+        q->th = std::thread([q]() {
+            for (;;) {
+                std::function<void()> op;
+                { std::unique_lock<std::mutex> lk(q->m); q->cv.wait(lk, [q] { return q->stop || !q->ops.empty(); }); if (q->ops.empty()) return; op = std::move(q->ops.front()); q->ops.pop_front(); }
+                op();
+            }
+        });
+    }
+    auto enqueue = [&](int dev, std::function<void()> op) { DevQ *q = devq[(size_t)dev].get(); { std::lock_guard<std::mutex> lk(q->m); q->ops.push_back(std::move(op)); } q->cv.notify_one(); };
+    auto stop_workers = [&]() { for (auto &q : devq) { { std::lock_guard<std::mutex> lk(q->m); q->stop = true; } q->cv.notify_one(); if (q->th.joinable()) q->th.join(); } };
     long n_submitted = 0;
     auto submit = [&](Chunk &ck) -> int {
         Batch &B = ck.B;
@@ -816,11 +838,9 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!B.cig_wide && !hb.cig8) hb.cig8 = &zero8;
         if (!hb.read_seq) hb.read_seq = &zero8;
         }
-        if (reserver.joinable()) reserver.join();
         const double t0 = now_s();
-        ck.dev = (int)(n_submitted++ % G);
         const int e = lamsa_hp_submit_batch(hs[(size_t)ck.dev], &hb);
-        submit_s += now_s() - t0;
+        { std::lock_guard<std::mutex> lk(stat_m); submit_s += now_s() - t0; }
         if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_submit_batch failed: %d %s\n", e, lamsa_hp_last_error(hs[(size_t)ck.dev])); return 2; }
         return 0;
     };
@@ -898,16 +918,27 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         return 0;
     };
     std::future<int> writer;                                 // the write_chunk task of the chunk collected last
+    std::vector<std::future<int>> dev_writer((size_t)G);     // per device: the write task that still reads the results of its last collect
     auto collect_and_write = [&](Chunk *ck) -> int {
-        if (writer.valid()) { const int e = writer.get(); if (e) return e; }      // its result buffers are about to be reused
-        lamsa_hp_result res;
-        const double t0 = now_s();
-        lamsa_hp_handle *hc = hs[(size_t)ck->dev];
-        const int e = lamsa_hp_collect_batch(hc, &res);
-        wait_s += now_s() - t0;
-        if (e != LAMSA_HP_OK) { fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", e, lamsa_hp_last_error(hc)); return 2; }
-        kernel_ms += lamsa_hp_last_kernel_ms(hc, 0) + lamsa_hp_last_kernel_ms(hc, 1);
-        writer = std::async(std::launch::async, write_chunk, ck, res);
+        // the results of a collect stay valid until the next collect on the same handle: the chunk collected from this device
+        // before must have been written
+        if (dev_writer[(size_t)ck->dev].valid()) { const int e = dev_writer[(size_t)ck->dev].get(); if (e) return e; }
+        ck->collected = std::promise<void>();
+        std::future<void> done = ck->collected.get_future();
+        enqueue(ck->dev, [&, ck]() {
+            const double t0 = now_s();
+            lamsa_hp_handle *hc = hs[(size_t)ck->dev];
+            ck->col_rc = ck->sub_rc ? ck->sub_rc : lamsa_hp_collect_batch(hc, &ck->res);
+            { std::lock_guard<std::mutex> lk(stat_m); wait_s += now_s() - t0; if (ck->col_rc == LAMSA_HP_OK) kernel_ms += lamsa_hp_last_kernel_ms(hc, 0) + lamsa_hp_last_kernel_ms(hc, 1); }
+            if (ck->col_rc != LAMSA_HP_OK && !ck->sub_rc) fprintf(stderr, "[lamsa_aln] lamsa_hp_collect_batch failed: %d %s\n", ck->col_rc, lamsa_hp_last_error(hc));
+            ck->collected.set_value();
+        });
+        done.wait();
+        if (ck->col_rc != LAMSA_HP_OK) return 2;
+        if (writer.valid()) { const int e = writer.get(); if (e) return e; }      // SAM text is written in input order, one chunk at a time
+        std::shared_future<int> sf = std::async(std::launch::async, write_chunk, ck, ck->res).share();
+        writer = std::async(std::launch::deferred, [sf]() { return sf.get(); });
+        dev_writer[(size_t)ck->dev] = std::async(std::launch::deferred, [sf]() { return sf.get(); });
         return 0;
     };
     // Two chunks are in flight on the device (lamsa_hp_submit_batch): while the GPU aligns chunk i-1, chunk i is
@@ -931,16 +962,20 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         const bool have = ret == 0 && !cur->B.reads.empty();
         if (have) {
             next = std::async(std::launch::async, prepare);  // overlaps with everything below
-            ret = submit(*cur);
-            if (!ret) flying.push_back(cur);
+            if (reserver.joinable()) reserver.join();
+            cur->dev = (int)(n_submitted++ % G); cur->sub_rc = 0;
+            enqueue(cur->dev, [&, cur]() { cur->sub_rc = submit(*cur); });       // on the device's own thread: the next chunk can go to the next device meanwhile
+            flying.push_back(cur);
         }
-        while (!flying.empty() && ((int)flying.size() > G || !have || ret)) {
+        while (!flying.empty() && ((int)flying.size() >= 2 * G || !have || ret)) {
             const int e = collect_and_write(flying.front()); if (e && !ret) ret = e;
             flying.pop_front();
         }
         if (!have || ret) break;
     }
     if (writer.valid()) { const int e = writer.get(); if (e && !ret) ret = e; }
+    for (auto &f : dev_writer) if (f.valid()) f.get();
+    stop_workers();
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();
     saver.close();

@@ -46,11 +46,17 @@ def test_end_to_end_files_at_scale(tmp_path):
     want = subprocess.run([os.path.join(ROOT, "oracle", "lamsa_oracle"), "aln", "-T", "ont2d", "-t", "16", "-R", "0", d + "/ref.fa", d + "/reads.fa"],
                           capture_output=True, text=True)
     assert want.returncode == 0, want.stderr[-2000:]
-    got = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "--batch", "300", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+    got = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", "16", "--batch", "300", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
     assert got.returncode == 0, got.stderr[-2000:]
     a, b = G.strip_pg(got.stdout), G.strip_pg(want.stdout)
     assert len(a.splitlines()) >= 1024 + 6
     assert a == b
+    # the binary hit stream on the MI355X: written beside a run, then aligned from (no GEM text, no parse) -- the same SAM both times
+    one = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", "16", "--batch", "300", "--save-hits", d + "/hits.bin", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+    assert one.returncode == 0 and G.strip_pg(one.stdout) == b, one.stderr[-2000:]
+    two = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", "4", "--hits", d + "/hits.bin", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+    assert two.returncode == 0 and G.strip_pg(two.stdout) == b, two.stderr[-2000:]
+    assert os.path.getsize(d + "/hits.bin") < 0.8 * os.path.getsize(d + "/reads.fa.seed.gem.map")      # compact form: one byte per seed-CIGAR element
 
 
 @pytest.mark.parametrize("name", G.RESCUE_SCENARIOS)

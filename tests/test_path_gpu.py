@@ -103,6 +103,43 @@ def test_hip_compact_cigar_form(tmp_path):
     h.close()
 
 
+def test_hip_batch_beyond_2_31_cigar_elements():
+    """131 072 reads x 10 kbp in ONE batch: 2.2 G seed-CIGAR elements, more than 32-bit offsets can address.  The compact form of the
+    boundary (one byte per element, offsets summed up on the device) takes it; every read comes back with status 0 and a sample
+    equals the oracle word for word.  The word form with its 32-bit offsets is refused with a message, not wrapped."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import simbatch
+    from lamsa_amd import hp
+    n = 131072
+    ref = simbatch.SimRef(1_000_000_000, n_contigs=12, seed=5, threads=16)
+    B = simbatch.SimBatch(ref, n, 10000, "ont2d", seed=77, threads=16)
+    assert B.n_cig > 0x7fffffff
+    P = hp.make_para("ont2d")
+    h = hp.LamsaHp(P, ref=(ref.pac, ref.l_pac, ref.seq_off, ref.seq_len))
+    with pytest.raises(RuntimeError, match="2\\^31"):
+        h.upload_batch(B)
+    Bc = hp.compact_batch(B)
+    h.upload_batch(Bc)
+    raw = h.run_uploaded(fetch=True, raw=True)
+    stream, r_off, r_len, status = raw
+    assert (np.asarray(status) == 0).all()
+    idx = list(range(0, n, 4099))[:32] + [n - 1]
+    lp = reflib.lo_para("ont2d")
+    # the sample for the oracle: its seed CIGARs re-based (in B they lie beyond what B's 32-bit offsets can say)
+    cn = np.asarray(B.h_cig_n, np.int64); off = np.concatenate([[0], np.cumsum(cn)])
+    sub = simbatch.take(B, idx)
+    hits = np.concatenate([np.arange(B.hit_off[B.seed_off[i]], B.hit_off[B.seed_off[i + 1]]) for i in idx])
+    sub.cig = np.concatenate([B.cig[off[k]:off[k + 1]] for k in hits] + [np.zeros(4, np.int32)])
+    sub.h_cig_off = np.concatenate([np.concatenate([[0], np.cumsum(cn[hits])[:-1]]), np.zeros(4, np.int64)]).astype(np.int32)
+    want = reflib.oracle_streams(sub, lp, 8)
+    for k, i in enumerate(idx):
+        got = stream[int(r_off[i]):int(r_off[i]) + int(r_len[i])].tolist()
+        assert got == want[k], i
+    h.close()
+
+
 def test_hip_rejects_a_megabase_read():
     """A read with more than 32767 seeds (1.2 Mbp at the 25-bp step) is refused with LAMSA_HP_EINVAL and a message: the
     device keeps seed ids in 16 bits, and wrapped ids would chain into wrong alignments with status 0."""
