@@ -22,7 +22,7 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
     a.cig_cap_off = cig_cap_off; a.cig = cig;
     std::vector<char> slab(slab_bytes);
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr;
-    static int32_t lds[HP_LDS_WORDS];
+    static thread_local int32_t lds[HP_LDS_WORDS];
     for (int j = 0; j < n; ++j) dp_run_job(a, j, 0, lds);
     return 0;
 }
@@ -46,7 +46,7 @@ static void emu_sort_index(const BatchIn &in, int n_reads, std::vector<int32_t> 
     const int64_t n_hits = n_reads ? in.hit_off[in.seed_off[n_reads]] : 0;
     srt.assign((size_t)n_hits + 1, 0); rnk.assign((size_t)n_hits + 1, 0);
     std::vector<uint64_t> keys((size_t)n_hits + 1, 0);
-    static uint64_t lw[HP_LDS_WORDS / 2];
+    static thread_local uint64_t lw[HP_LDS_WORDS / 2];
     int pb, cb; emu_sort_widths(in, n_reads, pb, cb);
     for (int r = 0; r < n_reads; ++r) {
         const int64_t hb = in.hit_off[in.seed_off[r]]; const int H = (int)(in.hit_off[in.seed_off[r + 1]] - hb);
@@ -102,7 +102,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr; a.out.read_work = nullptr; a.out.diag = nullptr;
     std::vector<char> slab(slab_bytes);
-    static int32_t lds[HP_LDS_WORDS];
+    static thread_local int32_t lds[HP_LDS_WORDS];
     if (scale == 1 && g_emu_phased) {
         // the product's main pass: chain1 -> fill -> chain2 -> fill -> publish, every phase over the whole batch before the next starts
         PhaseArgs p;
@@ -122,7 +122,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
         p.lj_cap = g_emu_lane_dp ? (int)(1024 + 64 * (int64_t)n + n_bases / 8) : 0;
         std::vector<LjRec> ljv((size_t)p.lj_cap + 1); std::vector<int32_t> ljq((size_t)LJ_NBUCKET * p.lj_cap + 1);
         p.ljobs = ljv.data(); p.lj_bucket = ljq.data();
-        static int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+        static thread_local int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
         PhaseCtl ctl; memset(&ctl, 0, sizeof ctl);
         p.g_nd = nd.data(); p.g_nseed = nseed.data(); p.g_sidx = sidx.data(); p.meta = meta.data(); p.units = units.data(); p.bucket_q = bq.data();
         p.fl_base = fl.data(); p.line_base = lines.data(); p.ctl = &ctl;
@@ -164,7 +164,7 @@ extern "C" int emu_lane_dp(const lamsa_hp_para *P, int n, const uint8_t *seq, co
     { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } }
     std::vector<uint8_t> z((size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
     std::vector<cig_t> cb((size_t)3 * HP_LJ_CIG * 64);
-    static int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+    static thread_local int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
     if (!lj_params_ok(P)) return -2;
     for (int j0 = 0; j0 < n; j0 += 64) {
         for (int l = 0; l < 64 && j0 + l < n; ++l) {

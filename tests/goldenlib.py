@@ -53,17 +53,18 @@ def stage_scenario(name, tmpdir):
     d = os.path.join(GOLD, name)
     for ext in (".ann", ".amb", ".pac", ".bwt", ".sa"):
         shutil.copy(os.path.join(GOLD, "ref", "ref.fa" + ext), os.path.join(tmpdir, "ref.fa" + ext))
-    shutil.copy(os.path.join(d, "reads.fa"), os.path.join(tmpdir, "reads.fa"))
-    with gzip.open(os.path.join(d, "reads.fa.seed.gem.map.gz"), "rb") as f, open(os.path.join(tmpdir, "reads.fa.seed.gem.map"), "wb") as g:
-        g.write(f.read())
+    for src, dst in (("reads.fa.gz", "reads.fa"), ("reads.fa.seed.gem.map.gz", "reads.fa.seed.gem.map")):
+        with gzip.open(os.path.join(d, src), "rb") as f, open(os.path.join(tmpdir, dst), "wb") as g:
+            g.write(f.read())
     args = open(os.path.join(d, "args.txt")).read().split()
-    gold = open(os.path.join(d, "golden_R0.sam")).read()
+    gold = gzip.open(os.path.join(d, "golden_R0.sam.gz"), "rt").read()
     return os.path.join(tmpdir, "ref.fa"), os.path.join(tmpdir, "reads.fa"), args, gold
 
 
 def golden_full(name):
     """SAM of the reference's default run (stage 4 on) for the scenarios where it differs from -R 0."""
-    return open(os.path.join(GOLD, name, "golden_full.sam")).read()
+    import gzip
+    return gzip.open(os.path.join(GOLD, name, "golden_full.sam.gz"), "rt").read()
 
 
 def strip_pg(text):

@@ -1,7 +1,7 @@
 """Whole-path golden fixtures: simulated reads -> real GEM seeding -> reference SAM.
 
-Shared index: tests/golden/ref/ref.fa.{ann,amb,pac,bwt,sa}.  For every scenario: tests/golden/<name>/{reads.fa,
-reads.fa.seed.gem.map.gz,args.txt,golden_R0.sam[,golden_full.sam if it differs]}.  `golden_R0.sam` is the
+Shared index: tests/golden/ref/ref.fa.{ann,amb,pac,bwt,sa}.  For every scenario: tests/golden/<name>/{reads.fa.gz,
+reads.fa.seed.gem.map.gz,args.txt,golden_R0.sam.gz[,golden_full.sam.gz if it differs]}.  `golden_R0.sam` is the
 reference run with `-N -I -R 0` (stage 4, the BWT rescue, disabled from the command line),
 `golden_full.sam` the default run.  Inputs and outputs only -- nothing of the reference's code.
 """
@@ -23,15 +23,15 @@ LAMSA = os.path.join(ROOT, "oracle", "_ref", "lamsa")
 
 REF = dict(seed=23, contigs=[260000, 140000], repeats=[(300, 260), (1000, 60), (6000, 12)])
 SCEN = [  # name, args, n_reads, length, profile, extra
-    ("c1_perfect", [], 16, 5000, "perfect", {}),
-    ("c2_pacbio", ["-T", "pacbio"], 10, 5000, "pacbio", {}),
-    ("c3_ont", ["-T", "ont2d"], 6, 10000, "ont", {}),
-    ("c4_pb20k", ["-T", "pacbio", "-w", "200"], 2, 20000, "pb20k", {}),
-    ("c5_sv", ["-V", "10000"], 10, 10000, "lowerr", {"sv_frac": 0.67}),
-    ("c6_edge", ["-T", "ont2d"], 6, 2500, "ont", {"n_frac": 0.01, "edge": True}),
+    ("c1_perfect", [], 100, 5000, "perfect", {}),
+    ("c2_pacbio", ["-T", "pacbio"], 100, 5000, "pacbio", {}),
+    ("c3_ont", ["-T", "ont2d"], 100, 10000, "ont", {}),
+    ("c4_pb20k", ["-T", "pacbio", "-w", "200"], 50, 20000, "pb20k", {}),
+    ("c5_sv", ["-V", "10000"], 100, 10000, "lowerr", {"sv_frac": 0.67}),
+    ("c6_edge", ["-T", "ont2d"], 100, 2500, "ont", {"n_frac": 0.01, "edge": True}),
     # stage 4 (BWT rescue): reads carrying 40-320 bp pieces of other loci between their flanks; default -R
-    ("c7_rescue", [], 14, 4000, "lowerr", {"rescue": True}),
-    ("c8_rescue_ont", ["-T", "ont2d"], 8, 6000, "ont", {"rescue": True}),
+    ("c7_rescue", [], 100, 4000, "lowerr", {"rescue": True}),
+    ("c8_rescue_ont", ["-T", "ont2d"], 100, 6000, "ont", {"rescue": True}),
 ]
 
 
@@ -103,18 +103,21 @@ def make_reads(only=None):
         os.makedirs(os.path.join(GOLD, "ref"), exist_ok=True)
         for ext in (".ann", ".amb", ".pac", ".bwt", ".sa"):      # .bwt / .sa: the FM index stage 4 searches
             shutil.copy(ref + ext, os.path.join(GOLD, "ref", "ref.fa" + ext))
-        shutil.copy(rd, os.path.join(d, "reads.fa"))
-        with open(rd + ".seed.gem.map", "rb") as f, gzip.GzipFile(os.path.join(d, "reads.fa.seed.gem.map.gz"), "wb", mtime=0) as g:
-            g.write(f.read())
+        for old in ("reads.fa", "golden_R0.sam", "golden_full.sam", "golden_full.sam.gz"):
+            if os.path.exists(os.path.join(d, old)):
+                os.remove(os.path.join(d, old))
+        for src, dst in ((rd, "reads.fa.gz"), (rd + ".seed.gem.map", "reads.fa.seed.gem.map.gz")):
+            with open(src, "rb") as f, gzip.GzipFile(os.path.join(d, dst), "wb", mtime=0) as g:
+                g.write(f.read())
         body = {}
         for kind in ("full", "R0"):
             with open(os.path.join(tmp, "%s.%s.sam" % (name, kind))) as f:
                 body[kind] = [l for l in f if not l.startswith("@PG")]
-        with open(os.path.join(d, "golden_R0.sam"), "w") as g:
-            g.writelines(body["R0"])
+        with gzip.GzipFile(os.path.join(d, "golden_R0.sam.gz"), "wb", mtime=0) as g:
+            g.write("".join(body["R0"]).encode())
         if body["full"] != body["R0"]:          # stage 4 (BWT rescue) changed the output: keep the default run too
-            with open(os.path.join(d, "golden_full.sam"), "w") as g:
-                g.writelines(body["full"])
+            with gzip.GzipFile(os.path.join(d, "golden_full.sam.gz"), "wb", mtime=0) as g:
+                g.write("".join(body["full"]).encode())
         with open(os.path.join(d, "args.txt"), "w") as f:
             f.write(" ".join(args) + "\n")
         sz = sum(os.path.getsize(os.path.join(d, x)) for x in os.listdir(d))
