@@ -818,7 +818,6 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
         if (rc) return rc;
         if (T.slab.ensure(slab_per_wave * (size_t)n_waves) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) { h->err = "hipMalloc(reserve)"; return LAMSA_HP_ENOMEM; }
     }
-    if (S->stream.ensure(4 * (size_t)cap / 4 + 64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
     return LAMSA_HP_OK;
 }
 

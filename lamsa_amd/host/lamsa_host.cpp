@@ -772,7 +772,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     std::future<Chunk *> scanned = std::async(std::launch::async, scan);
     // Device buffers (scratch slabs, inter-launch state, input / output: tens of GB) are allocated while the first chunk is being
     // parsed, sized from that chunk, instead of inside the first submit.
-    std::thread reserver; double reserve_s = 0;
+    std::thread reserver; double reserve_s = 0; bool reserve_started = false;
     auto prepare = [&]() -> Chunk * {
         const double t0 = now_s();
         Chunk *c = scanned.get();
@@ -780,14 +780,15 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         Batch &B = c->B;
         const int n = (int)B.reads.size();
         if (n == 0 || c->ret) return c;
-        if (n_scanned <= 2 && !reserver.joinable() && !opt.parse_only && !hs.empty()) {
+        if (!reserve_started && !opt.parse_only && !hs.empty()) {
+            reserve_started = true;
             int64_t nb = 0; int max_len = 0;
             for (const Read &rd : B.reads) { nb += (int64_t)rd.seq.size(); max_len = std::max(max_len, (int)rd.seq.size()); }
             const int32_t r_n = (int32_t)std::max(n, opt.chunk_reads > n ? std::min(opt.chunk_reads, 2 * n) : n);
             const int64_t r_nb = nb + nb / 4 + 4096;
             reserver = std::thread([&hs, &reserve_s, r_n, r_nb, max_len]() {
                 const double t = now_s();
-                for (lamsa_hp_handle *hh : hs) lamsa_hp_reserve(hh, r_n, r_nb, r_nb / 3, 3 * r_nb, 2 * max_len + 1024, 16384);
+                for (lamsa_hp_handle *hh : hs) lamsa_hp_reserve(hh, r_n, r_nb, r_nb / 3, 3 * r_nb, max_len + max_len / 4 + 256, 8192);
                 reserve_s = now_s() - t;
             });
         }
