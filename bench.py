@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=0, help="host threads for input generation and the CPU baseline (0 = every core of the box, os.cpu_count())")
     ap.add_argument("--sequential", action="store_true", help="wait for every step before starting the next (default: consecutive steps are queued two deep)")
-    ap.add_argument("--stream-chunks", type=int, default=8, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
+    ap.add_argument("--stream-chunks", type=int, default=16, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
                     "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")

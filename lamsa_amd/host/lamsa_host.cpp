@@ -718,7 +718,11 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                    int sub_rc = 0, col_rc = 0; lamsa_hp_result res; std::promise<void> collected; };
     // One worker thread per device runs that device's submit / collect calls in the order they are queued (a handle is not
     // thread-safe, and the copies of a submit block their caller): the uploads of different devices then run side by side.
-    struct DevQ { std::thread th; std::mutex m; std::condition_variable cv; std::deque<std::function<void()>> ops; bool stop = false; };
+    struct DevQ {
+        std::thread th; std::mutex m; std::condition_variable cv; std::deque<std::function<void()>> ops; bool stop = false;
+        void finish() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_one(); if (th.joinable()) th.join(); }   // runs what is queued, then ends
+        ~DevQ() { finish(); }                                   // every way out of run_aln (--parse-only, errors) ends the thread
+    };
     std::mutex stat_m;
     HitsWriter saver;
     if (!opt.save_hits.empty() && !from_hits && !saver.open(opt.save_hits, P)) { fprintf(stderr, "[lamsa_aln] Can't write hit stream %s\n", opt.save_hits.c_str()); return 1; }
@@ -820,7 +824,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         });
     }
     auto enqueue = [&](int dev, std::function<void()> op) { DevQ *q = devq[(size_t)dev].get(); { std::lock_guard<std::mutex> lk(q->m); q->ops.push_back(std::move(op)); } q->cv.notify_one(); };
-    auto stop_workers = [&]() { for (auto &q : devq) { { std::lock_guard<std::mutex> lk(q->m); q->stop = true; } q->cv.notify_one(); if (q->th.joinable()) q->th.join(); } };
+    auto stop_workers = [&]() { for (auto &q : devq) q->finish(); };
     long n_submitted = 0;
     auto submit = [&](Chunk &ck) -> int {
         Batch &B = ck.B;

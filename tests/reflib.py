@@ -209,6 +209,20 @@ def emu_cli():
     return out
 
 
+def emu_capi_lib():
+    """tests/_build/liblamsa_hp_emu.so: the C-ABI of include/lamsa_hp.h on the CPU lane emulation, as a shared library
+    (what tests/test_glue_cpu.py links the patched reference against instead of liblamsa_hp.so)."""
+    os.makedirs(EMU_DIR, exist_ok=True)
+    out = os.path.join(EMU_DIR, "liblamsa_hp_emu.so")
+    srcs = [os.path.join(ROOT, "tests", "emu", "emu_api.cpp"), os.path.join(ROOT, "tests", "emu", "emu_capi.cpp")]
+    deps = srcs + [os.path.join(ROOT, "include", "lamsa_hp.h"), os.path.join(ROOT, "tests", "emu", "hp", "wave.h")] + \
+        [os.path.join(ROOT, "lamsa_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "lamsa_amd", "csrc")) if f.endswith(".h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run(["g++"] + EMU_FLAGS + ["-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "tests", "emu"),
+                        "-I", os.path.join(ROOT, "lamsa_amd", "csrc"), "-o", out] + srcs + ["-lpthread"], check=True, cwd=EMU_DIR)
+    return out
+
+
 def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
     """Run DP jobs through the emulated device code (same kernel sources, CPU lanes)."""
     import sys

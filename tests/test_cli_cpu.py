@@ -92,6 +92,17 @@ def test_stage4_bwt_rescue_matches_reference_default_run(cli, name, tmp_path):
     assert G.strip_pg(q.stdout) == G.strip_pg(want_r0)
 
 
+def test_parse_only_ends(cli, tmp_path):
+    """--parse-only (read + parse, no alignment: the host-side rate of tools/cli_bench.py) must come back -- it once
+    left the per-device submit threads waiting -- and must write no alignments."""
+    ref, reads, args, _ = G.stage_scenario("c2_pacbio", str(tmp_path))
+    out = str(tmp_path / "out.sam")
+    p = subprocess.run([cli, "aln", "-N", "-t", "3", "--batch", "7", "--parse-only", "-o", out] + args + [ref, reads], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "100 reads" in p.stderr
+    assert all(l.startswith("@") for l in open(out).read().splitlines())
+
+
 def test_chunks_dealt_over_several_devices(cli, tmp_path):
     """--devices: one handle per listed device, chunks round-robin, output in input order (two handles on device 0 here)."""
     ref, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path))
