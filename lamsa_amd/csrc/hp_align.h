@@ -97,7 +97,7 @@ HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap,
 }
 
 // ---- one read's view of the batch (hp_batch.h) and its scratch ----
-HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, const BatchIn &in, int rd, char *slab, size_t slab_bytes, HP_L int32_t *lds, long long *prof, int lds_words = HP_LDS_WORDS)
+HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, const BatchIn &in, int rd, char *slab, size_t slab_bytes, HP_L int32_t *lds, long long *prof, int lds_words = HP_BOTH_LDS_WORDS)
 {
     r.cx.P = &P; r.cx.status = 0; r.cx.n_cells = 0; r.n_pairs = 0; r.cx.lds = lds; r.cx.lds_words = lds_words; r.cx.prof = prof ? prof + (size_t)rd * 64 : nullptr;
     arena_init(r.cx.tmp, slab, slab_bytes);
@@ -186,7 +186,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     if (o.w && r.rc_read && nm && sidx && sort_work && r.nd && G.beg && G.rb && G.r_beg) {
         const int c = H + 1;
         { HP_T0(t_sort_);
-        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
+        sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_BOTH_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
         HP_TADD(cx, 46, t_sort_); }
         arena_release(cx.tmp, sort_mark);
         r.srt = sidx; r.rnk = sidx + c;

@@ -22,7 +22,7 @@ using namespace hp;
 #endif
 __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs a)
 {
-    __shared__ int32_t lds[HP_LDS_WORDS];            // this wave's DP rows, query window and direction matrix (hp_ksw.h)
+    __shared__ int32_t lds[HP_BOTH_LDS_WORDS];       // chaining state or DP rows, query window and direction matrix (hp_ksw.h)
     const int slot = blockIdx.x;
     for (;;) {
         int u = 0;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
 #define HP_CHAIN_WAVES_PER_SIMD 4
 #endif
 #ifndef HP_FILL_WAVES_PER_SIMD
-#define HP_FILL_WAVES_PER_SIMD 4
+#define HP_FILL_WAVES_PER_SIMD 8
 #endif
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
 {
@@ -457,7 +457,9 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
         long long sum[64] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 64; ++k) sum[k] += pr[(size_t)r * 64 + k];
         fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
         fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles) targets %lld trips %lld init_Mcyc %lld\n", sum[11], sum[12], sum[13] / 1000000);
-        fprintf(stderr, "[HP_PROF] update_range: calls %lld total %lld prefilter %lld prologue %lld (Mcyc) chunks %lld | mini_line calls %lld tail+walk %lld Mcyc | forced %lld\n", sum[19], sum[16] / 1000000, sum[17] / 1000000, sum[18] / 1000000, sum[22], sum[21], sum[20] / 1000000, sum[23]);
+        fprintf(stderr, "[HP_PROF] line_build: %lld lines (%lld without a gap), %lld anchors, %lld gaps | Mcyc: anchor walk %lld, gap list %lld, gaps in lanes %lld, gaps one by one %lld, assembly %lld\n",
+                sum[21], sum[22], sum[12], sum[23], sum[16] / 1000000, sum[17] / 1000000, sum[18] / 1000000, sum[19] / 1000000, sum[20] / 1000000);
+        fprintf(stderr, "[HP_PROF] gaps: %lld in lines with fewer than HP_GAP_MIN gaps (%lld lines with gaps); lane gaps: %lld hits scanned, %lld refused (range too long or too many active hits)\n", sum[54], sum[55], sum[11], sum[13]);
         { const char *nm[] = {"ksw_global", "ksw_extend", "backtrack", "ref_fetch", "head_fix", "frag_extend", "split_mapping", "tail_fix", "res_split", "res_aux", "mini_line_regs", "sort index"};
           for (int k = 0; k < 12; ++k) fprintf(stderr, "[HP_PROF] %-16s %8lld Mcyc %10lld calls\n", nm[k], sum[24 + 2 * k] / 1000000, sum[25 + 2 * k]);
           fprintf(stderr, "[HP_PROF] direction-matrix bytes in HBM %lld (%lld jobs); hits passed through nodes_per_init %lld (%lld calls)\n", sum[52], sum[53], sum[54], sum[55]);

@@ -285,7 +285,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
     const int H = r.H;
 #ifdef HP_PROF
     const long long tu0_ = wv::clock();
-    if (r.prof) { r.prof[19] += 1; if (force) r.prof[23] += 1; }
+    if (r.prof) { r.prof[13] += 1; }
 #endif
     for (int tb = k0; tb < k1; tb += 64) {
 #ifdef HP_PROF
@@ -328,7 +328,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
         }
         unsigned long long todo = force ? 1ull : wv::ballot(c);
 #ifdef HP_PROF
-        if (r.prof) { r.prof[17] += wv::clock() - tp0_; r.prof[22] += 1; }
+        if (r.prof) { r.prof[13] += 1; }
 #endif
         if (!todo) continue;
 #ifdef HP_PROF
@@ -355,7 +355,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             }
         }
 #ifdef HP_PROF
-        if (r.prof) r.prof[18] += wv::clock() - tq0_;
+        if (r.prof) r.prof[13] += 1;
 #endif
         for (;;) {
             const int t = tb + li;
@@ -399,7 +399,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, out0, out1, okl;
             WAVE_FOR(l) {                                // first trip: the records are already here
 #ifdef HP_PROF
-                if (l == 0 && r.prof) r.prof[12] += 1;
+                if (l == 0 && r.prof) r.prof[13] += 1;
 #endif
                 key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0;
                 int ow[2], oka = 0;
@@ -420,7 +420,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
             int any_ok = wv::ballot(okl) != 0;
             for (int cc = 1; live0 || live1; ++cc) {     // wide windows (repeat clusters): further trips, fetched directly
 #ifdef HP_PROF
-                if (r.prof) r.prof[12] += 1;
+                if (r.prof) r.prof[13] += 1;
 #endif
                 {   const int lo_left = rT - cc * 64, hi_left = H - 1 - rT - cc * 64;
                     r.n_pairs += (live0 ? (lo_left < 0 ? 0 : (lo_left < 64 ? lo_left : 64)) : 0) + (live1 ? (hi_left < 0 ? 0 : (hi_left < 64 ? hi_left : 64)) : 0); }
@@ -502,7 +502,7 @@ HP_NOINL void dp_update_range(ReadCtx &r, int k0, int k1, int start_slot, int dp
         }
     }
 #ifdef HP_PROF
-    if (r.prof) r.prof[16] += wv::clock() - tu0_;
+    if (r.prof) r.prof[13] += 1;
 #endif
 }
 HP_INL void dp_update(ReadCtx &r, int t, int start_slot, int dp_flag, bool sons) { dp_update_range(r, t, t + 1, start_slot, dp_flag, true, sons); }
@@ -1146,7 +1146,7 @@ HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t
     dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false, false);      // callers guarantee left_x + 2 <= right_x
 #ifdef HP_PROF
     const long long tm0_ = wv::clock();
-    if (r.prof) r.prof[21] += 1;
+    if (r.prof) r.prof[13] += 1;
 #endif
     int max_score, max_NM = 0, max_n = 0, max_node = head;
     if (_tail == 0) {
@@ -1192,7 +1192,7 @@ HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t
     *de_score += max_score - old_score;
     *de_NM += max_NM - old_NM;
 #ifdef HP_PROF
-    if (r.prof) r.prof[20] += wv::clock() - tm0_;
+    if (r.prof) r.prof[13] += 1;
 #endif
     return max_n;
 }

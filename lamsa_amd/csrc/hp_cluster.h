@@ -224,7 +224,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
 // look-up and a write-back round trip per cluster for a handful of comparisons.  Here 64 such clusters are handled at once, one
 // per lane: the lane keeps the cluster's MIN hits (ascending hit order, from C.csrt) in its own strip of LDS -- six words each --
 // and runs frag_dp_update (:701-764) over them exactly as dp_cluster_lds does.
-#define HP_CLL_MCAP 6
+#define HP_CLL_MCAP (HP_LANE_STRIP_WORDS / 384 < 6 ? HP_LANE_STRIP_WORDS / 384 : 6)
 HP_INL int gap_edge(const EdgeK &K, int sp, int qpos, int qsid, int qld, int tpos, int tsid, int tld)
 {   // get_fseed_dis (:596-634) for two hits of the same contig and strand, the first of an earlier seed (cf. dp_cluster_lds)
     const int dsid = tsid - qsid, span = dsid * K.seed_step;

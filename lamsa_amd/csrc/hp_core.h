@@ -22,18 +22,25 @@ HP_INL size_t arena_mark(const Arena &a) { return a.top; }
 HP_INL void arena_release(Arena &a, size_t m) { a.top = m; }
 
 // LDS of one wave (= one workgroup): circular H and E rows, staged query bases, direction matrix (see hp_ksw.h).
-// Sized for 4 waves per SIMD = 16 workgroups per CU: 16 x 9.5 KB of the CU's 160 KB.  Bands up to w = 222 use the
+// Sized for the fill kernel's 8 waves per SIMD = 32 workgroups per CU (the hardware's limit): 32 x 5 KB of the CU's 160 KB.  The fill
+// kernel is bound by the latency each wave exposes, and every step up in occupancy paid even though it costs VGPRs (64 at 8 waves) and
+// LDS for the direction matrix (measured, ms per step of 65 536 reads: 4 waves / 5 KB matrix 326, 5 / 3.5 KB 322, 6 / 2.1 KB 307,
+// 7 / 1.2 KB 295, 8 / 0.5 KB 294 -- profiles/r02_variants_occupancy*.txt).  Bands up to w = 222 use the
 // LDS rows (the presets use 10..200); wider ones fall back to rows in HBM.
 #ifndef HP_LDS_CELLS
 #define HP_LDS_CELLS 512
 #endif
 #ifndef HP_LDS_Z_BYTES
-#define HP_LDS_Z_BYTES 5120
+#define HP_LDS_Z_BYTES 512
 #endif
 #define HP_LDS_WORDS (2 * HP_LDS_CELLS + HP_LDS_CELLS / 4 + HP_LDS_Z_BYTES / 4)
 #ifndef HP_CHAIN_LDS_WORDS
-#define HP_CHAIN_LDS_WORDS HP_LDS_WORDS      // LDS words of a wave of the chaining kernels (>= HP_SORT_BLOCK * 2 for the hit sort)
+#define HP_CHAIN_LDS_WORDS 2432             // LDS words of a wave of the chaining kernels (>= HP_SORT_BLOCK * 2 for the hit sort; 16 waves per CU)
 #endif
+// LDS words of a wave that runs BOTH halves (the one-kernel form of the retry pass, the CPU emulation): enough for either
+#define HP_BOTH_LDS_WORDS (HP_CHAIN_LDS_WORDS > HP_LDS_WORDS ? HP_CHAIN_LDS_WORDS : HP_LDS_WORDS)
+// the lane strips of hp_cluster.h / hp_gaps.h (six words per entry and lane) are cut from the chaining kernels' LDS
+#define HP_LANE_STRIP_WORDS HP_CHAIN_LDS_WORDS
 
 struct Ctx {
     const lamsa_hp_para *P;   // parameters (kernel argument copy)

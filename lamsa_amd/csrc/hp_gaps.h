@@ -17,8 +17,11 @@
 
 namespace hp {
 
-#define HP_GAP_MCAP 6             // active hits of a gap a lane can hold (six words each in LDS)
+#define HP_GAP_MCAP (HP_LANE_STRIP_WORDS / 384 < 6 ? HP_LANE_STRIP_WORDS / 384 : 6)   // active hits of a gap a lane can hold: six words each in the lane's LDS strip, at most six
+static_assert(HP_GAP_MCAP >= 2, "the chaining kernels need at least 768 words of LDS per wave");
+#ifndef HP_GAP_RANGE
 #define HP_GAP_RANGE 96           // hits in the seed range of a gap a lane will scan
+#endif
 #ifndef HP_GAP_MIN
 #define HP_GAP_MIN 6              // lines with fewer gaps run them through the wave-wide routine
 #endif
@@ -39,6 +42,10 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = left; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
     const int k_lo = (int)(g_hoff[left_x + 1] - r.hb), k_hi = (int)(g_hoff[right_x] - r.hb), k_t0 = (int)(g_hoff[left_x + 2] - r.hb);
+#ifdef HP_PROF
+    if (r.prof) atomicAdd((unsigned long long *)&r.prof[11], (unsigned long long)(k_hi - k_lo));
+    if (k_hi - k_lo > HP_GAP_RANGE) { if (r.prof) atomicAdd((unsigned long long *)&r.prof[13], 1ull); return; }
+#endif
     if (k_hi - k_lo > HP_GAP_RANGE) return;
     const NodeS Fh = node_load(ns + left);
     const int head_nm = g_hnm[left], sp = Fh.strand;
@@ -46,20 +53,32 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
 #define GW(e, w) strip[((e) * 6 + (w)) * 64]
     // ---- frag_dp_per_init over the range (:766-784, :1086-1091): the hits the head can be connected to
     int m = 0;
-    for (int k = k_lo; k < k_hi; ++k) {
-        const NodeS Q = node_load(ns + k);
-        const int df = Q.dp_flag;
-        if (df != MULTI_FLAG && df != 0 - MULTI_FLAG) continue;
-        if (Q.chr != Fh.chr || Q.strand != sp) continue;
-        const long long rel = Q.pos - Fh.pos;
-        if (rel > 0x3fffffffll || rel < -0x3fffffffll) continue;                       // far beyond any connectable distance
-        const int flag = gap_edge(K, sp, 0, Fh.sid, Fh.len_dif8, (int)rel, Q.sid, Q.len_dif8);
-        if (flag == F_UNCONNECT) continue;
-        if (m >= HP_GAP_MCAP) return;                                                  // too many for a lane
-        GW(m, 0) = (int)rel; GW(m, 1) = Q.slot_j; GW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
-        GW(m, 3) = (int)(((unsigned)(2 + score_table(flag)) << 16) | (unsigned)((g_hnm[k] + head_nm) & 0xffff));
-        GW(m, 4) = k; GW(m, 5) = (0xff << 24) | (1 << 16) | (F_INIT << 8) | flag;       // from (0xff = the head) | node_n | son_flag | match_flag
-        ++m;
+    // four records in flight per lane: the loop is a chain of dependent HBM round trips otherwise (a gap's range is ~40 hits)
+    for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
+        NodeS Qs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Qs[u] = node_load(ns + (k0 + u < k_hi ? k0 + u : k_hi - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u;
+            if (k >= k_hi) break;
+            const NodeS &Q = Qs[u];
+            const int df = Q.dp_flag;
+            if (df != MULTI_FLAG && df != 0 - MULTI_FLAG) continue;
+            if (Q.chr != Fh.chr || Q.strand != sp) continue;
+            const long long rel = Q.pos - Fh.pos;
+            if (rel > 0x3fffffffll || rel < -0x3fffffffll) continue;                   // far beyond any connectable distance
+            const int flag = gap_edge(K, sp, 0, Fh.sid, Fh.len_dif8, (int)rel, Q.sid, Q.len_dif8);
+            if (flag == F_UNCONNECT) continue;
+#ifdef HP_PROF
+            if (m >= HP_GAP_MCAP && r.prof) atomicAdd((unsigned long long *)&r.prof[13], 1ull);
+#endif
+            if (m >= HP_GAP_MCAP) return;                                              // too many for a lane
+            GW(m, 0) = (int)rel; GW(m, 1) = Q.slot_j; GW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
+            GW(m, 3) = (int)(((unsigned)(2 + score_table(flag)) << 16) | (unsigned)((g_hnm[k] + head_nm) & 0xffff));
+            GW(m, 4) = k; GW(m, 5) = (0xff << 24) | (1 << 16) | (F_INIT << 8) | flag;   // from (0xff = the head) | node_n | son_flag | match_flag
+            ++m;
+        }
     }
     // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
     for (int a = 0; a < m; ++a) {
@@ -178,10 +197,20 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     if (!anc) { arena_release(cx.tmp, mark); return -1; }
     int32_t *anc_x = anc + (H + 2);
     int A = 0;
+#ifdef HP_PROF
+    long long tl_ = wv::clock();
+#define HP_LSTAMP(k) do { const long long now_ = wv::clock(); if (r.prof) r.prof[(k)] += now_ - tl_; tl_ = now_; } while (0)
+#else
+#define HP_LSTAMP(k) do { } while (0)
+#endif
     for (int right = max_node; right >= 0 && A <= H; right = g_from[right]) anc[A++] = right;
     HP_G int32_t *g_anc = (HP_G int32_t *)anc, *g_ancx = (HP_G int32_t *)anc_x;
     for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ancx[i0 + l] = g_seed[g_anc[i0 + l]]; } }
     wv::sync();
+    HP_LSTAMP(16);
+#ifdef HP_PROF
+    if (r.prof) { r.prof[21] += 1; r.prof[12] += A; }
+#endif
     // Most lines of a read against a repeat-rich genome are a few hits of neighbouring seed slots at some repeat copy: no gap at all.
     {
         int any_gap = anc_x[0] < seed_out - 1;
@@ -195,6 +224,10 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
             for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ln0[i0 + l] = g_anc[i0 + l]; } }
             wv::sync();
             arena_release(cx.tmp, mark);
+            HP_LSTAMP(17);
+#ifdef HP_PROF
+            if (r.prof) r.prof[22] += 1;
+#endif
             return A;
         }
     }
@@ -229,6 +262,10 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
         G += __builtin_popcountll(m);
     }
     wv::sync();
+    HP_LSTAMP(17);
+#ifdef HP_PROF
+    if (r.prof) { r.prof[23] += G; if (G < HP_GAP_MIN) r.prof[54] += G; r.prof[55] += 1; }
+#endif
     // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
     // (a lane walks the hit range of its gap by itself, one dependent load after the other: that pays when many gaps share the wait,
     // not for the two or three gaps of a short line)
@@ -277,39 +314,72 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
         }
     }
     wv::sync();
-    for (int g = 0; g < G; ++g) {                                                       // the others, one at a time
-        if (o_lane[g]) continue;
-        int ds = 0, dn = 0;
-        const int n = mini_line(r, g_left[g], g_right[g], g_rx[g], _line, &ds, &dn, 1, g_tail[g]);
-        if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); return -1; }
-        if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return -1; }
-        o_n[g] = n; o_off[g] = pool_n;
-        for (int k = 0; k < n; ++k) pool[pool_n + k] = _line[k];
-        pool_n += n; d_score += ds; d_NM += dn;
-        wv::sync();
+    HP_LSTAMP(18);
+    for (int g0 = 0; g0 < G; g0 += 64) {                                                // the others, one at a time
+        wv::Lane<int> todo, lf, rt, rx, tl;                                             // their parameters by readlane, not by a load per gap
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            todo[l] = g < G && !o_lane[g];
+            lf[l] = g < G ? g_left[g] : -1; rt[l] = g < G ? g_right[g] : -1; rx[l] = g < G ? g_rx[g] : 0; tl[l] = g < G ? g_tail[g] : 0;
+        }
+        unsigned long long m = wv::ballot(todo);
+        while (m) {
+            const int q = __builtin_ctzll(m), g = g0 + q;
+            m &= m - 1;
+            int ds = 0, dn = 0;
+            const int n = mini_line(r, wv::bcast(lf, q), wv::bcast(rt, q), wv::bcast(rx, q), _line, &ds, &dn, 1, wv::bcast(tl, q));
+            if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); return -1; }
+            if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return -1; }
+            o_n[g] = n; o_off[g] = pool_n;
+            wv::sync();
+            for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < n) pool[pool_n + k0 + l] = _line[k0 + l]; } }
+            pool_n += n; d_score += ds; d_NM += dn;
+            wv::sync();
+        }
     }
     *line_score += d_score; *line_NM += d_NM;
+    HP_LSTAMP(19);
     // ---- the line, end node first: [nodes beyond the end node], anchor 0, [nodes of the gap after it], anchor 1, ...
     int node_i = 0;
     {
-        int gi = 0;
         HP_G int32_t *g_ln = (HP_G int32_t *)ln; HP_G int32_t *g_seg = (HP_G int32_t *)(posx + (H + A + 8));
-        if (G > 0 && g_after[0] == -1) {
-            const int n = o_n[0], off = o_off[0];
-            for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < n) { g_ln[node_i + k] = pool[off + n - 1 - k]; g_seg[node_i + k] = k > 0; } } }
-            node_i += n; gi = 1;
-            g_seg[node_i] = n > 0;                                                       // pair (last node beyond the end, end node)
-        } else g_seg[0] = 0;
-        for (int i = 0; i < A; ++i) {
-            ln[node_i++] = anc[i];
-            if (gi < G && g_after[gi] == i) {
-                const int n = o_n[gi], off = o_off[gi];
-                for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < n) { g_ln[node_i + k] = pool[off + n - 1 - k]; g_seg[node_i + k] = 1; } } }
-                node_i += n;
-                g_seg[node_i] = 1;                                                       // pair (last node of the gap or the anchor itself, next anchor)
-                ++gi;
-            } else g_seg[node_i] = 0;
+        // Positions by prefix sums instead of one anchor after the other: an anchor sits at its index plus the nodes of all gaps before it.
+        HP_G int32_t *g_na = g_ancx;                       // per anchor: nodes of the gap that follows it << 1 | 1, or 0 (the slots are not needed any more)
+        HP_G int32_t *g_pa = (HP_G int32_t *)posx;         // per anchor: its position in the line
+        const HP_G int32_t *gg_after = (const HP_G int32_t *)g_after, *gg_on = (const HP_G int32_t *)o_n, *gg_off = (const HP_G int32_t *)o_off;
+        const HP_G int32_t *g_pool = (const HP_G int32_t *)pool;
+        const int first = (G > 0 && g_after[0] == -1) ? 1 : 0;
+        const int n_first = first ? o_n[0] : 0, off_first = first ? o_off[0] : 0;
+        for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_na[i0 + l] = 0; } }
+        wv::sync();
+        for (int g0 = first; g0 < G; g0 += 64) { WAVE_FOR(l) { const int g = g0 + l; if (g < G) g_na[gg_after[g]] = (gg_on[g] << 1) | 1; } }
+        for (int k0 = 0; k0 < n_first; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < n_first) { g_ln[k] = g_pool[off_first + n_first - 1 - k]; g_seg[k] = k > 0; } } }
+        wv::sync();
+        int carry = n_first, carry_has = n_first > 0;      // anchor 0: pair (last node beyond the end, end node)
+        for (int i0 = 0; i0 < A; i0 += 64) {
+            wv::Lane<int> ex, has, pre;
+            WAVE_FOR(l) { const int i = i0 + l; const int na = i < A ? g_na[i] : 0; ex[l] = na >> 1; has[l] = na & 1; }
+            pre = ex;
+            wv::scan_add_excl(pre);
+            const int last_has = wv::bcast(has, 63);
+            wv::shr1(has, carry_has);                      // pair (last node of the gap after the previous anchor or that anchor itself, this anchor)
+            WAVE_FOR(l) {
+                const int i = i0 + l;
+                if (i < A) { const int p = i + carry + pre[l]; g_pa[i] = p; g_ln[p] = g_anc[i]; g_seg[p] = has[l]; }
+            }
+            carry += wv::reduce_sum(ex); carry_has = last_has;
         }
+        wv::sync();
+        for (int g0 = first; g0 < G; g0 += 64) {
+            WAVE_FOR(l) {
+                const int g = g0 + l;
+                if (g < G) {
+                    const int n = gg_on[g], off = gg_off[g], st = g_pa[gg_after[g]] + 1;
+                    for (int k = 0; k < n; ++k) { g_ln[st + k] = g_pool[off + n - 1 - k]; g_seg[st + k] = 1; }
+                }
+            }
+        }
+        node_i = A + carry;
         wv::sync();
         // every node that came out of a mini DP is tracked now (:1376, :1398)
         for (int k0 = 0; k0 < pool_n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < pool_n) gd[pool[k0 + l]].dp_flag = TRACKED_FLAG; } }
@@ -330,6 +400,8 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
         wv::sync();
     }
     arena_release(cx.tmp, mark);
+    HP_LSTAMP(20);
+#undef HP_LSTAMP
     return node_i;
 }
 

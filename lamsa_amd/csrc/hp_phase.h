@@ -142,7 +142,7 @@ HP_INL void pers_bind(ReadCtx &r, const PhaseArgs &a, int rd)
 #define PH_TMID(k, v) do { } while (0)
 #endif
 
-HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_LDS_WORDS)
+HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_CHAIN_LDS_WORDS)
 {
 #ifdef HP_PROF
     long long ph_t_ = wv::clock();
@@ -183,7 +183,7 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
     if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;       // the read is lost already (another line or phase failed)
     PH_T0();
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, HP_LDS_WORDS);
     pers_bind(r, a, rd);
     Ctx &cx = r.cx;
     FLines F;
@@ -272,7 +272,7 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
     RdMeta &M = a.meta[rd];
     if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, 0);
     pers_bind(r, a, rd);
     const lamsa_hp_para *P = r.cx.P;
     if (!lj_params_ok(P)) return;
@@ -428,7 +428,7 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
 }
 
 // ---------------------------------------------------------------- chain2: one read
-HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_LDS_WORDS)
+HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_CHAIN_LDS_WORDS)
 {
     RdMeta &M = a.meta[rd];
     if (M.status & (ST_REFEXIT | ST_OVERFLOW)) return;

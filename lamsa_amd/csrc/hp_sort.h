@@ -25,7 +25,9 @@ HP_INL uint64_t hit_sort_key(int32_t chr, int8_t strand, int64_t pos)
 
 HP_INL int bits_of(unsigned long long x) { return x ? 64 - (int)__builtin_clzll(x) : 0; }
 
+#ifndef HP_SORT_BLOCK
 #define HP_SORT_BLOCK 1024               // words sorted / merged in LDS at a time (8 KB of the wave's 9.5 KB)
+#endif
 
 // one stage of the network on 64-bit words (WP: pointer into LDS or HBM): pair t has lo = t with a 0 bit inserted at
 // bit log2(j) and hi = lo ^ flip; four pairs per lane in flight

@@ -22,7 +22,7 @@ extern "C" int emu_dp_batch(const lamsa_hp_para *P, int n, const uint8_t *seq,
     a.cig_cap_off = cig_cap_off; a.cig = cig;
     std::vector<char> slab(slab_bytes);
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr;
-    static thread_local int32_t lds[HP_LDS_WORDS];
+    static thread_local int32_t lds[HP_BOTH_LDS_WORDS];
     for (int j = 0; j < n; ++j) dp_run_job(a, j, 0, lds);
     return 0;
 }
@@ -46,11 +46,11 @@ static void emu_sort_index(const BatchIn &in, int n_reads, std::vector<int32_t> 
     const int64_t n_hits = n_reads ? in.hit_off[in.seed_off[n_reads]] : 0;
     srt.assign((size_t)n_hits + 1, 0); rnk.assign((size_t)n_hits + 1, 0);
     std::vector<uint64_t> keys((size_t)n_hits + 1, 0);
-    static thread_local uint64_t lw[HP_LDS_WORDS / 2];
+    static thread_local uint64_t lw[HP_BOTH_LDS_WORDS / 2];
     int pb, cb; emu_sort_widths(in, n_reads, pb, cb);
     for (int r = 0; r < n_reads; ++r) {
         const int64_t hb = in.hit_off[in.seed_off[r]]; const int H = (int)(in.hit_off[in.seed_off[r + 1]] - hb);
-        sort_read_hits(in.h_pos + hb, in.h_chr + hb, in.h_strand + hb, H, srt.data() + hb, rnk.data() + hb, keys.data() + hb, lw, HP_LDS_WORDS / 2, pb, cb);
+        sort_read_hits(in.h_pos + hb, in.h_chr + hb, in.h_strand + hb, H, srt.data() + hb, rnk.data() + hb, keys.data() + hb, lw, HP_BOTH_LDS_WORDS / 2, pb, cb);
     }
 }
 
@@ -102,7 +102,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.out.stream = stream; a.out.stream_cap = stream_cap; a.out.cursor = &cursor;
     a.out.read_out_off = read_off; a.out.read_out_len = read_len; a.out.read_status = status; a.out.read_tbases = nullptr; a.out.read_work = nullptr; a.out.diag = nullptr;
     std::vector<char> slab(slab_bytes);
-    static thread_local int32_t lds[HP_LDS_WORDS];
+    static thread_local int32_t lds[HP_BOTH_LDS_WORDS];
     if (scale == 1 && g_emu_phased) {
         // the product's main pass: chain1 -> fill -> chain2 -> fill -> publish, every phase over the whole batch before the next starts
         PhaseArgs p;

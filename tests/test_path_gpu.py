@@ -104,7 +104,7 @@ def test_hip_compact_cigar_form(tmp_path):
 
 
 def test_hip_batch_beyond_2_31_cigar_elements():
-    """131 072 reads x 10 kbp in ONE batch: 2.2 G seed-CIGAR elements, more than 32-bit offsets can address.  The compact form of the
+    """147 456 reads x 10 kbp in ONE batch: 2.3 G seed-CIGAR elements, more than 32-bit offsets can address.  The compact form of the
     boundary (one byte per element, offsets summed up on the device) takes it; every read comes back with status 0 and a sample
     equals the oracle word for word.  The word form with its 32-bit offsets is refused with a message, not wrapped."""
     import os
@@ -112,7 +112,7 @@ def test_hip_batch_beyond_2_31_cigar_elements():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import simbatch
     from lamsa_amd import hp
-    n = 131072
+    n = 147456
     ref = simbatch.SimRef(1_000_000_000, n_contigs=12, seed=5, threads=16)
     B = simbatch.SimBatch(ref, n, 10000, "ont2d", seed=77, threads=16)
     assert B.n_cig > 0x7fffffff
