@@ -1592,6 +1592,9 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
     { const long long t2_ = wv::clock(); if (r.prof) { r.prof[58] += t2_ - tq_; r.prof[59] += all_min ? 0 : 1; } }
 #endif
     HP_CSTAMP(6);
+#if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 1
+    return true;                 // traffic experiment (tools/chain_stops.sh): nothing after the MIN pass
+#endif
     if (seed_out > 1) {                                                                           // main pass, :1345-1350
         // cluster by cluster out of LDS; clusters that do not fit LDS through dp_update_range; then the son lists
         bool any_big = false;
@@ -1629,12 +1632,18 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
     }
 
     HP_CSTAMP(7);
+#if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 2
+    return true;
+#endif
     NScore ns;
     if (!ns_alloc(r.cx, ns, H + 1, 0)) return false;
     ns.min_score_thd = 2;
     track_leaves(r, 0, seed_out - 1, MIN_FLAG, ns);                                                 // :1356-1361
 
     HP_CSTAMP(8);
+#if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 3
+    return true;
+#endif
     const int o_l = ns.node_n;
     LSet L;
     Trig T;
@@ -1665,6 +1674,9 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
 #undef HP_TRIG_PUSH
     L.n = l_i;
     HP_CSTAMP(9);
+#if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 4
+    return true;
+#endif
     const int line_n = set_bound(r, L, 0, l_i, &T);                   // :1435
     const bool okf = build_flines(r, L, line_n, F, fs);
     HP_CSTAMP(10);

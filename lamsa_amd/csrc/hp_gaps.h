@@ -179,6 +179,53 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
     O.n = max_n; O.d_score = max_score - old_score; O.d_NM = max_NM - old_NM;
 }
 
+// The gaps of a line that no lane has taken (o_lane == 0), one after the other through mini_line.  A function of its own on purpose:
+// mini_line_sets needs ~100 VGPRs, so whatever the caller holds in registers at the call is saved to and restored from scratch
+// around it -- 80 calls per read.  Inside line_build that was ~50 dwords per lane and call (12 KB per wave, most of the chaining
+// kernel's HBM traffic: the scratch of 4 096 waves does not stay in L2); here it is the handful of values this loop needs.
+// gp: the per-gap arrays of line_build (GA entries each, in the order left, right, lx, rx, tail, after, o_n, o_off, ..., o_lane at 15).
+struct GapRest { int pool_n, d_score, d_NM; };
+HP_NOINL int mini_line_far(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+{
+    return mini_line(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+}
+HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t *pool, int pool_n, int32_t *_line)
+{
+    Ctx &cx = r.cx;
+    const int H = r.H;
+    const int32_t *g_left = gp, *g_right = gp + GA, *g_rx = gp + 3 * GA, *g_tail = gp + 4 * GA, *o_lane = gp + 15 * GA;
+    int32_t *o_n = gp + 6 * GA, *o_off = gp + 7 * GA;
+    GapRest R; R.pool_n = pool_n; R.d_score = 0; R.d_NM = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        wv::Lane<int> todo, lf, rt, rx, tl;                                             // their parameters by readlane, not by a load per gap
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            todo[l] = g < G && !o_lane[g];
+            lf[l] = g < G ? g_left[g] : -1; rt[l] = g < G ? g_right[g] : -1; rx[l] = g < G ? g_rx[g] : 0; tl[l] = g < G ? g_tail[g] : 0;
+        }
+        unsigned long long m = wv::ballot(todo);
+        while (m) {
+            const int q = __builtin_ctzll(m), g = g0 + q;
+            m &= m - 1;
+            int ds = 0, dn = 0;
+            // the usual case straight into the register routine; everything else (longer ranges: reach_run and the listing, the memory
+            // version) behind a call of its own, so that this loop's frame stays small
+            const int left = wv::bcast(lf, q), right = wv::bcast(rt, q), right_x = wv::bcast(rx, q), tail = wv::bcast(tl, q);
+            const int k_n = hoff(r, right_x) - hoff(r, nx(r, left) + 1);
+            int n = k_n <= 64 ? mini_line_sets<1>(r, left, right, right_x, _line, &ds, &dn, 1, tail, k_n, nullptr) : -1;
+            if (n < 0) { ds = 0; dn = 0; n = mini_line_far(r, left, right, right_x, _line, &ds, &dn, 1, tail); }
+            if (cx.status & ST_REFEXIT) { R.pool_n = -1; return R; }
+            if (R.pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; R.pool_n = -1; return R; }
+            o_n[g] = n; o_off[g] = R.pool_n;
+            wv::sync();
+            for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < n) pool[R.pool_n + k0 + l] = _line[k0 + l]; } }
+            R.pool_n += n; R.d_score += ds; R.d_NM += dn;
+            wv::sync();
+        }
+    }
+    return R;
+}
+
 // ---------------------------------------------------------------- one line of frag_line_BCC's loop (:1370-1432)
 // The anchors of the line from its end node `max_node` back to START, the mini DPs of all its gaps (one per lane where
 // possible, mini_line otherwise), the nodes in read order in ln[], the inter-line triggers (:1384-1386, :1404-1414).  Returns the
@@ -315,27 +362,10 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     }
     wv::sync();
     HP_LSTAMP(18);
-    for (int g0 = 0; g0 < G; g0 += 64) {                                                // the others, one at a time
-        wv::Lane<int> todo, lf, rt, rx, tl;                                             // their parameters by readlane, not by a load per gap
-        WAVE_FOR(l) {
-            const int g = g0 + l;
-            todo[l] = g < G && !o_lane[g];
-            lf[l] = g < G ? g_left[g] : -1; rt[l] = g < G ? g_right[g] : -1; rx[l] = g < G ? g_rx[g] : 0; tl[l] = g < G ? g_tail[g] : 0;
-        }
-        unsigned long long m = wv::ballot(todo);
-        while (m) {
-            const int q = __builtin_ctzll(m), g = g0 + q;
-            m &= m - 1;
-            int ds = 0, dn = 0;
-            const int n = mini_line(r, wv::bcast(lf, q), wv::bcast(rt, q), wv::bcast(rx, q), _line, &ds, &dn, 1, wv::bcast(tl, q));
-            if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); return -1; }
-            if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); return -1; }
-            o_n[g] = n; o_off[g] = pool_n;
-            wv::sync();
-            for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < n) pool[pool_n + k0 + l] = _line[k0 + l]; } }
-            pool_n += n; d_score += ds; d_NM += dn;
-            wv::sync();
-        }
+    {                                                                                   // the others, one at a time
+        const GapRest gr = gaps_one_by_one(r, G, gp, GA, pool, pool_n, _line);
+        if (gr.pool_n < 0) { arena_release(cx.tmp, mark); return -1; }
+        pool_n = gr.pool_n; d_score += gr.d_score; d_NM += gr.d_NM;
     }
     *line_score += d_score; *line_NM += d_NM;
     HP_LSTAMP(19);

@@ -166,7 +166,11 @@ HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32
         PH_TMID(0, ph_t_);
         FLines F;
         FlStore fs; fs.base = a.fl_base; fs.cap = a.fl_cap; fs.cursor = &a.ctl->fl_cursor; fs.got_off = 0; fs.got_tot = 0;
+#if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 0
+        const bool ok1 = true; F.n = 0; F.nfrag = 0;       // traffic experiment (tools/chain_stops.sh): sort index and node records only
+#else
         const bool ok1 = chain_first(r, F, &fs);
+#endif
         PH_TMID(1, ph_t_);
         if (ok1 && F.n > 0) units_push(a, r, rd, 0, F, fs);
         else if (!ok1 && !(cx.status & (ST_REFEXIT | ST_OVERFLOW))) cx.status |= ST_OVERFLOW;

@@ -9,9 +9,12 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --bare > $out/bench_stats.log 2>&1
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
-           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+# PMC_SETS="FETCH_SIZE;WRITE_SIZE" limits the counter passes (default: all five)
+if [ -n "${PMC_SETS:-}" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; else
+SETS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"
+      "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
+      "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"); fi
+for set in "${SETS[@]}"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
   # counter passes serialise the dispatches anyway: one launch at a time (--sequential)
   rocprofv3 --pmc $set --output-format csv -d $out/pmc_$n -- python3 bench.py "$@" --sequential --bare > $out/bench_pmc_$n.log 2>&1
