@@ -90,7 +90,10 @@ __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const Phase
 #ifndef HP_FILLDP_WAVES_PER_SIMD
 #define HP_FILLDP_WAVES_PER_SIMD 2
 #endif
-__global__ __launch_bounds__(64, 4) void k_filllist(const PhaseArgs *ap, int round)
+#ifndef HP_LIST_WAVES_PER_SIMD
+#define HP_LIST_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64, HP_LIST_WAVES_PER_SIMD) void k_filllist(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
     int n = 0;
@@ -439,6 +442,18 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 
 #ifdef HP_PROF
 // diagnostic builds (-DHP_PROF): per-read cycle counters kept by the kernels, summed and printed after a launch
+// Waves whose scratch slabs fit the device: two batches can be in flight, each with its own slabs, beside the inputs, the
+// inter-launch state and the outputs of both -- 100 GB of slabs per batch in flight on a 288-GB device.  Whole CUs' worth of
+// waves where that is possible (20-kbp reads at -w 200 need 15 MB per wave: 6 656 waves instead of the fill kernel's 8 192).
+static int cap_waves(int n_waves, size_t slab_per_wave, int n_cu)
+{
+    const size_t budget = (size_t)100 << 30;
+    if (slab_per_wave * (size_t)n_waves <= budget) return n_waves;
+    size_t fit = budget / (slab_per_wave ? slab_per_wave : 1);
+    if (n_cu > 0 && fit >= (size_t)n_cu) fit -= fit % (size_t)n_cu;
+    return fit < 1 ? 1 : (int)fit;
+}
+
 static void prof_report(Slot &T, const long long *d_prof, int n)
 {
     if (!d_prof) return;
@@ -508,7 +523,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pdb, k_filldp_big, 64, 0) != hipSuccess || pdb < 1) pdb = 2;
     int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb;
     int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
-    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
     w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves);
     const PhasedLayout Y = phased_layout(n, n_hits, T.n_bases, O.stream_cap);
     const int unit_cap = Y.unit_cap, lj_cap = Y.lj_cap; const int64_t fl_cap = Y.fl_cap, line_cap = Y.line_cap, job_cap = Y.job_cap;
@@ -573,7 +588,7 @@ static int launch_align(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, Ou
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_align_batch, 64, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     int n_waves = h->n_cu * per_cu;
     if (n_waves > n_units) n_waves = n_units;
-    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
     if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     const int n = T.n_reads;
     AlignArgs a;
@@ -810,7 +825,7 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     size_t slab_per_wave = slab_bytes_for(h->para, max_read_len, max_hits_per_read, 1);
     if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
     int n_waves = h->n_cu * 16;
-    while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)160 << 30)) n_waves /= 2;
+    n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
     const int64_t cap = main_stream_cap(n_reads, n_bases);
     const PhasedLayout Y = phased_layout(n_reads, n_hits, n_bases, cap);
     // the packed input of a batch (upload_into): every array plus its 256-byte alignment, both CIGAR forms' staging included
