@@ -300,16 +300,23 @@ def main():
         if a.cpu_seconds > 0 and world == 1 and not a.bare:               # the CPU baseline is measured on rank 0 of the single-GPU run only
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
             probe = min(256, a.reads)                      # estimate the rate on a probe, then size the sample for ~cpu_seconds
-            t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, threads); tp = time.perf_counter() - t0
+            # The box shows every core of the host but may grant this job a share of them (a CPU quota): the thread count is chosen by
+            # a probe -- all visible cores, 64, 32, 16 -- and the baseline runs with the fastest; `cores` is what it then used.
+            cand = sorted({threads} | {t for t in (64, 32, 16) if t < threads}, reverse=True)
+            rates = {}
+            for t in cand:
+                t0 = time.perf_counter(); reflib.oracle_streams(take_first(B, probe), lp, t); rates[t] = probe / max(time.perf_counter() - t0, 1e-3)
+            cpu_threads = max(rates, key=lambda t: rates[t]); tp = probe / rates[cpu_threads]
             n_s = int(max(probe, min(a.reads, probe * a.cpu_seconds / max(tp, 1e-3))))
             sample = take_first(B, n_s)
-            t0 = time.perf_counter(); want = reflib.oracle_streams(sample, lp, threads); tc = time.perf_counter() - t0
+            t0 = time.perf_counter(); want = reflib.oracle_streams(sample, lp, cpu_threads); tc = time.perf_counter() - t0
             same = sum(1 for i in range(n_s) if want[i] == streams[i])
-            cpu = {"value": round(float(sample.read_off[-1]) / tc / 1e9, 6), "unit": "Gbase/s", "cores": threads, "kind": "port",
-                   "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path, one read per task) on all %d cores of the box, %.1f s" % (n_s, threads, tc),
+            cpu = {"value": round(float(sample.read_off[-1]) / tc / 1e9, 6), "unit": "Gbase/s", "cores": cpu_threads, "kind": "port",
+                   "sample": "first %d reads of the rank-0 batch, oracle (plain-C port of the reference path, one read per task) on %d threads (of %d visible cores; "
+                             "probe of %d reads, reads/s by thread count: %s), %.1f s" % (n_s, cpu_threads, threads, probe, ", ".join("%d: %.0f" % (t, rates[t]) for t in cand), tc),
                    "reads_per_s": round(n_s / tc, 3), "gpu_equals_cpu_on_sample": "%d/%d reads" % (same, n_s), "host_cpu": cpu_model()}
             try:
-                cpu["reference_binary"] = reference_binary_baseline(B, ref, wl, threads, a.cpu_seconds)
+                cpu["reference_binary"] = reference_binary_baseline(B, ref, wl, cpu_threads, a.cpu_seconds)
             except Exception as e:                           # a reported extra, never a reason to lose the bench line
                 cpu["reference_binary"] = {"error": repr(e)[:200]}
         hits = np.diff(B.hit_off)

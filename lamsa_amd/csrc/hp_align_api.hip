@@ -440,8 +440,6 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     return LAMSA_HP_OK;
 }
 
-#ifdef HP_PROF
-// diagnostic builds (-DHP_PROF): per-read cycle counters kept by the kernels, summed and printed after a launch
 // Waves whose scratch slabs fit the device: two batches can be in flight, each with its own slabs, beside the inputs, the
 // inter-launch state and the outputs of both -- 100 GB of slabs per batch in flight on a 288-GB device.  Whole CUs' worth of
 // waves where that is possible (20-kbp reads at -w 200 need 15 MB per wave: 6 656 waves instead of the fill kernel's 8 192).
@@ -454,6 +452,8 @@ static int cap_waves(int n_waves, size_t slab_per_wave, int n_cu)
     return fit < 1 ? 1 : (int)fit;
 }
 
+#ifdef HP_PROF
+// diagnostic builds (-DHP_PROF): per-read cycle counters kept by the kernels, summed and printed after a launch
 static void prof_report(Slot &T, const long long *d_prof, int n)
 {
     if (!d_prof) return;
@@ -824,7 +824,12 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     if (S->n_fifo || S->n_res) { h->err = "batches are in flight"; return LAMSA_HP_EINVAL; }
     size_t slab_per_wave = slab_bytes_for(h->para, max_read_len, max_hits_per_read, 1);
     if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
-    int n_waves = h->n_cu * 16;
+    int per_cu = 16;                                         // the widest grid of the launch sequence (launch_phased): the fill kernel's
+    { int pc = 0, pf = 0, pd = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) == hipSuccess && pc > per_cu) per_cu = pc;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) == hipSuccess && pf > per_cu) per_cu = pf;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) == hipSuccess && pd > per_cu) per_cu = pd; }
+    int n_waves = h->n_cu * per_cu;
     n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
     const int64_t cap = main_stream_cap(n_reads, n_bases);
     const PhasedLayout Y = phased_layout(n_reads, n_hits, n_bases, cap);

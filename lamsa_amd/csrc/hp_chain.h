@@ -1,7 +1,7 @@
 // hp_chain.h -- sparse-DP chaining of seed hits into lines on one wavefront
 // (reference src/lamsa_dp_con.c + src/lamsa_heap.c).
 //
-//   edge_flag(_packed) <- get_fseed_dis         lamsa_dp_con.c:596
+//   edge_flag_packed  <- get_fseed_dis          lamsa_dp_con.c:596-634 (gap_edge in hp_cluster.h: the same on 32-bit relative positions)
 //   dp_update_range    <- frag_dp_update        :701   targets in order; candidates = the target's neighbours in the
 //                                                      (contig, strand, position) order, spread over the 64 lanes
 //   min_extend_all <- frag_min_extend           :1031  all MIN hits x all hits, blocked, records in registers
@@ -82,34 +82,6 @@ HP_INL int mapn(const ReadCtx &r, int x) { return (int)(r.hit_off[x + 1] - r.hit
 HP_INL int sid(const ReadCtx &r, int x) { int s = r.seed_id[x]; return r.flip ? r.seed_all + 1 - s : s; }
 HP_INL int nx(const ReadCtx &r, int node) { return node < 0 ? -1 : r.n_seed[node]; }
 
-// ---------------------------------------------------------------- edge classification (get_fseed_dis, :596-634)
-HP_INL int edge_flag(const ReadCtx &r, int pre, int cur)
-{
-    if (pre < 0 || cur < 0) return F_MATCH;
-    if (pre == cur) return F_MATCH;
-    const int xp = r.n_seed[pre], xc = r.n_seed[cur];
-    if (xp == xc) return F_UNCONNECT;
-    const int sp = r.h_strand[pre];
-    if (r.h_chr[cur] != r.h_chr[pre] || r.h_strand[cur] != sp) return F_CHR_DIF;
-    const lamsa_hp_para *P = r.cx.P;
-    const int idp = sid(r, xp), idc = sid(r, xc), did = iabs(idp - idc);
-    if (did * P->seed_step < P->seed_len) return F_UNCONNECT;
-    const int64_t exp = r.h_pos[pre] + (int64_t)(sp * (idc - idp) * P->seed_step);
-    const int64_t act = r.h_pos[cur];
-    const int dis = (int)((int64_t)sp * ((idp < idc) ? (act - exp) : (exp - act))
-                          - ((sp * (idp - idc) < 0) ? r.h_len_dif[pre] : r.h_len_dif[cur]));
-    const int mat_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
-    if (dis <= mat_dis && dis >= -mat_dis) {
-        if (did == 1) return F_MATCH;
-        if (did <= 3 * P->mismatch_thd) return F_MISMATCH;
-        return F_LONG_MISMATCH;
-    }
-    if (dis > mat_dis && dis < P->SV_len_thd) return F_DELETE;
-    if ((dis < -mat_dis && dis >= 0 - (did * P->seed_step - P->seed_len)) ||
-        (dis < -(P->split_len / 2) && dis >= -P->SV_len_thd)) return F_INSERT;
-    return F_UNCONNECT;
-}
-
 // ---------------------------------------------------------------- node helpers
 HP_INL void node_set(ReadCtx &r, int n, int from, int score, int NM, int match_flag, int dp_flag)
 {   // fnode_set, :636
@@ -117,13 +89,6 @@ HP_INL void node_set(ReadCtx &r, int n, int from, int score, int NM, int match_f
     r.nd[n].match_flag = (uint8_t)match_flag; r.nd[n].dp_flag = (int8_t)dp_flag;
     r.n_node_n[n] = 1; r.n_in_de[n] = 0; r.n_son_n[n] = 0; r.n_first[n] = -1; r.n_last[n] = -1;
     r.n_max_score[n] = score; r.n_max_NM[n] = NM; r.n_max_node[n] = n;
-}
-HP_FN void node_per_init(ReadCtx &r, int n, int from, int dp_flag)
-{   // frag_dp_per_init, :766
-    if (from < 0) { node_set(r, n, from, 1, r.h_nm[n], F_MATCH, dp_flag); return; }
-    int flag = edge_flag(r, from, n);
-    if (flag != F_UNCONNECT && flag != F_CHR_DIF) node_set(r, n, from, 2 + score_table(flag), r.h_nm[n] + r.h_nm[from], flag, dp_flag);
-    else r.nd[n].dp_flag = (int8_t)(0 - dp_flag);
 }
 HP_INL void add_son(ReadCtx &r, int fa, int son)
 {   // fnode_add_son, :683 (append keeps insertion order, which get_max_son depends on)
