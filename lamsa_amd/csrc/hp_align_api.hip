@@ -441,11 +441,12 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 }
 
 // Waves whose scratch slabs fit the device: two batches can be in flight, each with its own slabs, beside the inputs, the
-// inter-launch state and the outputs of both -- 100 GB of slabs per batch in flight on a 288-GB device.  Whole CUs' worth of
-// waves where that is possible (20-kbp reads at -w 200 need 15 MB per wave: 6 656 waves instead of the fill kernel's 8 192).
+// inter-launch state and the outputs of both -- 72 GB of slabs per batch in flight on a 288-GB device (100 GB each did not fit beside
+// the rest for 20-kbp reads).  Whole CUs' worth of waves where that is possible (20-kbp reads at -w 200 need 17 MB per wave: 4 096
+// waves instead of the fill kernel's 8 192).
 static int cap_waves(int n_waves, size_t slab_per_wave, int n_cu)
 {
-    const size_t budget = (size_t)100 << 30;
+    const size_t budget = (size_t)72 << 30;
     if (slab_per_wave * (size_t)n_waves <= budget) return n_waves;
     size_t fit = budget / (slab_per_wave ? slab_per_wave : 1);
     if (n_cu > 0 && fit >= (size_t)n_cu) fit -= fit % (size_t)n_cu;

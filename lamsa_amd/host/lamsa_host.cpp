@@ -32,6 +32,8 @@
 #include <immintrin.h>
 #endif
 #include <fcntl.h>
+#include <sstream>
+#include <sys/wait.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -282,6 +284,53 @@ static int seeds_of(const lamsa_hp_para &P, int L) { return L < P.seed_len ? 0 :
 // the seed-result file, mapped (or, where that fails, read) into memory: lines are handed out as spans, never copied
 struct MapText {
     const char *p = nullptr; size_t n = 0, pos = 0; bool mapped = false; std::vector<char> owned; Prefault pf;
+    // Follow mode (the reference runs the mapper to completion first, src/lamsa_aln.c:1179-1193): the map
+    // is still being written by the mapper started by run_seeding; lines are read as they appear, the end of the file counts only once
+    // the mapper has exited.  The text of a read is handed out as a string of its own (the chunk keeps it until it is parsed).
+    int follow_fd = -1; long follow_pid = 0; int follow_status = 0; bool follow_done = false; std::string fbuf; size_t fpos = 0; std::string follow_path;
+    bool following() const { return follow_pid != 0; }
+    bool open_follow(const std::string &path, long pid) { follow_path = path; follow_pid = pid; p = ""; return true; }
+    // more bytes of the growing file into fbuf; false: the mapper is gone and everything it wrote has been read
+    bool follow_more() {
+        for (;;) {
+            if (follow_fd < 0) follow_fd = ::open(follow_path.c_str(), O_RDONLY);
+            if (follow_fd >= 0) {
+                if (fpos > (1u << 20)) { fbuf.erase(0, fpos); fpos = 0; }
+                const size_t at = fbuf.size();
+                fbuf.resize(at + (1u << 20));
+                const ssize_t got = ::read(follow_fd, &fbuf[at], 1u << 20);
+                fbuf.resize(at + (got > 0 ? (size_t)got : 0));
+                if (got > 0) return true;
+            }
+            if (follow_done) return false;                                    // the mapper had exited before this (empty) read
+            int st = 0;
+            const pid_t w = waitpid((pid_t)follow_pid, &st, WNOHANG);
+            if (w == (pid_t)follow_pid || w < 0) { follow_done = true; follow_status = w < 0 ? -1 : st; continue; }   // one more read picks up what it wrote last
+            usleep(2000);
+        }
+    }
+    // the next `lines` lines of the growing map as one string; false when the mapper's output ends first
+    bool take_follow(int lines, std::string &out) {
+        out.clear();
+        size_t scan = fpos;
+        for (int left = lines; left > 0; ) {
+            const void *nl = scan < fbuf.size() ? memchr(fbuf.data() + scan, '\n', fbuf.size() - scan) : nullptr;
+            if (nl) { scan = (size_t)((const char *)nl - fbuf.data()) + 1; --left; continue; }
+            const size_t keep = scan - fpos;
+            if (!follow_more()) return false;
+            scan = fpos + keep;                                                // fbuf may have been compacted: fpos moved with it
+        }
+        out.assign(fbuf.data() + fpos, scan - fpos);
+        fpos = scan;
+        return true;
+    }
+    // after the last read: has the mapper ended well?  (waits for it)
+    bool follow_finish() {
+        if (!follow_pid) return true;
+        if (!follow_done) { int st = 0; follow_status = waitpid((pid_t)follow_pid, &st, 0) < 0 ? -1 : st; follow_done = true; }
+        if (follow_fd >= 0) { ::close(follow_fd); follow_fd = -1; }
+        return follow_status != -1 && WIFEXITED(follow_status) && WEXITSTATUS(follow_status) == 0;
+    }
     bool open(const std::string &path) {
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
@@ -298,7 +347,7 @@ struct MapText {
         p = owned.data(); n = owned.size();
         return true;
     }
-    ~MapText() { pf.finish(); if (mapped) munmap((void *)p, n); }
+    ~MapText() { pf.finish(); if (mapped) munmap((void *)p, n); if (follow_fd >= 0) ::close(follow_fd); }
     // the next `lines` lines as [a, b); false when the file ends first
     bool take(int lines, const char *&a, const char *&b) {
         a = p + pos;
@@ -582,7 +631,11 @@ void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index 
 // seeds (<reads>.seed, names "<read>_<i>:<offset>"; <reads>.seed.info as the reference writes it) and the GEM mapper is
 // run on them with the reference's arguments; its output <reads>.seed.gem.map is what run_aln reads.  The mapper and
 // the <ref>.gem index belong to the reference's bundle (`lamsa index`); nothing of them is part of this repository.
-int run_seeding(const Options &opt, const lamsa_hp_para &P)
+// Cuts the seeds as split_seed does (src/lamsa_aln.c:225-303), then starts the bundle's gem-mapper with the arguments of gem/gem_map.sh.
+// pid == nullptr: waits for it, as the reference does (lamsa_gem, :1179-1193).  Otherwise the mapper is left running and its process id
+// returned: run_aln reads the map while it is being written, so seeding overlaps parsing and the GPU (it must be started before any GPU
+// call of this process: a process that has initialised the GPU must not fork + exec on this pool).
+int run_seeding(const Options &opt, const lamsa_hp_para &P, long *pid)
 {
     FastxReader fx;
     if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
@@ -614,9 +667,25 @@ int run_seeding(const Options &opt, const lamsa_hp_para &P)
     char num[256];
     snprintf(num, sizeof num, " -m %f -e %f --min-matched-bases %f --max-big-indel-length 3 -d %d -D 0 -T %d %s", mis, ed, mat, P.per_aln_m, opt.n_thread > 0 ? opt.n_thread : 1,
              opt.fastest ? "--fast-mapping=0" : "--fast-mapping");
-    const std::string cmd = shell_quote(mapper) + " -I " + shell_quote(idx) + " -i " + shell_quote(seed_f) + " -o " + shell_quote(outp) + num + " 2>> " + shell_quote(outp + ".log");
+    ::remove((outp + ".map").c_str());                   // a stale map of an earlier run must not be taken for this one's
+    std::vector<std::string> av = {mapper, "-I", idx, "-i", seed_f, "-o", outp};
+    { std::istringstream is(num); std::string w; while (is >> w) av.push_back(w); }
     fprintf(stderr, "[lamsa_aln] Executing gem-mapper ... \n");
-    if (system(cmd.c_str()) != 0) { fprintf(stderr, "[lamsa_aln] Seeding undone, gem-mapper exit abnormally.\n"); return 1; }
+    fflush(stderr);
+    const pid_t child = fork();
+    if (child < 0) { fprintf(stderr, "[lamsa_aln] Seeding undone, cannot start gem-mapper.\n"); return 1; }
+    if (child == 0) {
+        const int lf = ::open((outp + ".log").c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+        if (lf >= 0) { dup2(lf, 2); ::close(lf); }
+        std::vector<char *> argv;
+        for (std::string &a : av) argv.push_back(&a[0]);
+        argv.push_back(nullptr);
+        execv(mapper.c_str(), argv.data());
+        _exit(127);
+    }
+    if (pid) { *pid = (long)child; return 0; }
+    int st = 0;
+    if (waitpid(child, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "[lamsa_aln] Seeding undone, gem-mapper exit abnormally.\n"); return 1; }
     fprintf(stderr, "[lamsa_aln] gem-mapper done!\n");
     return 0;
 }
@@ -682,6 +751,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             fprintf(stderr, "[lamsa_aln] %s is not a hit stream written with these seeding options (-T, -l, -i, -p)\n", opt.hits.c_str()); return 1;
         }
         hitsf.pos = sizeof hh;
+    } else if (opt.mapper_pid) { mapt.open_follow(map_path, opt.mapper_pid);
     } else if (!mapt.open(map_path)) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
     FastxReader fx;
     if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
@@ -714,7 +784,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
     // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
     // The chunk buffers are recycled.
-    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; bool mapped = false; lamsa_hp_batch hb; int dev = 0;
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; std::vector<std::string> text; bool mapped = false; lamsa_hp_batch hb; int dev = 0;
                    int sub_rc = 0, col_rc = 0; lamsa_hp_result res; std::promise<void> collected; };
     // One worker thread per device runs that device's submit / collect calls in the order they are queued (a handle is not
     // thread-safe, and the copies of a submit block their caller): the uploads of different devices then run side by side.
@@ -732,7 +802,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
         Chunk *c = &pool[(size_t)(n_scanned++ % (2 * G + 6))];
         Batch &B = c->B;
-        B.clear(); c->ret = 0; c->span.clear(); c->mapped = false;
+        B.clear(); c->ret = 0; c->span.clear(); c->text.clear(); c->mapped = false;
         if (eof) return c;
         const double t0 = now_s();
         Read rd;
@@ -763,9 +833,23 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             return c;
         }
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
-            if (!fx.next(rd)) { eof = true; break; }
+            if (!fx.next(rd)) {
+                eof = true;
+                if (mapt.following()) {                      // the reads are through: the mapper must have ended, and ended well
+                    if (!mapt.follow_finish()) { fprintf(stderr, "[lamsa_aln] Seeding undone, gem-mapper exit abnormally.\n"); c->ret = 1; B.clear(); return c; }
+                    fprintf(stderr, "[lamsa_aln] gem-mapper done!\n");
+                }
+                break;
+            }
             const char *la, *lb;
-            if (!mapt.take(seeds_of(P, (int)rd.seq.size()), la, lb)) { fprintf(stderr, "[lamsa_read_seq] seeds' GEM map result does not match the reads\n"); c->ret = 1; eof = true; return c; }
+            bool got;
+            if (mapt.following()) {
+                if (c->text.capacity() < (size_t)opt.chunk_reads + 1) c->text.reserve((size_t)opt.chunk_reads + 1);      // no reallocation: the spans point into the strings
+                c->text.emplace_back();
+                got = mapt.take_follow(seeds_of(P, (int)rd.seq.size()), c->text.back());
+                la = c->text.back().data(); lb = la + c->text.back().size();
+            } else got = mapt.take(seeds_of(P, (int)rd.seq.size()), la, lb);
+            if (!got) { fprintf(stderr, "[lamsa_read_seq] seeds' GEM map result does not match the reads\n"); c->ret = 1; eof = true; return c; }
             c->span.emplace_back(la, lb);
             chunk_bases += (int64_t)rd.seq.size();
             B.reads.emplace_back(); std::swap(B.reads.back(), rd);

@@ -68,6 +68,8 @@ struct Options {
     // seeding front end (lamsa_aln_c, src/lamsa_aln.c:1224-1275): -N reuses <reads>.seed.gem.map, otherwise the read file is
     // cut into seeds and the GEM mapper of the reference's bundle is run on them
     int no_seed_aln = 0, fastest = 0;
+    int seed_first = 0;                                   // --seed-first: wait for the mapper before aligning, as the reference does; default: read its map while it is being written
+    long mapper_pid = 0;                                  // set by main(): the mapper started by run_seeding and still running
     std::string save_hits, hits;                          // --save-hits FILE: also write the parsed chunks as a binary hit stream; --hits FILE: read that instead of the GEM map text
     int parse_only = 0;                                   // --parse-only: read and parse the inputs, no GPU work, no output (ingest timing)
     float ed_rate = -1, mis_rate = -1, mat_rate = -1;     // -e, -x; defaults per read type (src/lamsa_aln.h:26-70)
@@ -79,7 +81,7 @@ struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
 
 void sam_header(std::string &o, const Index &ix, const std::string &pg);
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);
-int run_seeding(const Options &opt, const lamsa_hp_para &P);
+int run_seeding(const Options &opt, const lamsa_hp_para &P, long *pid = nullptr);   // pid: leave the mapper running and return its process id
 int run_index(const std::string &fasta, const std::string &gem_dir, bool with_gem);      // index.cpp
 int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats);
 

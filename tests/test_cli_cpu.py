@@ -103,6 +103,47 @@ def test_parse_only_ends(cli, tmp_path):
     assert all(l.startswith("@") for l in open(out).read().splitlines())
 
 
+def _fake_mapper(d, map_src, pieces=6, delay=0.25, rc=0, stop_after=None):
+    """A stand-in for the bundle's gem-mapper: writes the prepared map to `<-o PREFIX>.map` in pieces, slowly."""
+    os.makedirs(d, exist_ok=True)
+    exe = os.path.join(d, "gem-mapper")
+    with open(exe, "w") as f:
+        f.write("""#!/usr/bin/env python3
+import sys, time
+a = sys.argv[1:]
+out = a[a.index("-o") + 1] + ".map"
+data = open(%r, "rb").read()
+n = %d; cut = [len(data) * i // n for i in range(n + 1)]
+with open(out, "wb") as g:
+    for i in range(n):
+        if %r is not None and i >= %r:
+            break
+        g.write(data[cut[i]:cut[i + 1]]); g.flush(); time.sleep(%f)
+sys.exit(%d)
+""" % (map_src, pieces, stop_after, stop_after, delay, rc))
+    os.chmod(exe, 0o755)
+    return d
+
+
+def test_map_is_read_while_the_mapper_writes_it(cli, tmp_path):
+    """Seeding overlapped with the rest: the mapper is started and left running, its map is read as it
+    grows -- here a stand-in that writes the fixture's map in six slow pieces, cutting lines in the middle.  Same SAM; `--seed-first`
+    (wait for the mapper, as the reference does) too; a mapper that dies half way is an error, not a short output."""
+    ref, reads, args, gold = G.stage_scenario("c2_pacbio", str(tmp_path))
+    keep = str(tmp_path / "map.keep")
+    shutil.move(reads + ".seed.gem.map", keep)
+    gem = _fake_mapper(str(tmp_path / "gem"), keep)
+    for extra in ([], ["--seed-first"]):
+        p = subprocess.run([cli, "aln", "-R", "0", "-t", "2", "--batch", "9", "--gem-dir", gem] + extra + args + [ref, reads], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "gem-mapper done!" in p.stderr
+        assert G.strip_pg(p.stdout) == G.strip_pg(gold)
+        os.remove(reads + ".seed.gem.map")
+    gem = _fake_mapper(str(tmp_path / "gem2"), keep, rc=3, stop_after=3)
+    p = subprocess.run([cli, "aln", "-R", "0", "--batch", "9", "--gem-dir", gem] + args + [ref, reads], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and ("exit abnormally" in p.stderr or "does not match" in p.stderr)
+
+
 def test_chunks_dealt_over_several_devices(cli, tmp_path):
     """--devices: one handle per listed device, chunks round-robin, output in input order (two handles on device 0 here)."""
     ref, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path))

@@ -52,6 +52,7 @@ def gigar(words, nm, reverse):
 def _write_part(args):
     path, r0, r1, seed_len, seed_step = args
     B = _SHARED["B"]
+    cig_off = _SHARED.get("cig_off")              # 64-bit starts of the seed CIGARs (a batch may hold more than 2^31 elements: B.h_cig_off wraps)
     with open(path + ".fa", "w") as fa, open(path + ".map", "w") as mp:
         for r in range(r0, r1):
             seq = B.read_seq[int(B.read_off[r]):int(B.read_off[r + 1])]
@@ -65,7 +66,7 @@ def _write_part(args):
                 hits = []
                 if s is not None:
                     for k in range(int(B.hit_off[s]), int(B.hit_off[s + 1])):
-                        co, cn = int(B.h_cig_off[k]), int(B.h_cig_n[k])
+                        co, cn = int(cig_off[k]) if cig_off is not None else int(B.h_cig_off[k]), int(B.h_cig_n[k])
                         st = int(B.h_strand[k])
                         hits.append("chr%d:%s:%d:%s" % (int(B.h_chr[k]), "+" if st > 0 else "-", int(B.h_pos[k]), gigar(B.cig[co:co + cn], int(B.h_nm[k]), st < 0)))
                 mp.write("r%d_%d\tN\t*\t0\t%s\n" % (r, sd, ",".join(hits) if hits else "-"))
@@ -83,6 +84,10 @@ def write_reads(path, B, seed_len=50, seed_step=25, workers=1):
     n = B.n_reads
     workers = max(1, min(workers, n // 64 if n >= 128 else 1))
     _SHARED["B"] = B
+    if int(B.n_cig) > 0x7fffffff:                   # the CIGARs lie back to back in hit order (tools/simhits.c)
+        import numpy as np
+        cn = np.asarray(B.h_cig_n[:B.n_hits], np.int64)
+        _SHARED["cig_off"] = np.concatenate([[0], np.cumsum(cn)[:-1]])
     per = (n + workers - 1) // workers
     jobs = [(path + ".part%d" % w, w * per, min(n, (w + 1) * per), seed_len, seed_step) for w in range(workers) if w * per < n]
     if workers == 1:
