@@ -23,7 +23,7 @@ static_assert(HP_GAP_MCAP >= 2, "the chaining kernels need at least 768 words of
 #define HP_GAP_RANGE 96           // hits in the seed range of a gap a lane will scan
 #endif
 #ifndef HP_GAP_MIN
-#define HP_GAP_MIN 1              // lines with fewer gaps run them through the wave-wide routine (1: every line uses the lanes)
+#define HP_GAP_MIN 6              // lines with fewer gaps run them through the wave-wide routine
 #endif
 
 struct GapOut {                   // per lane
@@ -33,62 +33,26 @@ struct GapOut {                   // per lane
     int r_from, r_score, r_NM, r_nn, r_mf;     // the right anchor after the forced update (_tail == 1)
 };
 
-// One gap on one lane.  left >= 0: the head (left_x its slot).  left < 0: the pass from START to the line's first anchor (tail, right >= 0):
-// handled when the read's clusters are at hand (cl_lo / cl_srt of hp_cluster.h) and the anchor's cluster is small.  right >= 0 when tail,
-// right_x = right's slot (or seed_out).  LDS strip: word w of entry e at strip[(e * 6 + w) * 64].
-#define HP_GAP_CLMAX 12           // hits of the right anchor's cluster a lane will look at for a pass from START
-HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int left, int right, int left_x, int right_x, int tail, GapOut &O,
-                     const int32_t *cl_lo = nullptr, const int32_t *cl_srt = nullptr)
+// One gap on one lane.  left >= 0 (the head), right >= 0 when tail, right_x = right's slot (or seed_out).  LDS strip: word w of
+// entry e at strip[(e * 6 + w) * 64].
+HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int left, int right, int left_x, int right_x, int tail, GapOut &O)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = left; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
-    const bool from_start = left < 0;
-    if (from_start) { if (!cl_lo || !tail || right < 0) return; left_x = -1; }
     const int k_lo = (int)(g_hoff[left_x + 1] - r.hb), k_hi = (int)(g_hoff[right_x] - r.hb), k_t0 = (int)(g_hoff[left_x + 2] - r.hb);
 #ifdef HP_PROF
-    if (r.prof && !from_start) atomicAdd((unsigned long long *)&r.prof[11], (unsigned long long)(k_hi - k_lo));
-    if (!from_start && k_hi - k_lo > HP_GAP_RANGE) { if (r.prof) atomicAdd((unsigned long long *)&r.prof[13], 1ull); return; }
+    if (r.prof) atomicAdd((unsigned long long *)&r.prof[11], (unsigned long long)(k_hi - k_lo));
+    if (k_hi - k_lo > HP_GAP_RANGE) { if (r.prof) atomicAdd((unsigned long long *)&r.prof[13], 1ull); return; }
 #endif
-    if (!from_start && k_hi - k_lo > HP_GAP_RANGE) return;
-    // positions are kept relative to the pass's anchor: the head, or the right anchor when there is no head
-    const NodeS Fh = node_load(ns + (from_start ? right : left));
-    const int head_nm = from_start ? 0 : (int)g_hnm[left], sp = Fh.strand;
+    if (k_hi - k_lo > HP_GAP_RANGE) return;
+    const NodeS Fh = node_load(ns + left);
+    const int head_nm = g_hnm[left], sp = Fh.strand;
     if ((long long)(r.seed_id[r.seed_out - 1] - r.seed_id[0] + 1) * K.seed_step > 0x3fffffffll) return;
 #define GW(e, w) strip[((e) * 6 + (w)) * 64]
     // ---- frag_dp_per_init over the range (:766-784, :1086-1091): the hits the head can be connected to
     int m = 0;
-    if (from_start) {
-        // No head: frag_dp_per_init activates every hit of the seed range (:946-951), but only those that reach the right anchor through
-        // any number of edges can matter, and they lie in the anchor's run of the sorted order (reach_run) -- a subset of its CLUSTER
-        // (cluster_reach >= the reach of any pass; hits of the cluster outside the run connect to nothing inside it).  The cluster's
-        // hits are listed in ascending hit order in cl_srt[lo .. lo + n): those of the seed range become the entries.
-        const HP_G int32_t *g_lo = (const HP_G int32_t *)cl_lo, *g_cs = (const HP_G int32_t *)cl_srt, *g_rnk = (const HP_G int32_t *)r.rnk;
-        const int lo = g_lo[g_rnk[right]], H = r.H;
-        int n = 1;
-        while (n <= HP_GAP_CLMAX && lo + n < H && g_lo[lo + n] == lo) ++n;
-        if (n > HP_GAP_CLMAX) return;                                                  // the read's true locus: not for a lane
-        for (int q0 = 0; q0 < n; q0 += 4) {
-            NodeS Qs[4]; int ids[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { ids[u] = g_cs[lo + (q0 + u < n ? q0 + u : n - 1)]; Qs[u] = node_load(ns + ids[u]); }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (q0 + u >= n) break;
-                const NodeS &Q = Qs[u]; const int id = ids[u];
-                const int df = Q.dp_flag;
-                if ((Q.slot_j >> 14) >= right_x || (df != MULTI_FLAG && df != 0 - MULTI_FLAG)) continue;
-                const long long rel = Q.pos - Fh.pos;
-                if (rel > 0x3fffffffll || rel < -0x3fffffffll) return;
-                if (m >= HP_GAP_MCAP) return;                                          // too many for a lane
-                GW(m, 0) = (int)rel; GW(m, 1) = Q.slot_j; GW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
-                GW(m, 3) = (int)((1u << 16) | (unsigned)(g_hnm[id] & 0xffff));          // fnode_set(START): score 1, the hit's own NM
-                GW(m, 4) = id; GW(m, 5) = (0xff << 24) | (1 << 16) | (F_INIT << 8) | F_MATCH;
-                ++m;
-            }
-        }
-    } else
     // four records in flight per lane: the loop is a chain of dependent HBM round trips otherwise (a gap's range is ~40 hits)
     for (int k0 = k_lo; k0 < k_hi; k0 += 4) {
         NodeS Qs[4];
@@ -266,8 +230,7 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
 // The anchors of the line from its end node `max_node` back to START, the mini DPs of all its gaps (one per lane where
 // possible, mini_line otherwise), the nodes in read order in ln[], the inter-line triggers (:1384-1386, :1404-1414).  Returns the
 // number of nodes, or -1 (status flagged).  `_line`: scratch of H + 2 words for mini_line.
-HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i,
-                        const int32_t *cl_lo = nullptr, const int32_t *cl_srt = nullptr)
+HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i)
 {
     Ctx &cx = r.cx;
     const int H = r.H, seed_out = r.seed_out;
@@ -360,7 +323,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
         WAVE_FOR(l) {
             const int g = g0 + l;
             GapOut O; O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
-            if (g < G && (g_left[g] >= 0 || cl_lo) && use_lanes) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O, cl_lo, cl_srt);
+            if (g < G && g_left[g] >= 0 && use_lanes) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
             nn[l] = g < G ? O.n : 0; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0;
             if (g < G) {
                 o_n[g] = O.n; o_ds[g] = O.d_score; o_dn[g] = O.d_NM; o_rf[g] = O.r_from; o_rs[g] = O.r_score; o_rn[g] = O.r_NM; o_rnn[g] = O.r_nn; o_rmf[g] = O.r_mf; o_lane[g] = O.n >= 0;
