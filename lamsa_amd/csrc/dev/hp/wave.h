@@ -33,6 +33,7 @@ constexpr int W = 64;
 
 // LDS read-modify-write without a returned value (ds_and_b32): lanes of one wave may target the same dword
 HP_INL void lds_and(HP_L int *p, int mask) { (void)__hip_atomic_fetch_and(p, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+HP_INL void lds_or(HP_L int *p, int mask) { (void)__hip_atomic_fetch_or(p, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 HP_INL int lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -113,7 +113,7 @@ HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, co
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.rc_read = nullptr; r.t_bases = 0;
-    r.prof = r.cx.prof;
+    r.prof = r.cx.prof; r.leaf_bits = nullptr; r.leaf_on = false;
 }
 
 // the packed 32-byte record and the seed slot of every hit, one hit per lane: its slot by binary search in the read's

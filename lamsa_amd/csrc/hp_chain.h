@@ -74,6 +74,8 @@ struct ReadCtx {
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
     NodeS *nd;                  // 32-byte hot record per hit (static facts + score/NM/flags)
     const int32_t *srt, *rnk;   // hits sorted by (contig, strand, position) and the inverse permutation (local indices)
+    HP_L int32_t *leaf_bits; bool leaf_on;   // while track_leaves runs (leaf_on): one bit per seed slot that may hold a hit to start a track from, in LDS
+                                // (a flag of its own: the wave's LDS starts at offset 0, which is what a null LDS pointer compares equal to)
     long long *prof;            // diagnostic build only
 };
 
@@ -641,12 +643,15 @@ HP_FN int ns_add_bounded(NScore &ns, int node, int score, int NM)
     }
     return -2;
 }
-HP_FN void ns_add_end(ReadCtx &r, NScore &ns, int score, int NM, int node)
+// path (may be null): the ancestors of `node` in lane order, n_path <= 64 of them, when the caller has just walked them -- they are
+// then marked with one store instead of being chased through n_from again
+HP_FN void ns_add_end(ReadCtx &r, NScore &ns, int score, int NM, int node, const wv::Lane<int> *path = nullptr, int n_path = 0)
 {   // node_add_score, lamsa_dp_con.c:786
     if (score < ns.min_score_thd) return;
     if (ns.node_n >= ns.cap) { r.cx.status |= ST_OVERFLOW; return; }
     ns.score[ns.node_n] = score; ns.NM[ns.node_n] = NM; ns.node[ns.node_n++] = node;
     r.nd[node].dp_flag = TRACKED_FLAG;
+    if (path) { HP_G NodeS *gd = (HP_G NodeS *)r.nd; WAVE_FOR(l) { if (l < n_path) gd[(*path)[l]].dp_flag = TRACKED_FLAG; } return; }
     for (int t = r.n_from[node]; t >= 0; t = r.n_from[t]) r.nd[t].dp_flag = TRACKED_FLAG;
 }
 
@@ -672,10 +677,14 @@ HP_FN void detach(ReadCtx &r, int s, int max_node, NScore &ns)
     r.n_node_n[max_node] -= (r.n_node_n[s] - 1);
     ns_add_end(r, ns, r.n_max_score[s], r.n_max_NM[s], max_node);
 }
+HP_INL void leaf_mark(ReadCtx &r, int f)
+{   // see track_leaves: the driver only visits seeds whose bit is set
+    if (r.leaf_on) { const int x = r.n_seed[f]; r.leaf_bits[x >> 5] |= (int)(1u << (x & 31)); }
+}
 HP_FN void cut_branch(ReadCtx &r, int f, NScore &ns)
 {   // :831-870
     const int keep = best_son(r, f);
-    if (keep < 0) { r.cx.status |= ST_REFEXIT; r.n_in_de[f] = 0; return; }
+    if (keep < 0) { r.cx.status |= ST_REFEXIT; r.n_in_de[f] = 0; leaf_mark(r, f); return; }
     for (int s = r.n_first[f], c = 0, nn = r.n_son_n[f]; c < nn && s >= 0; ++c) {
         const int nxt = r.n_next[s];
         if (s != keep) detach(r, s, r.n_max_node[s], ns);
@@ -691,32 +700,45 @@ HP_FN void cut_branch(ReadCtx &r, int f, NScore &ns)
         r.n_max_node[f] = r.n_max_node[keep]; r.n_max_score[f] = r.n_max_score[keep]; r.n_max_NM[f] = r.n_max_NM[keep];
     }
     r.n_in_de[f] = 0;
+    leaf_mark(r, f);                                  // f is complete: a track starts from it when its seed is reached
 }
 HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
 {   // branch_track_new, :873-920
+    // The walk up a chain is a pointer chase through HBM: what a step needs (son count, score, predecessor) is requested together, one
+    // memory round trip per step, and the nodes walked are kept in a lane register so that node_add_score need not chase them again.
+    const HP_G int32_t *g_from = (const HP_G int32_t *)r.n_from, *g_son_n = (const HP_G int32_t *)r.n_son_n;
+    const HP_G NodeS *g_nd = (const HP_G NodeS *)r.nd;
     int max_score, max_NM, max_node;
     r.n_in_de[n] = -1;
-    if (r.n_son_n[n] == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = r.nd[n].score; max_NM = r.n_max_NM[n] = r.nd[n].NM; }
+    const int n_sons = g_son_n[n], n_score = g_nd[n].score, n_NM = g_nd[n].NM;
+    int fa = g_from[n];
+    if (n_sons == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = n_score; max_NM = r.n_max_NM[n] = n_NM; }
     else { max_node = r.n_max_node[n]; max_score = r.n_max_score[n]; max_NM = r.n_max_NM[n]; }
-    int fa = r.n_from[n];
+    wv::Lane<int> path;                               // the ancestors of max_node walked so far, while path_ok
+    WAVE_FOR(l) { path[l] = 0; }
+    int n_path = 0; bool path_ok = n_sons == 0;       // a leaf: max_node is n itself, its ancestors are exactly the nodes walked below
     while (fa >= 0) {
-        if (r.n_son_n[fa] == 1) {
-            if (r.nd[fa].score > max_score) {         // negative edge
+        const int fa_sons = g_son_n[fa], fa_score = g_nd[fa].score, fa_from = g_from[fa];
+        if (fa_sons == 1) {
+            if (fa_score > max_score) {               // negative edge
                 const int s = r.n_first[fa];
                 r.n_in_de[s] = -1;
                 detach(r, s, max_node, ns);
                 r.n_son_n[fa] = 0; r.n_first[fa] = r.n_last[fa] = -1;
                 max_score = r.nd[fa].score; max_NM = r.nd[fa].NM; max_node = fa;
+                n_path = 0; path_ok = true;           // from here on the ancestors of max_node = fa are what is walked next
+            } else if (path_ok) {
+                if (n_path < 64) { WAVE_FOR(l) { if (l == n_path) path[l] = fa; } ++n_path; } else path_ok = false;
             }
             r.n_max_score[fa] = max_score; r.n_max_NM[fa] = max_NM; r.n_max_node[fa] = max_node; r.n_in_de[fa] = -1;
-            fa = r.n_from[fa];
+            fa = fa_from;                             // detach() above changes n_from of the son only, never of fa
         } else {
             --r.n_in_de[fa];
             if (r.n_in_de[fa] == 0) cut_branch(r, fa, ns);
             return;
         }
     }
-    ns_add_end(r, ns, max_score, max_NM, max_node);
+    ns_add_end(r, ns, max_score, max_NM, max_node, path_ok ? &path : nullptr, n_path);
 }
 
 // ---------------------------------------------------------------- which hits can matter for the chain into `node`
@@ -761,36 +783,106 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
 // order, every hit that is (still) a leaf of the pass starts a track.  The leaf test of a seed's hits is done by the
 // lanes when the seed is reached: tracking a hit only changes hits of earlier seeds (its ancestors) and sons whose own
 // tracks are complete, never another hit of the same seed that has not been visited yet.
+// The reference looks at every seed; most have nothing to start from, and looking costs a memory round trip each.  Here one pass
+// over all hits of the range marks the seeds that hold a leaf now (a bit per seed in LDS); a hit becomes a leaf later only
+// through cut_branch, which marks its seed (always an earlier one than the track that completed it); the driver visits the
+// marked seeds only, last to first, with the same test as before.
+HP_INL void track_slot(ReadCtx &r, int h0, int h1, int dp_flag, bool skip_lone, NScore &ns)
+{
+    const HP_G NodeS *ns_ = (const HP_G NodeS *)r.nd;
+    const HP_G int32_t *g_in_de = (const HP_G int32_t *)r.n_in_de, *g_from = (const HP_G int32_t *)r.n_from, *g_son_n = (const HP_G int32_t *)r.n_son_n;
+    for (int b = h0; b < h1; b += 64) {
+        wv::Lane<int> leaf;
+        WAVE_FOR(l) {
+            const int k = b + l;
+            int v = 0;
+            if (k < h1) {
+                int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0;
+                // A hit without predecessor and without sons is a path of its own with score 1: node_add_score (:786) drops it when the
+                // threshold is above that, and nothing reads what branch_track_new would leave in its own fields
+                if (v && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) v = 0;
+            }
+            leaf[l] = v;
+        }
+        for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) branch_track(r, b + __builtin_ctzll(m), ns);
+    }
+}
 HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_flag, NScore &ns)
 {
     const HP_G NodeS *ns_ = (const HP_G NodeS *)r.nd;
     const HP_G int32_t *g_in_de = (const HP_G int32_t *)r.n_in_de, *g_from = (const HP_G int32_t *)r.n_from, *g_son_n = (const HP_G int32_t *)r.n_son_n;
+    const HP_G int32_t *g_seed = (const HP_G int32_t *)r.n_seed;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const int64_t hb = r.hb;
     const bool skip_lone = ns.min_score_thd > 1;
-    for (int i0 = last_slot; i0 >= first_slot; i0 -= 63) {
-        // hit offsets of up to 63 seeds (i0-62 .. i0) and the end of the last one, one per lane
-        wv::Lane<int> ho;
-        WAVE_FOR(l) { const int x = i0 - 62 + l; ho[l] = (x >= 0 && x <= r.seed_out) ? (int)(g_hoff[x] - hb) : 0; }
-        for (int i = i0; i >= first_slot && i > i0 - 63; --i) {
-            const int h0 = wv::bcast(ho, i - (i0 - 62)), h1 = wv::bcast(ho, i + 1 - (i0 - 62));
-            for (int b = h0; b < h1; b += 64) {
-                wv::Lane<int> leaf;
-                WAVE_FOR(l) {
-                    const int k = b + l;
-                    int v = 0;
-                    if (k < h1) {
-                        int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0;
-                        // A hit without predecessor and without sons is a path of its own with score 1: node_add_score (:786) drops it when the
-                        // threshold is above that, and nothing reads what branch_track_new would leave in its own fields
-                        if (v && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) v = 0;
-                    }
-                    leaf[l] = v;
+    if (last_slot < first_slot) return;
+    const int nw = (last_slot >> 5) + 1, w_lo = first_slot >> 5;
+#ifdef HP_TRACK_ALL
+    if (true) {
+#else
+    if (nw > r.cx.lds_words) {                           // more seeds than this wave's LDS has bits for: every seed, as the reference
+#endif
+        for (int i = last_slot; i >= first_slot; --i) track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
+        return;
+    }
+    HP_L int32_t *bits = r.cx.lds;
+    for (int w0 = w_lo; w0 < nw; w0 += 64) { WAVE_FOR(l) { if (w0 + l < nw) bits[w0 + l] = 0; } }
+    wv::sync();
+    {
+        const int k_lo = (int)(g_hoff[first_slot] - hb), k_hi = (int)(g_hoff[last_slot + 1] - hb);
+        for (int b = k_lo; b < k_hi; b += 64) {
+            WAVE_FOR(l) {
+                const int k = b + l;
+                if (k < k_hi) {
+                    int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q);
+                    int v = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0;
+                    if (v && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) v = 0;
+                    if (v) { const int x = g_seed[k]; wv::lds_or(bits + (x >> 5), (int)(1u << (x & 31))); }
                 }
-                for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) branch_track(r, b + __builtin_ctzll(m), ns);
             }
         }
     }
+    wv::sync();
+    r.leaf_bits = bits; r.leaf_on = true;
+#ifdef HP_TRACK_DEBUG
+    // diagnosis: every seed as the reference, and count (in the pair-evaluation counter) the leaves found in seeds whose bit is not set
+    for (int w0 = w_lo; w0 < nw; w0 += 64) { WAVE_FOR(l) { if (w0 + l < nw) bits[1024 + w0 + l] = bits[w0 + l]; } }      // snapshot of the initial marks
+    wv::sync();
+    for (int i = last_slot; i >= first_slot; --i) {
+        wv::sync();
+        const unsigned v = (unsigned)wv::uni(bits[i >> 5]);
+        const long long before = (long long)ns.node_n;
+        const int h0 = (int)(g_hoff[i] - hb), h1 = (int)(g_hoff[i + 1] - hb);
+        int found = 0;
+        for (int b = h0; b < h1; b += 64) {
+            wv::Lane<int> leaf;
+            WAVE_FOR(l) { const int k = b + l; int vv = 0; if (k < h1) { int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); vv = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0; if (vv && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) vv = 0; } leaf[l] = vv; }
+            if (wv::ballot(leaf)) found = 1;
+        }
+        if (found && !((v >> (i & 31)) & 1)) { r.n_pairs += 1000000000ll; const unsigned v0 = (unsigned)wv::uni(bits[1024 + (i >> 5)]); if ((v0 >> (i & 31)) & 1) r.n_pairs += 100000000ll; r.n_pairs += 10000ll * i; }
+        if (found) r.n_pairs += 1000000ll;
+        (void)before;
+        track_slot(r, h0, h1, dp_flag, skip_lone, ns);
+    }
+    r.leaf_on = false;
+    return;
+#endif
+    for (int w = nw - 1; w >= w_lo; --w) {
+        for (;;) {
+            wv::sync();
+            unsigned v = (unsigned)wv::uni(bits[w]);
+            if (w == w_lo) v &= ~0u << (first_slot & 31);
+            if (w == nw - 1 && (last_slot & 31) != 31) v &= (2u << (last_slot & 31)) - 1;
+            if (!v) break;
+            const int bit = 31 - __builtin_clz(v);
+            wv::sync();
+            bits[w] = (int)((unsigned)wv::uni(bits[w]) & ~(1u << bit));
+            wv::sync();
+            const int i = w * 32 + bit;
+            track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
+        }
+    }
+    r.leaf_on = false;
 }
 
 // ---------------------------------------------------------------- frag_mini_dp_line with the whole pass in registers

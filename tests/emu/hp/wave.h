@@ -24,6 +24,7 @@ namespace wv {
 constexpr int W = 64;
 
 HP_INL void lds_and(int *p, int mask) { *p &= mask; }
+HP_INL void lds_or(int *p, int mask) { *p |= mask; }
 
 template <class T> struct Lane {
     T v[64];
