@@ -522,6 +522,11 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     int pdb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pdb, k_filldp_big, 64, 0) != hipSuccess || pdb < 1) pdb = 2;
+    // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU cap the persistent grids below what fits a CU, so that the launches of two
+    // batches in flight can share the CUs instead of the later one waiting for the earlier one's waves to exit
+    { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0;
+      if (cf > 0 && cf < pf) pf = cf;
+      if (cc > 0 && cc < pc) pc = cc; }
     int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb;
     int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
     n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
