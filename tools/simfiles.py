@@ -84,7 +84,7 @@ def write_reads(path, B, seed_len=50, seed_step=25, workers=1):
     n = B.n_reads
     workers = max(1, min(workers, n // 64 if n >= 128 else 1))
     _SHARED["B"] = B
-    if int(B.n_cig) > 0x7fffffff:                   # the CIGARs lie back to back in hit order (tools/simhits.c)
+    if int(getattr(B, "n_cig", 0)) > 0x7fffffff:    # the CIGARs lie back to back in hit order (tools/simhits.c)
         import numpy as np
         cn = np.asarray(B.h_cig_n[:B.n_hits], np.int64)
         _SHARED["cig_off"] = np.concatenate([[0], np.cumsum(cn)[:-1]])
