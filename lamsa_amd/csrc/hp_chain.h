@@ -817,11 +817,7 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
     const bool skip_lone = ns.min_score_thd > 1;
     if (last_slot < first_slot) return;
     const int nw = (last_slot >> 5) + 1, w_lo = first_slot >> 5;
-#ifdef HP_TRACK_ALL
-    if (true) {
-#else
     if (nw > r.cx.lds_words) {                           // more seeds than this wave's LDS has bits for: every seed, as the reference
-#endif
         for (int i = last_slot; i >= first_slot; --i) track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
         return;
     }
@@ -844,29 +840,6 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
     }
     wv::sync();
     r.leaf_bits = bits; r.leaf_on = true;
-#ifdef HP_TRACK_DEBUG
-    // diagnosis: every seed as the reference, and count (in the pair-evaluation counter) the leaves found in seeds whose bit is not set
-    for (int w0 = w_lo; w0 < nw; w0 += 64) { WAVE_FOR(l) { if (w0 + l < nw) bits[1024 + w0 + l] = bits[w0 + l]; } }      // snapshot of the initial marks
-    wv::sync();
-    for (int i = last_slot; i >= first_slot; --i) {
-        wv::sync();
-        const unsigned v = (unsigned)wv::uni(bits[i >> 5]);
-        const long long before = (long long)ns.node_n;
-        const int h0 = (int)(g_hoff[i] - hb), h1 = (int)(g_hoff[i + 1] - hb);
-        int found = 0;
-        for (int b = h0; b < h1; b += 64) {
-            wv::Lane<int> leaf;
-            WAVE_FOR(l) { const int k = b + l; int vv = 0; if (k < h1) { int q[4]; hp_load16((const HP_G char *)(ns_ + k) + 16, q); vv = (int)(int8_t)(q[1] & 0xff) == dp_flag && g_in_de[k] == 0; if (vv && skip_lone && g_from[k] < 0 && g_son_n[k] == 0) vv = 0; } leaf[l] = vv; }
-            if (wv::ballot(leaf)) found = 1;
-        }
-        if (found && !((v >> (i & 31)) & 1)) { r.n_pairs += 1000000000ll; const unsigned v0 = (unsigned)wv::uni(bits[1024 + (i >> 5)]); if ((v0 >> (i & 31)) & 1) r.n_pairs += 100000000ll; r.n_pairs += 10000ll * i; }
-        if (found) r.n_pairs += 1000000ll;
-        (void)before;
-        track_slot(r, h0, h1, dp_flag, skip_lone, ns);
-    }
-    r.leaf_on = false;
-    return;
-#endif
     for (int w = nw - 1; w >= w_lo; --w) {
         for (;;) {
             wv::sync();
