@@ -473,6 +473,10 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
         long long sum[64] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 64; ++k) sum[k] += pr[(size_t)r * 64 + k];
         fprintf(stderr, "[HP_PROF] cycles: setup chain1 fill1 chain2 fill2 publish | in chain1: init+minext mainscan track pop-loop bound+flines | o_l H\n");
         fprintf(stderr, "[HP_PROF] SUM  "); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", sum[k] / 1000000); fprintf(stderr, " (Mcycles) targets %lld trips %lld init_Mcyc %lld\n", sum[11], sum[12], sum[13] / 1000000);
+#ifdef HP_PROF_TRACK
+        fprintf(stderr, "[HP_PROF] branch tracking (-DHP_PROF_TRACK: the line_build stamps below are off): marking pass %lld Mcyc; %lld seeds visited; %lld tracks, %lld Mcyc in them, %lld steps up; "
+                        "%lld arrivals at a node with several sons, %lld Mcyc in cut_branch\n", sum[16] / 1000000, sum[19], sum[18], sum[17] / 1000000, sum[20], sum[21], sum[22] / 1000000);
+#endif
         fprintf(stderr, "[HP_PROF] line_build: %lld lines (%lld without a gap), %lld anchors, %lld gaps | Mcyc: anchor walk %lld, gap list %lld, gaps in lanes %lld, gaps one by one %lld, assembly %lld\n",
                 sum[21], sum[22], sum[12], sum[23], sum[16] / 1000000, sum[17] / 1000000, sum[18] / 1000000, sum[19] / 1000000, sum[20] / 1000000);
         fprintf(stderr, "[HP_PROF] gaps: %lld in lines with fewer than HP_GAP_MIN gaps (%lld lines with gaps); lane gaps: %lld hits scanned, %lld refused (range too long or too many active hits)\n", sum[54], sum[55], sum[11], sum[13]);

@@ -719,6 +719,9 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
     int n_path = 0; bool path_ok = n_sons == 0;       // a leaf: max_node is n itself, its ancestors are exactly the nodes walked below
     while (fa >= 0) {
         const int fa_sons = g_son_n[fa], fa_score = g_nd[fa].score, fa_from = g_from[fa];
+#ifdef HP_PROF_TRACK
+        if (r.prof) r.prof[20] += 1;
+#endif
         if (fa_sons == 1) {
             if (fa_score > max_score) {               // negative edge
                 const int s = r.n_first[fa];
@@ -734,7 +737,14 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
             fa = fa_from;                             // detach() above changes n_from of the son only, never of fa
         } else {
             --r.n_in_de[fa];
+#ifdef HP_PROF_TRACK
+            if (r.prof) r.prof[21] += 1;
+            const long long tcb_ = wv::clock();
+#endif
             if (r.n_in_de[fa] == 0) cut_branch(r, fa, ns);
+#ifdef HP_PROF_TRACK
+            if (r.prof) r.prof[22] += wv::clock() - tcb_;
+#endif
             return;
         }
     }
@@ -804,7 +814,15 @@ HP_INL void track_slot(ReadCtx &r, int h0, int h1, int dp_flag, bool skip_lone, 
             }
             leaf[l] = v;
         }
-        for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) branch_track(r, b + __builtin_ctzll(m), ns);
+        for (unsigned long long m = wv::ballot(leaf); m; m &= m - 1) {
+#ifdef HP_PROF_TRACK
+            const long long tb_ = wv::clock();
+#endif
+            branch_track(r, b + __builtin_ctzll(m), ns);
+#ifdef HP_PROF_TRACK
+            if (r.prof) { r.prof[17] += wv::clock() - tb_; r.prof[18] += 1; }
+#endif
+        }
     }
 }
 HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_flag, NScore &ns)
@@ -821,6 +839,9 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
         for (int i = last_slot; i >= first_slot; --i) track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
         return;
     }
+#ifdef HP_PROF_TRACK
+    const long long tt0_ = wv::clock();
+#endif
     HP_L int32_t *bits = r.cx.lds;
     for (int w0 = w_lo; w0 < nw; w0 += 64) { WAVE_FOR(l) { if (w0 + l < nw) bits[w0 + l] = 0; } }
     wv::sync();
@@ -839,6 +860,9 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
         }
     }
     wv::sync();
+#ifdef HP_PROF_TRACK
+    if (r.prof) r.prof[16] += wv::clock() - tt0_;
+#endif
     r.leaf_bits = bits; r.leaf_on = true;
     for (int w = nw - 1; w >= w_lo; --w) {
         for (;;) {
@@ -852,6 +876,9 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
             bits[w] = (int)((unsigned)wv::uni(bits[w]) & ~(1u << bit));
             wv::sync();
             const int i = w * 32 + bit;
+#ifdef HP_PROF_TRACK
+            if (r.prof) r.prof[19] += 1;
+#endif
             track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
         }
     }

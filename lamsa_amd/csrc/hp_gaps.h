@@ -244,7 +244,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     if (!anc) { arena_release(cx.tmp, mark); return -1; }
     int32_t *anc_x = anc + (H + 2);
     int A = 0;
-#ifdef HP_PROF
+#if defined(HP_PROF) && !defined(HP_PROF_TRACK)
     long long tl_ = wv::clock();
 #define HP_LSTAMP(k) do { const long long now_ = wv::clock(); if (r.prof) r.prof[(k)] += now_ - tl_; tl_ = now_; } while (0)
 #else
@@ -255,7 +255,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ancx[i0 + l] = g_seed[g_anc[i0 + l]]; } }
     wv::sync();
     HP_LSTAMP(16);
-#ifdef HP_PROF
+#if defined(HP_PROF) && !defined(HP_PROF_TRACK)
     if (r.prof) { r.prof[21] += 1; r.prof[12] += A; }
 #endif
     // Most lines of a read against a repeat-rich genome are a few hits of neighbouring seed slots at some repeat copy: no gap at all.
@@ -272,7 +272,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
             wv::sync();
             arena_release(cx.tmp, mark);
             HP_LSTAMP(17);
-#ifdef HP_PROF
+#if defined(HP_PROF) && !defined(HP_PROF_TRACK)
             if (r.prof) r.prof[22] += 1;
 #endif
             return A;
@@ -310,7 +310,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     }
     wv::sync();
     HP_LSTAMP(17);
-#ifdef HP_PROF
+#if defined(HP_PROF) && !defined(HP_PROF_TRACK)
     if (r.prof) { r.prof[23] += G; if (G < HP_GAP_MIN) r.prof[54] += G; r.prof[55] += 1; }
 #endif
     // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
