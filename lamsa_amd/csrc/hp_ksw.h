@@ -677,6 +677,169 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     return er;
 }
 
+// ksw_extend_core for queries of 63 .. HP_REG2_QMAX bases: the row in TWO registers per lane -- column j of the reference's eh[] array is
+// lane (j & 63) of register set (j >> 6) -- so that a row is one pass over both sets instead of two trips through the LDS row with the
+// scalar bookkeeping of a tile each (~1 050 instructions per row there, ~450 here; the junction extensions of a noisy read, 65-125
+// query bases, are 38 % of the fill kernel's DP time).  Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg.
+#define HP_REG2_QMAX 126
+HP_INL unsigned long long lt_mask64(int x) { return x <= 0 ? 0ull : (x >= 64 ? ~0ull : ((1ull << x) - 1)); }      // bits below x
+HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
+{
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
+    HP_T0(te0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
+    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const size_t mark = arena_mark(cx.tmp);
+    const bool zl = HP_ZFITS(n_col, tlen);
+    uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)n_col * tlen + 1);
+    int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
+#ifdef HP_PROF
+    if (!zl && cx.prof) { cx.prof[52] += (long long)n_col * tlen; cx.prof[53] += 1; }
+#endif
+    HP_L uint8_t *LZ = (HP_L uint8_t *)(cx.lds + 2 * HP_LDS_CELLS) + HP_LDS_CELLS;
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
+    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+    wv::Lane<int> Hs[2], Es[2], qb[2], tl;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        WAVE_FOR(l) {                                                      // first row, :692-694
+            const int j = 64 * c + l;
+            Hs[c][l] = j == 0 ? h0 : (j == 1 ? h1v : ((j <= qlen && h1v - (j - 2) * e_ins > e_ins) ? h1v - (j - 1) * e_ins : 0));
+            Es[c][l] = 0;
+            qb[c][l] = j < qlen ? (int)gq[(long)j * qs] : 4;
+        }
+    }
+    WAVE_FOR(l) { tl[l] = 4; }
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            const int d_beg = i > w ? i - w : 0;
+            if (beg < i - w) beg = i - w;                                  // :718-720
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            cx.n_cells += end > beg ? end - beg : 0;                       // accounting: DP cell updates (bench.py: GCUPS)
+            if (zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
+            else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
+            int h1_init;
+            if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+            else h1_init = 0;
+            wv::Lane<int> m[2], key[2], hcur[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                WAVE_FOR(l) {
+                    const int j = 64 * c + l;
+                    const int hm = Hs[c][l];
+                    const int M = hm ? hm + HP_SUB(ti, qb[c][l]) : 0;      // :737
+                    int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
+                    m[c][l] = M;
+                    key[c][l] = (j >= beg && j < end) ? tt + j * e_ins : HP_SCAN_IDENT;
+                }
+            }
+            // F along the row: an exclusive prefix maximum over the 128 columns = the scan of each set, the second one topped up with
+            // the maximum of the whole first set
+            const int top0 = wv::reduce_max(key[0]);
+            wv::scan_max_excl(key[0], HP_SCAN_IDENT);
+            wv::scan_max_excl(key[1], HP_SCAN_IDENT);
+            WAVE_FOR(l) { key[1][l] = key[1][l] > top0 ? key[1][l] : top0; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                WAVE_FOR(l) {
+                    const int j = 64 * c + l;
+                    hcur[c][l] = -1;
+                    if (j >= beg && j < end) {
+                        int f = 0 - (j - beg) * e_ins;                     // F(i,beg) = 0 carried along the row
+                        if (j > beg) { const int g = key[c][l] - (j - 1) * e_ins; f = g > f ? g : f; }
+                        int M = m[c][l], ee = Es[c][l], h, tt;
+                        int dir = M > ee ? 0 : 1; h = M > ee ? M : ee;      // ties: E over M   :738-739
+                        dir = h > f ? dir : 2;    h = h > f ? h : f;        //       F over both :740-741
+                        tt = M - oe_del; tt = tt > 0 ? tt : 0; ee -= e_del;
+                        if (ee > tt) dir |= 1 << 2; else ee = tt;           // :745-750
+                        tt = M - oe_ins; tt = tt > 0 ? tt : 0; f -= e_ins;
+                        if (f > tt) dir |= 2 << 4;                          // :751-755
+                        Es[c][l] = ee;
+                        hcur[c][l] = h;
+                        if (zl) z_put(LZ, i, n_col, j - d_beg, dir); else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
+                    }
+                }
+            }
+            // row maximum, last j among equals (:743-744)
+            int mrow = 0, mj = -1;
+            {
+                const int hm0 = wv::reduce_max(hcur[0]), hm1 = wv::reduce_max(hcur[1]);
+                const int hmax = hm1 > hm0 ? hm1 : hm0;
+                if (hmax >= 0) {
+                    wv::Lane<int> eq;
+                    mrow = hmax;
+                    if (hm1 >= hm0) { WAVE_FOR(l) eq[l] = hcur[1][l] == hmax; mj = 64 + 63 - __builtin_clzll(wv::ballot(eq)); }
+                    else { WAVE_FOR(l) eq[l] = hcur[0][l] == hmax; mj = 63 - __builtin_clzll(wv::ballot(eq)); }
+                }
+            }
+            int h_last = h1_init;                                          // H(i,end-1), or the first-column value when the row is empty
+            if (beg < end) h_last = end - 1 < 64 ? wv::bcast(hcur[0], end - 1) : wv::bcast(hcur[1], end - 1 - 64);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { WAVE_FOR(l) { if (hcur[c][l] < 0) hcur[c][l] = 0; } }
+            const int carry = wv::bcast(hcur[0], 63);
+            wv::shr1(hcur[1], carry);                                      // eh[j+1].h = H(i,j), across the two sets
+            wv::shr1(hcur[0], 0);
+            wv::Lane<int> nz[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                WAVE_FOR(l) {
+                    const int j = 64 * c + l;
+                    if (beg < end) { if (j == beg) Hs[c][l] = h1_init; else if (j > beg && j <= end) Hs[c][l] = hcur[c][l]; }
+                    else if (j == end) Hs[c][l] = h1_init;                 // eh[end].h = h1 when the row is empty (:758)
+                    if (j == end) Es[c][l] = 0;                            // :758
+                    nz[c][l] = j >= beg && j <= end && (Hs[c][l] != 0 || Es[c][l] != 0);
+                }
+            }
+            const int jj = beg < end ? end : beg;                          // loop variable j after the row
+            if (jj == qlen) {                                              // :759-762
+                max_ie = gscore > h_last ? max_ie : i;
+                gscore = gscore > h_last ? gscore : h_last;
+            }
+            if (mrow == 0) { stop_rows = true; break; }                    // :763
+            if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+            else if (zdrop > 0) {                                          // :767-773
+                if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
+                else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
+            }
+            // shrink the band for the next row, :775-778
+            {
+                const unsigned long long nz0 = wv::ballot(nz[0]), nz1 = wv::ballot(nz[1]);
+                const unsigned long long lo0 = nz0 & lt_mask64(end), lo1 = nz1 & lt_mask64(end - 64);          // non-zero indices in [beg, end)
+                const int nb = lo0 ? __builtin_ctzll(lo0) : (lo1 ? 64 + __builtin_ctzll(lo1) : end);
+                const unsigned long long up0 = nz0 & ~lt_mask64(nb), up1 = nz1 & ~lt_mask64(nb - 64);          // non-zero indices in [nb, end]
+                const int jl = up1 ? 64 + 63 - __builtin_clzll(up1) : (up0 ? 63 - __builtin_clzll(up0) : nb - 1);
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+            }
+        }
+    }
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
+    return er;
+}
+
 // ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
 HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                       int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
@@ -875,7 +1038,8 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
         w = w < max_del ? w : max_del;
     }
     const ExtRes er = qlen <= HP_REG_QMAX ? ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out)
-                    : (2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out));
+                    : (qlen <= HP_REG2_QMAX ? ksw_extend_reg2(cx, qlen, q, tlen, t, w, h0, out)
+                    : (2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out)));
     if (qle) *qle = er.qle;
     if (tle) *tle = er.tle;
     return er.score;

@@ -62,6 +62,29 @@ def test_emulated_kernels_match_oracle(rt):
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == []
 
 
+def _mid_jobs(seed, err):
+    """Queries of 58 .. 132 bases around every length near the limits of the register routines (62 | 63 .. 126 | 127), targets
+    from half to twice as long."""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for ql in list(range(58, 70)) + list(range(120, 133)) + [int(x) for x in rng.integers(63, 127, 60)]:
+        t = rng.integers(0, 4, size=int(ql * rng.uniform(0.5, 2.0)), dtype=np.uint8)
+        q = dpjobs.mutate(rng, t, *err)
+        q = np.concatenate([q, rng.integers(0, 4, size=max(0, ql - len(q)), dtype=np.uint8)])[:ql]
+        jobs.append((np.ascontiguousarray(q, np.uint8), np.ascontiguousarray(t, np.uint8)))
+    return jobs
+
+
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_emulated_extension_with_the_row_in_two_register_sets(rt):
+    """ksw_extend_core for queries of 63 .. 126 bases (ksw_extend_reg2: column j in lane j & 63 of register set j >> 6): extension and
+    two-sided extension, full and narrow bands (the band edge crosses from one set to the other), small and large h0."""
+    lp, P = reflib.lo_para(rt), hp_para_like(rt)
+    jobs = _mid_jobs(77 + len(rt), ERR[rt])
+    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (2, 0, 100), (2, 0, 12)):
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == [], (kind, w, h0)
+
+
 def test_emulated_kernels_edge_cases():
     lp, P = reflib.lo_para("ont2d"), hp_para_like("ont2d")
     rng = np.random.default_rng(5)
