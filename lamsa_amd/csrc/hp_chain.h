@@ -935,7 +935,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
     if (_tail == 0) { old_score = 1; old_NM = left_NM; }
     else { old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm; }
     // ---- gather + frag_dp_per_init (:766-784, :1086-1091)
-    if (head >= 0) r.n_pairs += n_ids;
+    long long pairs_ = head >= 0 ? n_ids : 0;      // accounting, flushed once at the end
     wv::Lane<int> A0[NS], A1[NS], A2[NS], A3[NS], B0[NS];
     wv::Lane<int> Dpf[NS], Son[NS], Mf[NS], Sc[NS], Nm[NS], Fr[NS], Nn[NS], Cf[NS], Id[NS], Tk[NS];
 #pragma unroll
@@ -969,7 +969,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
         int b_[4] = { B0[j][l], (Dpf[j][l] & 0xff) | (Son[j][l] << 8) | (Mf[j][l] << 16), Sc[j][l], Nm[j][l] }; Q = node_unpack(a_, b_); } while (0)
     // one target T against every loaded hit; returns the winner (cidx, or -1) and its edge class, score and NM
 #define HP_MS_SCAN(S, t_from_id, w_c, w_flag, w_score, w_nm, changed_) do { \
-        r.n_pairs += n_ids; \
+        pairs_ += n_ids; \
         wv::Lane<long long> key; wv::Lane<int> bp, bf, negp, n_p, n_f, n_c, n_n, okl; \
         WAVE_FOR(l) { key[l] = -1; bp[l] = 0; bf[l] = 0; negp[l] = -0x7fffffff; n_p[l] = 0; n_f[l] = 0; n_c[l] = 0; n_n[l] = 0; okl[l] = 0; } \
         _Pragma("unroll") for (int j = 0; j < NS; ++j) { \
@@ -1111,6 +1111,7 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
     wv::sync();
 #undef HP_MS_Q
 #undef HP_MS_SCAN
+    r.n_pairs += pairs_;
     if (bad) { r.cx.status |= ST_REFEXIT; return 0; }
     *de_score += max_score - old_score;
     *de_NM += max_NM - old_NM;

@@ -125,6 +125,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
     const HP_G int32_t *g_csrt = (const HP_G int32_t *)C.csrt, *g_lo = (const HP_G int32_t *)C.cl_lo_r;
     const EdgeK K = edge_consts(r.cx.P);
     const int H = r.H;
+    long long pairs_ = 0;                                      // accounting, flushed once at the end
     const size_t mark_ = arena_mark(r.cx.tmp);
     uint8_t *mk = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
     if (!mk) return;
@@ -173,7 +174,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
             const unsigned long long rsm = wv::ballot(rs) | 1ull;
             WAVE_FOR(l) seg[l] = 63 - __builtin_clzll(rsm & ((2ull << l) - 1));
             const int last = H - 1 - base < 63 ? H - 1 - base : 63;
-            r.n_pairs += (long long)__builtin_popcountll(mset) * (last + 1);
+            pairs_ += (long long)__builtin_popcountll(mset) * (last + 1);
             const int s_last = wv::bcast(sd, last), c_last = wv::bcast(qcl, last), st_last = wv::bcast(seg, last);
             unsigned long long next_carry = 0;
             for (unsigned long long mm = mset; mm; mm &= mm - 1) {
@@ -212,6 +213,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
         }
     }
     wv::sync();
+    r.n_pairs += pairs_;
     for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { const int k = b0 + l; if (k < H && gmk[k]) gd[k].dp_flag = MIN_FLAG; } }
     wv::sync();
     arena_release(r.cx.tmp, mark_);
@@ -368,6 +370,7 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
     // ---- targets in ascending hit order (C.csrt), 64 at a time: their places in the cluster and their records.  A target's
     // record is still what was loaded when its turn comes: only later targets (higher hit index) can choose it as their
     // predecessor and touch its son_flag.
+    long long pairs_ = 0;                                      // accounting, flushed once (a counter in r is a memory round trip per use)
     for (int o0 = 0; o0 < n; o0 += 64) {
         wv::Lane<int> tloc, T0, T1, T2, T3;
         WAVE_FOR(l) {
@@ -386,7 +389,7 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
             WAVE_FOR(l) { bhi[l] = NEG; blo[l] = -1; bi[l] = 0; bf[l] = 0; negp[l] = NEG; n_i[l] = 0; n_f[l] = 0; n_hi[l] = 0; okl[l] = 0; }
             for (int i0 = 0; i0 < n; i0 += 64) {
                 if (wv::bcast(bmin, i0 >> 6) >= x) continue;       // no hit of an earlier seed in this block
-                r.n_pairs += n - i0 < 64 ? n - i0 : 64;
+                pairs_ += n - i0 < 64 ? n - i0 : 64;
                 WAVE_FOR(l) {
                     const int i = i0 + l, ii = i < n ? i : 0;
                     const int q0 = L.w0[ii], q1 = L.w1[ii], q2 = L.w2[ii], q3 = L.w3[ii];
@@ -452,6 +455,7 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
             }
         }
     }
+    r.n_pairs += pairs_;
     // ---- write back: the dynamic half of the record, predecessor and node count
     wv::sync();
     for (int i0 = 0; i0 < n; i0 += 64) {

@@ -105,6 +105,7 @@ struct ExtRes { int score, qle, tle; };
 HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                         int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     HP_T0(tg0_);
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
@@ -131,7 +132,7 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         const int ti = gt[(long)i * ts];
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
-        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+        cells_ += end > beg ? end - beg : 0;
         const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
         int carryH = gH[beg];          // H(i-1,beg-1), read before the in-place update below
         int Fin = HP_NEG_INF;         // F(i,beg)
@@ -185,6 +186,7 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         dp_backtrack(cx, nullptr, z, nullptr, n_col, w, i, k, *out);
         HP_TADD(cx, 28, tb0_);
     }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 24, tg0_);
     return score;
@@ -194,6 +196,7 @@ HP_NOINL int ksw_global_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 // w is already adjusted (see ksw_extend).
 HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     const lamsa_hp_para *P = cx.P;
@@ -239,7 +242,7 @@ HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
-        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+        cells_ += end > beg ? end - beg : 0;
         int h1_init;
         if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
         else h1_init = 0;
@@ -336,6 +339,7 @@ HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     else { i = max_ie; k = qlen - 1; }
     er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
     return er;
@@ -355,6 +359,7 @@ HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
 HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                             int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     HP_T0(tg0_);
     qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);            // wave-uniform: keep them in scalar registers
     o_del = wv::uni(o_del); e_del = wv::uni(e_del); o_ins = wv::uni(o_ins); e_ins = wv::uni(e_ins);
@@ -386,7 +391,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
-        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+        cells_ += end > beg ? end - beg : 0;
         if (end > hw) {                                                    // columns entering the window
             for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_GH0(j); LE[j & HP_LDS_MASK] = HP_NEG_INF; } } }
             hw = end;
@@ -452,6 +457,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         dp_backtrack(cx, zl ? LZ : nullptr, z, nullptr, n_col, w, i, k, *out);
         HP_TADD(cx, 28, tb0_);
     }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 24, tg0_);
     return score;
@@ -468,6 +474,7 @@ HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                             int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     HP_T0(tg0_);
     qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);
     o_del = wv::uni(o_del); e_del = wv::uni(e_del); o_ins = wv::uni(o_ins); e_ins = wv::uni(e_ins);
@@ -497,7 +504,7 @@ HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
             const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
             const int beg = i > w ? i - w : 0;
             const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
-            cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+            cells_ += end > beg ? end - beg : 0;
             if (out && zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
             const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_NEG_INF;   // :579
             wv::Lane<int> m, key, hcur;
@@ -539,6 +546,7 @@ HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
         dp_backtrack(cx, zl ? LZ : nullptr, z, nullptr, n_col, w, i, k, *out);
         HP_TADD(cx, 28, tb0_);
     }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 24, tg0_);
 #ifdef HP_PROF
@@ -549,6 +557,7 @@ HP_NOINL int ksw_global_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 
 HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
@@ -589,7 +598,7 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
             if (beg < i - w) beg = i - w;                                  // :718-720
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
-            cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+            cells_ += end > beg ? end - beg : 0;
             if (zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
             else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
             int h1_init;
@@ -669,6 +678,7 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     else { i = max_ie; k = qlen - 1; }
     er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
 #ifdef HP_PROF
@@ -685,6 +695,7 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
 HP_INL unsigned long long lt_mask64(int x) { return x <= 0 ? 0ull : (x >= 64 ? ~0ull : ((1ull << x) - 1)); }      // bits below x
 HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
@@ -732,7 +743,7 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
             if (beg < i - w) beg = i - w;                                  // :718-720
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
-            cx.n_cells += end > beg ? end - beg : 0;                       // accounting: DP cell updates (bench.py: GCUPS)
+            cells_ += end > beg ? end - beg : 0;
             if (zl) { z_row_clear(LZ, i, n_col); wv::sync(); }
             else { growb[2 * i] = beg; growb[2 * i + 1] = end; }
             int h1_init;
@@ -835,6 +846,7 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     else { i = max_ie; k = qlen - 1; }
     er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
     return er;
@@ -854,6 +866,7 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 
 HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);
     // Arguments of a non-inlined device function arrive in vector registers: tell the compiler that they are
@@ -901,7 +914,7 @@ HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
         if (beg < i - w) beg = i - w;                                      // :718-720
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
-        cx.n_cells += end > beg ? end - beg : 0;                               // accounting: DP cell updates (bench.py: GCUPS)
+        cells_ += end > beg ? end - beg : 0;
         if (end > hw) {                                                    // columns entering the window
             for (int j0 = hw + 1; j0 <= end; j0 += 64) { WAVE_FOR(l) { const int j = j0 + l; if (j <= end) { LH[j & HP_LDS_MASK] = HP_EH0(j); LE[j & HP_LDS_MASK] = 0; } } }
             hw = end;
@@ -1014,6 +1027,7 @@ HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     else { i = max_ie; k = qlen - 1; }
     er.qle = k + 1; er.tle = i + 1; er.score = max;
     if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
     return er;
