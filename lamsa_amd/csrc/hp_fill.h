@@ -404,50 +404,57 @@ HP_INL void junction_geo(const ReadCtx &r, const FLines &F, int f1, int f2, JGeo
 
 struct MergeSrc { const cig_t *p; int n, first, last, reflen, readlen; };       // p == nullptr: a one-element CIGAR, the element in `first`
 
-// merge_cigar (:251-328) with _push_cigar (frag_check.h:158-184); `tail` = c1's last element (valid when c1.n > 0)
-HP_INL bool merge_fast(ReadCtx &r, CigV &c1, int &tail, int64_t *c1_refend, int *c1_readend, int chr, const MergeSrc &S)
+// merge_cigar (:251-328) with _push_cigar (frag_check.h:158-184) for the common cases; `tail` = the record's last CIGAR element (valid when n > 0).
+// It works on the record's running state held in registers (frags_merge): the length of the record's CIGAR, its reference and read
+// ends live in locals across the ~300 steps of a line and are written to `res` only around the calls of the general routines -- every
+// use of a field of `res` is a load, a wait and a store otherwise.  ovf: set instead of cx.status when the CIGAR buffer is full.
+struct MergeLoc { int n, readend; int64_t refend; };
+HP_INL void mloc_out(const MergeLoc &m, Rec &res) { res.cig.n = m.n; res.refend = m.refend; res.readend = m.readend; }
+HP_INL void mloc_in(MergeLoc &m, const Rec &res) { m.n = res.cig.n; m.refend = res.refend; m.readend = res.readend; }
+HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &ovf, int chr, const MergeSrc &S)
 {
     if (S.n == 0) return true;
     Ctx &cx = r.cx;
-    const int n1 = c1.n;
+    const int n1 = m.n;
     if (n1 > 1) {
         const int top = tail & 0xf, hop = S.first & 0xf;
         if ((((top == C_I || top == C_D) && (tail >> 4) <= 3) && hop != C_S && hop != C_H) ||
             (((hop == C_I || hop == C_D) && (S.first >> 4) <= 3) && top != C_S && top != C_H)) {           // boundary repair: the general routine
+            mloc_out(m, res);
             wv::sync();
             bool ok;
-            if (S.p) ok = merge_cigar_full(r, c1, c1_refend, c1_readend, chr, S.p, S.n, S.reflen, S.readlen);
+            if (S.p) ok = merge_cigar_full(r, res.cig, &res.refend, &res.readend, chr, S.p, S.n, S.reflen, S.readlen);
             else {
                 const size_t mark = arena_mark(cx.tmp);
                 cig_t *w = (cig_t *)arena_alloc(cx, sizeof(cig_t));
                 ok = w != nullptr;
-                if (ok) { ((HP_G cig_t *)w)[0] = S.first; wv::sync(); ok = merge_cigar_full(r, c1, c1_refend, c1_readend, chr, w, 1, S.reflen, S.readlen); }
+                if (ok) { ((HP_G cig_t *)w)[0] = S.first; wv::sync(); ok = merge_cigar_full(r, res.cig, &res.refend, &res.readend, chr, w, 1, S.reflen, S.readlen); }
                 arena_release(cx.tmp, mark);
             }
             wv::sync();
-            tail = c1.n > 0 ? (int)((const HP_G cig_t *)c1.c)[c1.n - 1] : 0;
-            return ok;
+            mloc_in(m, res);
+            tail = m.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[m.n - 1] : 0;
+            return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
         }
     }
-    HP_G cig_t *dst = (HP_G cig_t *)c1.c;
+    HP_G cig_t *dst = (HP_G cig_t *)res.cig.c;
     int j = 0;
     if (n1 > 0) {
         if ((tail & 0xf) == (S.first & 0xf)) { tail = tail + ((S.first >> 4) << 4); dst[n1 - 1] = tail; j = 1; }
         else if (((tail & 0xf) == C_I && (S.first & 0xf) == C_S) || ((tail & 0xf) == C_S && (S.first & 0xf) == C_I)) { tail = (((tail >> 4) + (S.first >> 4)) << 4) | C_S; dst[n1 - 1] = tail; j = 1; }
     }
-    const int m = S.n - j;
-    if (n1 + m > c1.cap) cx.status |= ST_OVERFLOW;
-    else if (m > 0) {
-        if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < m; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < m) dst[n1 + i] = src[j + i]; } } }
+    const int mm = S.n - j;
+    if (n1 + mm > res.cig.cap) ovf = true;
+    else if (mm > 0) {
+        if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
         else dst[n1] = S.first;
-        c1.n = n1 + m; tail = S.last;
+        m.n = n1 + mm; tail = S.last;
     }
-    *c1_refend += S.reflen;
-    *c1_readend += S.readlen;
-    return true;
+    m.refend += S.reflen;
+    m.readend += S.readlen;
+    return !ovf;
 }
 
-// the fragments f0 .. f0 + nfr - 1 of a line in the order frag_check walks them, with the junctions between them
 HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int strand, Rec &res)
 {
     Ctx &cx = r.cx;
@@ -458,7 +465,8 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
     HP_G int32_t *g_pl = (HP_G int32_t *)pl;
     wv::sync();
     int tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
-    bool ok = true;
+    bool ok = true, ovf = false;
+    MergeLoc ml; mloc_in(ml, res);                   // the record's running state, in registers
     for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
         // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
         WAVE_FOR(l) {
@@ -499,32 +507,38 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                 MergeSrc S;
                 S.p = r.cig + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
                 S.reflen = wv::bcast(V[6], q); S.readlen = P->seed_len;
-                ok = merge_fast(r, res.cig, tail, &res.refend, &res.readend, wv::bcast(V[7], q), S) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[7], q), S);
             } else {
+                mloc_out(ml, res);
                 wv::sync();
                 ok = frag_extend_multi(r, F, f, res);
                 wv::sync();
-                tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
+                mloc_in(ml, res);
+                tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
             }
             if (!ok || t == nfr - 1) continue;
             // split_mapping, :416-564
             const int kind = wv::bcast(V[8], q);
             if (kind == 3) {
+                mloc_out(ml, res);
                 wv::sync();
                 ok = split_mapping(r, F, f, strand == 1 ? f - 1 : f + 1, res);
                 wv::sync();
-                tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
+                mloc_in(ml, res);
+                tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
             } else if (kind != 0) {
                 MergeSrc S;
                 S.p = kind == 2 ? F.jarena + wv::bcast(V[9], q) : nullptr; S.n = wv::bcast(V[10], q); S.first = wv::bcast(V[11], q); S.last = wv::bcast(V[12], q);
                 S.reflen = wv::bcast(V[13], q); S.readlen = wv::bcast(V[14], q);
-                ok = merge_fast(r, res.cig, tail, &res.refend, &res.readend, wv::bcast(V[15], q), S) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
-            } else ok = !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[15], q), S);
+            }
         }
     }
+    mloc_out(ml, res);
+    if (ovf) cx.status |= ST_OVERFLOW;
     wv::sync();
     arena_release(cx.tmp, mark);
-    return ok;
+    return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
 }
 
 // ---------------------------------------------------------------- frag_head_bound_fix, :576-654
