@@ -708,12 +708,13 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
     // memory round trip per step, and the nodes walked are kept in a lane register so that node_add_score need not chase them again.
     const HP_G int32_t *g_from = (const HP_G int32_t *)r.n_from, *g_son_n = (const HP_G int32_t *)r.n_son_n;
     const HP_G NodeS *g_nd = (const HP_G NodeS *)r.nd;
+    HP_G int32_t *g_ms = (HP_G int32_t *)r.n_max_score, *g_mn = (HP_G int32_t *)r.n_max_NM, *g_mx = (HP_G int32_t *)r.n_max_node, *g_in_de = (HP_G int32_t *)r.n_in_de;
     int max_score, max_NM, max_node;
-    r.n_in_de[n] = -1;
+    g_in_de[n] = -1;
     const int n_sons = g_son_n[n], n_score = g_nd[n].score, n_NM = g_nd[n].NM;
     int fa = g_from[n];
-    if (n_sons == 0) { max_node = n; r.n_max_node[n] = n; max_score = r.n_max_score[n] = n_score; max_NM = r.n_max_NM[n] = n_NM; }
-    else { max_node = r.n_max_node[n]; max_score = r.n_max_score[n]; max_NM = r.n_max_NM[n]; }
+    if (n_sons == 0) { max_node = n; g_mx[n] = n; max_score = n_score; g_ms[n] = n_score; max_NM = n_NM; g_mn[n] = n_NM; }
+    else { max_node = g_mx[n]; max_score = g_ms[n]; max_NM = g_mn[n]; }
     wv::Lane<int> path;                               // the ancestors of max_node walked so far, while path_ok
     WAVE_FOR(l) { path[l] = 0; }
     int n_path = 0; bool path_ok = n_sons == 0;       // a leaf: max_node is n itself, its ancestors are exactly the nodes walked below
@@ -733,15 +734,16 @@ HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
             } else if (path_ok) {
                 if (n_path < 64) { WAVE_FOR(l) { if (l == n_path) path[l] = fa; } ++n_path; } else path_ok = false;
             }
-            r.n_max_score[fa] = max_score; r.n_max_NM[fa] = max_NM; r.n_max_node[fa] = max_node; r.n_in_de[fa] = -1;
+            g_ms[fa] = max_score; g_mn[fa] = max_NM; g_mx[fa] = max_node; g_in_de[fa] = -1;
             fa = fa_from;                             // detach() above changes n_from of the son only, never of fa
         } else {
-            --r.n_in_de[fa];
+            const int left_ = g_in_de[fa] - 1;
+            g_in_de[fa] = left_;
 #ifdef HP_PROF_TRACK
             if (r.prof) r.prof[21] += 1;
             const long long tcb_ = wv::clock();
 #endif
-            if (r.n_in_de[fa] == 0) cut_branch(r, fa, ns);
+            if (left_ == 0) cut_branch(r, fa, ns);
 #ifdef HP_PROF_TRACK
             if (r.prof) r.prof[22] += wv::clock() - tcb_;
 #endif
