@@ -1117,9 +1117,17 @@ HP_INL bool bi_near_diag(const lamsa_hp_para *P, int qlen, int tlen)
 }
 
 // ksw_bi_extend (src/ksw.c:862-926): result replaces out; returns the "gap exists" flag
-HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, int rh0, CigV &out)
+HP_NOINL int ksw_bi_extend(Ctx &cx_, int qlen, Seq q, int tlen, Seq t, int lh0, int rh0, CigV &out_)
 {
-    const lamsa_hp_para *P = cx.P;
+    // Arguments of a non-inlined device function arrive in vector registers; everything here is wave-uniform, and what lives across the
+    // calls below should sit in scalar registers (the DP routines use up to 55 of the 64 vector registers the fill kernel has per lane:
+    // what the caller keeps in vector registers goes to scratch and back around every call).
+    Ctx &cx = *(Ctx *)wv::uni64((long long)&cx_);
+    CigV &out = *(CigV *)wv::uni64((long long)&out_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); lh0 = wv::uni(lh0); rh0 = wv::uni(rh0);
+    q.p = (const uint8_t *)wv::uni64((long long)q.p); q.stride = wv::uni(q.stride);
+    t.p = (const uint8_t *)wv::uni64((long long)t.p); t.stride = wv::uni(t.stride);
+    const lamsa_hp_para *P = (const lamsa_hp_para *)wv::uni64((long long)cx.P);
     out.n = 0;
     if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }
     if (qlen == 0 && lh0 > 0) {
@@ -1134,8 +1142,11 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
     int ret = 0, res, lqe, lte, rqe, rte;
     CigV L, R;
     if (!cig_alloc(cx, L, qlen + tlen + 4) || !cig_alloc(cx, R, qlen + tlen + 4)) { arena_release(cx.tmp, mark); return 0; }
-    const int w = iabs(qlen - tlen) + 3 > P->band_w ? iabs(qlen - tlen) + 3 : P->band_w;   // :873
+    L.c = (cig_t *)wv::uni64((long long)L.c); R.c = (cig_t *)wv::uni64((long long)R.c); L.cap = wv::uni(L.cap); R.cap = wv::uni(R.cap);
+    const int band_w = wv::uni(P->band_w);
+    const int w = iabs(qlen - tlen) + 3 > band_w ? iabs(qlen - tlen) + 3 : band_w;         // :873
     res = ksw_extend_c(cx, qlen, q, tlen, t, w, lh0, &lqe, &lte, &L);
+    res = wv::uni(res); lqe = wv::uni(lqe); lte = wv::uni(lte);
     HP_T0(tbi1_);
     if (res < 2) {                                                                          // :875-880
         cig_pushv(cx, out, L.c, L.n);
@@ -1144,6 +1155,7 @@ HP_NOINL int ksw_bi_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int lh0, i
         ksw_global(cx, qlen, q, tlen, t, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &out);
     } else {
         res = ksw_extend_r(cx, qlen, q, tlen, t, w, rh0, &rqe, &rte, &R);
+        res = wv::uni(res); rqe = wv::uni(rqe); rte = wv::uni(rte);
         if (res < 2) {                                                                      // :892-899
             cig_push1(cx, R, res == 0 ? ((tlen - rte) << 4) | C_D : ((qlen - rqe) << 4) | C_I);
             cig_invert(R.c, R.n);
