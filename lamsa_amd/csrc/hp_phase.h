@@ -290,6 +290,15 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
     r.flip = strand != 1;                                                      // seed ids as a '-' line sees them (frag_check.c:926)
     const int64_t rbase = a.in.read_off[rd];
     long long tb = 0;
+    // the fragment of every seed of the line, written once fragment by fragment (a binary search per seed is eight dependent loads)
+    int32_t *frag_of = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(np + 1));
+    if (!frag_of) { r.flip = false; return; }
+    {
+        HP_G int32_t *g_fo = (HP_G int32_t *)frag_of;
+        const HP_G int32_t *g_so = (const HP_G int32_t *)F.fr_seed_off;
+        for (int b0 = 0; b0 < nfr; b0 += 64) { WAVE_FOR(l) { const int f = f0 + b0 + l; if (b0 + l < nfr) { for (int q = g_so[f]; q < g_so[f + 1]; ++q) g_fo[q - p0] = f; } } }
+        wv::sync();
+    }
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
         wv::Lane<int> ty, qo, ql, tl; wv::Lane<long long> tk, sl;
         WAVE_FOR(l) {
@@ -323,8 +332,7 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                 }
             } else if (c < n_cand) {                                            // gap in front of the seed at position p, frag_extend :360-385
                 const int p = p0 + (c - (nfr - 1));
-                int lo = f0, hi = f0 + nfr;                                     // its fragment: the last one starting at or before p
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (F.fr_seed_off[mid] <= p) lo = mid; else hi = mid; }
+                const int lo = ((const HP_G int32_t *)frag_of)[p - p0];        // its fragment
                 const int fb = F.fr_seed_off[lo], fe = F.fr_seed_off[lo + 1], i = p - fb, seed_n = fe - fb;
                 const int ip = strand == 1 ? i + 1 : i - 1;                     // the seed walked before it
                 if (seed_n > 1 && ip >= 0 && ip < seed_n) {
