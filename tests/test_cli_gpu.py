@@ -86,3 +86,20 @@ def test_default_run_equals_reference_default_run(name, tmp_path):
     p = subprocess.run([BIN, "aln", "-N"] + args + [ref, reads], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     assert G.strip_pg(p.stdout) == G.strip_pg(want)
+
+
+def test_map_is_read_while_the_mapper_writes_it_on_the_gpu(tmp_path):
+    """The product binary starts the mapper (a stand-in that writes the fixture's map in slow pieces) BEFORE its first GPU call and reads
+    the map while it grows: same SAM as with `-N` on the finished map, and with `--seed-first`."""
+    import shutil
+    import test_cli_cpu
+    ref, reads, args, gold = G.stage_scenario("c3_ont", str(tmp_path))
+    keep = str(tmp_path / "map.keep")
+    shutil.move(reads + ".seed.gem.map", keep)
+    gem = test_cli_cpu._fake_mapper(str(tmp_path / "gem"), keep, pieces=8, delay=0.2)
+    for extra in ([], ["--seed-first"]):
+        p = subprocess.run([BIN, "aln", "-R", "0", "-t", "4", "--batch", "16", "--gem-dir", gem] + extra + args + [ref, reads], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "gem-mapper done!" in p.stderr
+        assert G.strip_pg(p.stdout) == G.strip_pg(gold)
+        os.remove(reads + ".seed.gem.map")
