@@ -1687,7 +1687,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
             wv::sync();
             if (any_big) dp_update_range(r, hoff(r, 1), H, 0, MIN_FLAG, false, false, C.big);
         }
-        arena_release(r.cx.tmp, cmark);
+        if (!have_cl) arena_release(r.cx.tmp, cmark);                  // the clusters stay: the line loop below works on them (hp_gaps.h)
         if (!build_sons(r, (HP_L uint64_t *)r.cx.lds, r.cx.lds_words / 2)) return false;
     }
 
@@ -1723,7 +1723,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
         // pool never overflows: every node joins at most one line (TRACKED), plus one slack slot per line
         int32_t *ln = L.pool + next_start;
         T.off[l_i] = T.used; T.cnt[l_i] = 0;
-        const int node_i = line_build(r, max_node, ln, _line, &line_score, &line_NM, T, l_i);       // anchors, mini DPs of the gaps, triggers (hp_gaps.h)
+        const int node_i = line_build(r, max_node, ln, _line, &line_score, &line_NM, T, l_i, have_cl ? &C : nullptr);       // anchors, mini DPs of the gaps, triggers (hp_gaps.h)
         if (node_i < 0) return false;
         for (int k = 0; k < node_i / 2; ++k) { int t = ln[k]; ln[k] = ln[node_i - k - 1]; ln[node_i - k - 1] = t; }
         L.start[l_i] = next_start; L.len[l_i] = node_i; L.ls[l_i] = L.bs[l_i] = line_score; L.nm[l_i] = line_NM;

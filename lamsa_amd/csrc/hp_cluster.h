@@ -32,6 +32,7 @@ struct Clusters {
     int n_cl;                    // number of clusters
     int32_t *cs;                 // [n_cl + 1] first rank of each cluster (cs[n_cl] = H)
     int32_t *cl_lo_r;            // [H] by rank: first rank of the rank's cluster
+    int32_t *ce;                 // [H] by rank, valid at the first rank of a cluster: one past its last rank
     int32_t *csrt;               // [H] rank positions lo..hi-1 of a cluster hold its hits in ascending hit order
     uint8_t *big;                // [H] by hit: 1 = the hit's cluster did not fit LDS (dp_update_range handles its targets)
     long long reach;             // Rcl
@@ -60,8 +61,9 @@ HP_NOINL bool clusters_build(ReadCtx &r, Clusters &C, HP_L uint64_t *lw, int lds
     C.cs = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 2));
     C.cl_lo_r = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
     C.csrt = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
+    C.ce = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 1));
     C.big = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
-    if (!C.cs || !C.cl_lo_r || !C.csrt || !C.big) return false;
+    if (!C.cs || !C.cl_lo_r || !C.csrt || !C.ce || !C.big) return false;
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
     HP_G int32_t *g_cs = (HP_G int32_t *)C.cs, *g_lo = (HP_G int32_t *)C.cl_lo_r;
@@ -99,6 +101,7 @@ HP_NOINL bool clusters_build(ReadCtx &r, Clusters &C, HP_L uint64_t *lw, int lds
     g_cs[n_cl] = H;
     C.n_cl = n_cl;
     wv::sync();
+    { HP_G int32_t *g_ce = (HP_G int32_t *)C.ce; for (int c0 = 0; c0 < n_cl; c0 += 64) { WAVE_FOR(l) { const int c = c0 + l; if (c < n_cl) g_ce[g_cs[c]] = g_cs[c + 1]; } } }
     // the hits of every cluster in ascending hit order: one sort on (first rank of the cluster, hit index); the clusters keep
     // their rank ranges
     const size_t mark = arena_mark(r.cx.tmp);

@@ -59,6 +59,11 @@ struct Ctx {
 #define HP_TADD(cx, slot, v) do { } while (0)
 #endif
 
+// path counters of the tests' CPU build (tests/emu/emu_api.cpp defines HP_STAT): which variant of a routine a test has really run
+#ifndef HP_STAT
+#define HP_STAT(i) do { } while (0)
+#endif
+
 // returns nullptr (and flags overflow) when the slab is exhausted; callers must cope
 HP_INL void *arena_alloc(Ctx &cx, size_t bytes) {
     size_t b = (bytes + 15) & ~(size_t)15;

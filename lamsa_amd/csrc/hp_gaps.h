@@ -33,6 +33,108 @@ struct GapOut {                   // per lane
     int r_from, r_score, r_NM, r_nn, r_mf;     // the right anchor after the forced update (_tail == 1)
 };
 
+// The DP of one gap on one lane over the m hits that frag_dp_per_init has activated (entries 0..m-1 of the lane's LDS strip, ascending hit
+// order; word w of entry e at strip[(e * 6 + w) * 64]: 0 position relative to the gap's base | 1 slot_j | 2 sid, len_dif << 16 |
+// 3 score << 16, NM | 4 hit | 5 from (0xff: the head) << 24, node_n << 16, son_flag << 8, match_flag): frag_dp_update over the range,
+// the end of the line (best end node, or the forced update of the right anchor given by rrel / r_sid / r_ld / r_mf / right_nm when
+// r_ok), the walk back.  left: the head (or -1 = START), left_NM its NM (0 for START).
+HP_INL void gap_dp_core(const EdgeK &K, HP_L int32_t *strip, int m, int sp, int left, int left_x, int right_x, int tail, int left_NM,
+                        bool r_ok, int rrel, int r_sid, int r_ld, int r_mf, int right_nm, GapOut &O)
+{
+#define GW(e, w) strip[((e) * 6 + (w)) * 64]
+    // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
+    for (int a = 0; a < m; ++a) {
+        const int tpos = GW(a, 0), tsj = GW(a, 1), t2 = GW(a, 2), t3 = GW(a, 3);
+        const int tslot = tsj >> 14, tsid = (int)(short)(t2 & 0xffff), tld = (int)(int8_t)((t2 >> 16) & 0xff);
+        if (tslot < left_x + 2) continue;                                                // targets are the hits of slots left_x + 2 .. (:1094)
+        const int t_score = t3 >> 16, t_NM = t3 & 0xffff;
+        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
+        for (int b = 0; b < a; ++b) {
+            const int qsj = GW(b, 1), qslot = qsj >> 14;
+            if (qslot >= tslot) continue;
+            const int q5 = GW(b, 5);
+            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;                 // '+': the candidate already has a match son, :718-720
+            const int q2 = GW(b, 2), q3 = GW(b, 3);
+            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), tpos, tsid, tld);
+            if (flag == F_UNCONNECT) continue;
+            const int pos = ((tslot - 1 - qslot) << 14) | (qsj & 16383);                // scan order: seeds descending, hits ascending
+            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + t_NM;
+            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
+            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
+            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }   // '-': first match precursor, :726-733
+        }
+        int w_b = -1, w_f = 0, w_score = t_score, w_nm = t_NM;
+        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
+        else if (best_b >= 0) {
+            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
+            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
+        }
+        if (w_b >= 0) {                                                                  // :753-761
+            const int q5 = GW(w_b, 5);
+            GW(a, 3) = (int)(((unsigned)w_score << 16) | (unsigned)(w_nm & 0xffff));
+            GW(a, 5) = (w_b << 24) | ((((q5 >> 16) & 0xff) + 1) << 16) | (GW(a, 5) & 0xff00) | w_f;
+            GW(w_b, 5) = (q5 & ~0xff00) | (w_f << 8);
+        }
+    }
+    // ---- the end of the line
+    int max_c = -1, max_n = 0, max_score, max_NM = 0, old_score, old_NM;
+    if (!tail) {                                                                         // best end node, :1105-1123
+        old_score = 1; old_NM = left_NM;
+        max_score = old_score;
+        int bh = -0x7fffffff, bl = -1, bb = -1;
+        for (int b = 0; b < m; ++b) {
+            const int q3 = GW(b, 3), qsj = GW(b, 1);
+            const int pos = ((right_x - 1 - (qsj >> 14)) << 14) | (qsj & 16383);
+            const int hi = (int)(((unsigned)(q3 >> 16) << 16) | (unsigned)(65535 - (q3 & 0xffff))), lo = (1 << 28) - 1 - pos;
+            if (hi > bh || (hi == bh && lo > bl)) { bh = hi; bl = lo; bb = b; }
+        }
+        if (bb >= 0) {
+            const int sc = bh >> 16, nm = 65535 - (bh & 0xffff);
+            if (sc > max_score || (sc == max_score && nm < max_NM)) { max_c = bb; max_score = sc; max_NM = nm; max_n = (GW(bb, 5) >> 16) & 0xff; }
+        }
+    } else {                                                                             // forced update of the right anchor, :1125-1134
+        old_score = 2 + score_table(r_mf); old_NM = left_NM + right_nm;
+        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
+        for (int b = 0; b < m && r_ok; ++b) {
+            const int qsj = GW(b, 1), qslot = qsj >> 14, q5 = GW(b, 5);
+            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;
+            const int q2 = GW(b, 2), q3 = GW(b, 3);
+            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), rrel, r_sid, r_ld);
+            if (flag == F_UNCONNECT) continue;
+            const int pos = ((right_x - 1 - qslot) << 14) | (qsj & 16383);
+            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + old_NM;
+            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
+            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
+            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }
+        }
+        int w_b = -1, w_f = 0, w_score = old_score, w_nm = old_NM;
+        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
+        else if (best_b >= 0) {
+            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
+            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
+        }
+        O.r_mf = r_mf;
+        if (w_b >= 0) { O.r_from = GW(w_b, 4); O.r_nn = ((GW(w_b, 5) >> 16) & 0xff) + 1; O.r_mf = w_f; max_c = w_b; }
+        O.r_score = w_score; O.r_NM = w_nm;
+        max_score = w_score; max_NM = w_nm; max_n = O.r_nn - 1;
+    }
+    // ---- walk back to the head (:1136-1147)
+    {
+        int c = max_c, node_i = max_n - 1;
+        bool bad = max_n > HP_GAP_MCAP;
+        while (c >= 0 && !bad) {
+            if (node_i < 0) { bad = true; break; }
+            O.ids[node_i] = GW(c, 4); O.mfs[node_i] = GW(c, 5) & 0xff; --node_i;
+            const int f = (GW(c, 5) >> 24) & 0xff;
+            c = f == 0xff ? -1 : f;
+        }
+        if (node_i >= 0) bad = true;
+        if (bad) { O.n = -2; return; }
+    }
+#undef GW
+    O.n = max_n; O.d_score = max_score - old_score; O.d_NM = max_NM - old_NM;
+}
+
 // One gap on one lane.  left >= 0 (the head), right >= 0 when tail, right_x = right's slot (or seed_out).  LDS strip: word w of
 // entry e at strip[(e * 6 + w) * 64].
 HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int left, int right, int left_x, int right_x, int tail, GapOut &O)
@@ -41,7 +143,7 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = left; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
-    const int k_lo = (int)(g_hoff[left_x + 1] - r.hb), k_hi = (int)(g_hoff[right_x] - r.hb), k_t0 = (int)(g_hoff[left_x + 2] - r.hb);
+    const int k_lo = (int)(g_hoff[left_x + 1] - r.hb), k_hi = (int)(g_hoff[right_x] - r.hb);
 #ifdef HP_PROF
     if (r.prof) atomicAdd((unsigned long long *)&r.prof[11], (unsigned long long)(k_hi - k_lo));
     if (k_hi - k_lo > HP_GAP_RANGE) { if (r.prof) atomicAdd((unsigned long long *)&r.prof[13], 1ull); return; }
@@ -80,103 +182,16 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
             ++m;
         }
     }
-    // ---- frag_dp_update over the range (:701-764), targets in ascending hit order
-    for (int a = 0; a < m; ++a) {
-        const int tid = GW(a, 4);
-        if (tid < k_t0) continue;
-        const int tpos = GW(a, 0), tsj = GW(a, 1), t2 = GW(a, 2), t3 = GW(a, 3);
-        const int tslot = tsj >> 14, tsid = (int)(short)(t2 & 0xffff), tld = (int)(int8_t)((t2 >> 16) & 0xff);
-        const int t_score = t3 >> 16, t_NM = t3 & 0xffff;
-        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
-        for (int b = 0; b < a; ++b) {
-            const int qsj = GW(b, 1), qslot = qsj >> 14;
-            if (qslot >= tslot) continue;
-            const int q5 = GW(b, 5);
-            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;                 // '+': the candidate already has a match son, :718-720
-            const int q2 = GW(b, 2), q3 = GW(b, 3);
-            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), tpos, tsid, tld);
-            if (flag == F_UNCONNECT) continue;
-            const int pos = ((tslot - 1 - qslot) << 14) | (qsj & 16383);                // scan order: seeds descending, hits ascending
-            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + t_NM;
-            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
-            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
-            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }   // '-': first match precursor, :726-733
-        }
-        int w_b = -1, w_f = 0, w_score = t_score, w_nm = t_NM;
-        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
-        else if (best_b >= 0) {
-            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
-            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
-        }
-        if (w_b >= 0) {                                                                  // :753-761
-            const int q5 = GW(w_b, 5);
-            GW(a, 3) = (int)(((unsigned)w_score << 16) | (unsigned)(w_nm & 0xffff));
-            GW(a, 5) = (w_b << 24) | ((((q5 >> 16) & 0xff) + 1) << 16) | (GW(a, 5) & 0xff00) | w_f;
-            GW(w_b, 5) = (q5 & ~0xff00) | (w_f << 8);
-        }
-    }
-    // ---- the end of the line
-    int max_c = -1, max_n = 0, max_score, max_NM = 0, old_score, old_NM;
-    const int left_NM = head_nm;
-    if (!tail) {                                                                         // best end node, :1105-1123
-        old_score = 1; old_NM = left_NM;
-        max_score = old_score;
-        int bh = -0x7fffffff, bl = -1, bb = -1;
-        for (int b = 0; b < m; ++b) {
-            const int q3 = GW(b, 3), qsj = GW(b, 1);
-            const int pos = ((right_x - 1 - (qsj >> 14)) << 14) | (qsj & 16383);
-            const int hi = (int)(((unsigned)(q3 >> 16) << 16) | (unsigned)(65535 - (q3 & 0xffff))), lo = (1 << 28) - 1 - pos;
-            if (hi > bh || (hi == bh && lo > bl)) { bh = hi; bl = lo; bb = b; }
-        }
-        if (bb >= 0) {
-            const int sc = bh >> 16, nm = 65535 - (bh & 0xffff);
-            if (sc > max_score || (sc == max_score && nm < max_NM)) { max_c = bb; max_score = sc; max_NM = nm; max_n = (GW(bb, 5) >> 16) & 0xff; }
-        }
-    } else {                                                                             // forced update of the right anchor, :1125-1134
+    // ---- frag_dp_update over the range, the end of the line, the walk back
+    bool r_ok = false; int rrel = 0, r_sid = 0, r_ld = 0, r_mf = 0, right_nm = 0;
+    if (tail) {
         const NodeS Rt = node_load(ns + right);
-        const int right_nm = g_hnm[right];
-        old_score = 2 + score_table(Rt.match_flag); old_NM = left_NM + right_nm;
-        const long long rrel = Rt.pos - Fh.pos;
-        int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
-        const bool r_ok = Rt.chr == Fh.chr && Rt.strand == sp && rrel <= 0x3fffffffll && rrel >= -0x3fffffffll;
-        for (int b = 0; b < m && r_ok; ++b) {
-            const int qsj = GW(b, 1), qslot = qsj >> 14, q5 = GW(b, 5);
-            if (sp == 1 && ((q5 >> 8) & 0xff) <= F_MATCH_THD) continue;
-            const int q2 = GW(b, 2), q3 = GW(b, 3);
-            const int flag = gap_edge(K, sp, GW(b, 0), (int)(short)(q2 & 0xffff), (int)(int8_t)((q2 >> 16) & 0xff), (int)rrel, Rt.sid, Rt.len_dif8);
-            if (flag == F_UNCONNECT) continue;
-            const int pos = ((right_x - 1 - qslot) << 14) | (qsj & 16383);
-            const int cand = (q3 >> 16) + 1 + score_table(flag), nm = (q3 & 0xffff) + old_NM;
-            const int hi = (int)(((unsigned)cand << 16) | (unsigned)(65535 - nm)), lo = (1 << 28) - 1 - pos;
-            if (hi > best_hi || (hi == best_hi && lo > best_lo)) { best_hi = hi; best_lo = lo; best_b = b; best_f = flag; }
-            if (sp == -1 && flag <= F_MATCH_THD && 0 - pos > neg_p) { neg_p = 0 - pos; neg_b = b; neg_f = flag; neg_hi = hi; }
-        }
-        int w_b = -1, w_f = 0, w_score = old_score, w_nm = old_NM;
-        if (neg_b >= 0) { w_b = neg_b; w_f = neg_f; w_score = neg_hi >> 16; w_nm = 65535 - (neg_hi & 0xffff); }
-        else if (best_b >= 0) {
-            const int cand = best_hi >> 16, nm = 65535 - (best_hi & 0xffff);
-            if (cand > w_score || (cand == w_score && nm < w_nm)) { w_b = best_b; w_f = best_f; w_score = cand; w_nm = nm; }
-        }
-        O.r_mf = Rt.match_flag;
-        if (w_b >= 0) { O.r_from = GW(w_b, 4); O.r_nn = ((GW(w_b, 5) >> 16) & 0xff) + 1; O.r_mf = w_f; max_c = w_b; }
-        O.r_score = w_score; O.r_NM = w_nm;
-        max_score = w_score; max_NM = w_nm; max_n = O.r_nn - 1;
-    }
-    // ---- walk back to the head (:1136-1147)
-    {
-        int c = max_c, node_i = max_n - 1;
-        bool bad = max_n > HP_GAP_MCAP;
-        while (c >= 0 && !bad) {
-            if (node_i < 0) { bad = true; break; }
-            O.ids[node_i] = GW(c, 4); O.mfs[node_i] = GW(c, 5) & 0xff; --node_i;
-            const int f = (GW(c, 5) >> 24) & 0xff;
-            c = f == 0xff ? -1 : f;
-        }
-        if (node_i >= 0) bad = true;
-        if (bad) { O.n = -2; return; }
+        const long long rr = Rt.pos - Fh.pos;
+        right_nm = g_hnm[right]; r_sid = Rt.sid; r_ld = Rt.len_dif8; r_mf = Rt.match_flag; rrel = (int)rr;
+        r_ok = Rt.chr == Fh.chr && Rt.strand == sp && rr <= 0x3fffffffll && rr >= -0x3fffffffll;
     }
 #undef GW
-    O.n = max_n; O.d_score = max_score - old_score; O.d_NM = max_NM - old_NM;
+    gap_dp_core(K, strip, m, sp, left, left_x, right_x, tail, head_nm, r_ok, rrel, r_sid, r_ld, r_mf, right_nm, O);
 }
 
 // The gaps of a line that no lane has taken (o_lane == 0), one after the other through mini_line.  A function of its own on purpose:
@@ -226,11 +241,233 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
     return R;
 }
 
+// ---------------------------------------------------------------- the gaps of a line from the point of view of its CLUSTER
+// Every node of a line lies in one cluster of the read's hits (hp_cluster.h: no edge other than F_CHR_DIF / F_UNCONNECT joins two
+// clusters), and so does every hit a gap's pass can put on the line: frag_dp_per_init keeps what the head connects to, a pass from
+// START is only read along the chain into its right anchor.  So instead of every gap scanning the hits of its seed range (all ~40
+// hits of the repetitive seeds in between, from every cluster, for each of a read's ~330 gaps), ONE pass over the hits of the
+// line's cluster (C.csrt: ascending hit order) finds, for every hit that a mini DP may use at all (dp_flag +-MULTI), the gap its seed
+// slot falls into -- a slot -> gap table in LDS -- and whether that gap's head connects to it; the survivors, in ascending hit order
+// and therefore grouped by gap, are what the mini DPs run on: one gap per lane (gap_dp_core) for up to HP_GAP_MCAP hits, the
+// wave-wide routine on the listed hits beyond that.  Gaps without a survivor -- nearly all of them at the read's true locus, where
+// frag_min_extend has already promoted the colinear hit of every repetitive seed -- cost nothing: their mini line is empty and the
+// forced update of their right anchor finds no candidate (what it would leave in the anchor's score / NM / node_n is never read
+// again: the anchor is TRACKED, no later pass initialises, updates or scans it).
+// gp: the per-gap arrays of line_build.  Returns pool_n >= 0, -1 (status flagged) or -2: not applicable (the caller scans by seed range).
+#ifndef HP_GAPTAB_CAP_RT
+#define HP_GAPTAB_CAP_RT(cap) (cap)          // slots the LDS table holds; the tests' CPU build lowers it
+#endif
+#ifndef HP_GAP_MCAP_RT
+#define HP_GAP_MCAP_RT(cap) (cap)            // survivors of a gap a lane takes; the tests' CPU build lowers it
+#endif
+// HP_STAT slots: 0 lines by cluster, 1 lines by seed range, 2 gaps in lanes, 3 of them from START, 4 gaps through the wave-wide routine, 5 of them through memory
+HP_NOINL GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int G, int32_t *gp, int GA, int32_t *pool, int32_t *pool_mf, int32_t *_line)
+{
+    Ctx &cx = r.cx;
+    const int H = r.H, seed_out = r.seed_out;
+    const EdgeK K = edge_consts(cx.P);
+    GapRest R; R.pool_n = -2; R.d_score = 0; R.d_NM = 0;
+    if (seed_out > HP_GAPTAB_CAP_RT(2 * cx.lds_words) || G > 32767 || HP_GAP_MCAP * 6 * 64 > cx.lds_words) return R;
+    if ((long long)(r.seed_id[seed_out - 1] - r.seed_id[0] + 1) * K.seed_step > 0x3fffffffll) return R;           // 32-bit geometry below
+    const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
+    const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
+    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_csrt = (const HP_G int32_t *)C.csrt;
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
+    const int lo = C.cl_lo_r[r.rnk[max_node]], hi = C.ce[lo], n_c = hi - lo;
+    const NodeS N0 = node_load(ns + g_srt[lo]), N1 = node_load(ns + g_srt[hi - 1]);
+    if (N1.pos - N0.pos > 0x3fffffffll) return R;
+    const int sp = N0.strand;
+    const HP_G int32_t *g_left = (const HP_G int32_t *)gp, *g_right = (const HP_G int32_t *)(gp + GA), *g_lx = (const HP_G int32_t *)(gp + 2 * GA),
+                       *g_rx = (const HP_G int32_t *)(gp + 3 * GA), *g_tail = (const HP_G int32_t *)(gp + 4 * GA);
+    HP_G int32_t *o_n = (HP_G int32_t *)(gp + 6 * GA), *o_off = (HP_G int32_t *)(gp + 7 * GA), *o_s0 = (HP_G int32_t *)(gp + 8 * GA), *o_m = (HP_G int32_t *)(gp + 9 * GA),
+                 *o_lane = (HP_G int32_t *)(gp + 15 * GA);
+    const size_t mark = arena_mark(cx.tmp);
+    int32_t *sv = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 8 * (size_t)(n_c + 1));       // the survivors: six strip words, the gap, a spare
+    int32_t *s_id = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(n_c + 64));          // their hits, as a plain list
+    int32_t *rs = (int32_t *)arena_alloc(cx, sizeof(int32_t) * (size_t)(n_c + 2));             // first survivor of every run (= gap with survivors)
+    if (!sv || !s_id || !rs) { arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
+    HP_G int32_t *g_sv = (HP_G int32_t *)sv, *g_sid = (HP_G int32_t *)s_id, *g_rs = (HP_G int32_t *)rs;
+    // ---- slot -> gap (16 bits per slot, -1: the slot of an anchor, or outside every gap)
+    HP_L int16_t *tab = (HP_L int16_t *)cx.lds;
+    wv::sync();                                                    // whatever used this LDS before is done
+    { const int nw = (seed_out + 1) / 2; for (int w0 = 0; w0 < nw; w0 += 64) { WAVE_FOR(l) { if (w0 + l < nw) cx.lds[w0 + l] = -1; } } }
+    wv::sync();
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        WAVE_FOR(l) {
+            const int g = g0 + l;
+            if (g < G) { o_n[g] = 0; o_off[g] = 0; o_lane[g] = 1; const int x1 = g_rx[g]; for (int x = g_lx[g] + 1; x < x1; ++x) tab[x] = (int16_t)g; }
+        }
+    }
+    wv::sync();
+    // ---- one pass over the cluster's hits: frag_dp_per_init (:766-784, :1086-1091) for every gap at once
+    int n_surv = 0, n_eval = 0;
+    for (int i0 = 0; i0 < n_c; i0 += 64) {
+        wv::Lane<int> keep, u0, u1, u2, u3, u4, u5, ug, evl;
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            int ev = 0;
+            int kp = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, wg = 0;
+            if (i < n_c) {
+                const int id = g_csrt[lo + i];
+                int a[4], b[4];
+                hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
+                const int df = (int)(int8_t)(b[1] & 0xff);
+                if (df == MULTI_FLAG || df == 0 - MULTI_FLAG) {
+                    const int g = tab[a[3] >> 14];
+                    if (g >= 0) {
+                        const int left = g_left[g];
+                        const NodeS F = node_load(ns + (left >= 0 ? left : g_right[g]));      // the gap's base: the head, or the right anchor of a pass from START
+                        const long long qpos = (long long)(((unsigned long long)(unsigned)a[1] << 32) | (unsigned)a[0]);
+                        const int rel = (int)(qpos - F.pos);
+                        const int qsid = (int)(int16_t)(b[0] & 0xffff), qld = (int)(int8_t)((b[0] >> 24) & 0xff), nm = g_hnm[id];
+                        w0 = rel; w1 = a[3]; w2 = (qsid & 0xffff) | ((qld & 0xff) << 16); w4 = id; wg = g;
+                        if (left >= 0) {
+                            const int flag = gap_edge(K, sp, 0, F.sid, F.len_dif8, rel, qsid, qld);
+                            ev = 1;
+                            if (flag != F_UNCONNECT) {
+                                kp = 1;
+                                w3 = (int)(((unsigned)(2 + score_table(flag)) << 16) | (unsigned)((nm + g_hnm[left]) & 0xffff));
+                                w5 = (0xff << 24) | (1 << 16) | (F_INIT << 8) | flag;       // from (0xff = the head) | node_n | son_flag | match_flag
+                            }
+                        } else {                                                             // from START: fnode_set(START, 1, NM, F_MATCH), :771
+                            kp = 1; w3 = (int)((1u << 16) | (unsigned)(nm & 0xffff)); w5 = (0xff << 24) | (1 << 16) | (F_INIT << 8) | F_MATCH;
+                        }
+                    }
+                }
+            }
+            keep[l] = kp; u0[l] = w0; u1[l] = w1; u2[l] = w2; u3[l] = w3; u4[l] = w4; u5[l] = w5; ug[l] = wg; evl[l] = ev;
+        }
+        n_eval += __builtin_popcountll(wv::ballot(evl));
+        const unsigned long long m = wv::ballot(keep);
+        if (!m) continue;
+        WAVE_FOR(l) {
+            if (keep[l]) {
+                const int at = n_surv + __builtin_popcountll(m & ((1ull << l) - 1));
+                hp_store16(g_sv + 8 * (size_t)at, u0[l], u1[l], u2[l], u3[l]); hp_store16(g_sv + 8 * (size_t)at + 4, u4[l], u5[l], ug[l], 0);
+                g_sid[at] = u4[l];
+            }
+        }
+        n_surv += __builtin_popcountll(m);
+    }
+    r.n_pairs += n_eval;
+    wv::sync();
+    // ---- runs of equal gap (ascending hits = ascending slots = descending gaps: a gap's survivors are consecutive)
+    int n_runs = 0;
+    for (int j0 = 0; j0 < n_surv; j0 += 64) {
+        wv::Lane<int> st;
+        WAVE_FOR(l) { const int j = j0 + l; st[l] = j < n_surv && (j == 0 || g_sv[8 * (size_t)j + 6] != g_sv[8 * (size_t)(j - 1) + 6]); }
+        const unsigned long long m = wv::ballot(st);
+        WAVE_FOR(l) { if (st[l]) g_rs[n_runs + __builtin_popcountll(m & ((1ull << l) - 1))] = j0 + l; }
+        n_runs += __builtin_popcountll(m);
+    }
+    WAVE_FOR(l) { if (l == 0) g_rs[n_runs] = n_surv; }
+    wv::sync();
+    // ---- the mini DPs, one gap per lane
+    int pool_n = 0, d_score = 0, d_NM = 0;
+    bool any_wide = false;
+#define GW(e, w) strip[((e) * 6 + (w)) * 64]
+    for (int q0 = 0; q0 < n_runs; q0 += 64) {
+        wv::Lane<int> nn, ds, dn, gl;
+        WAVE_FOR(l) {
+            const int q = q0 + l;
+            GapOut O; O.n = 0; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
+            int g = -1;
+            if (q < n_runs) {
+                const int s0 = g_rs[q], m = g_rs[q + 1] - s0;
+                g = g_sv[8 * (size_t)s0 + 6];
+                if (m > HP_GAP_MCAP_RT(HP_GAP_MCAP)) { O.n = -1; o_lane[g] = 0; o_s0[g] = s0; o_m[g] = m; }
+                else {
+                    HP_L int32_t *strip = cx.lds + l;
+                    HP_STAT(2);
+                    for (int e = 0; e < m; ++e) {
+                        int u[4], v[4];
+                        hp_load16(g_sv + 8 * (size_t)(s0 + e), u); hp_load16(g_sv + 8 * (size_t)(s0 + e) + 4, v);
+                        GW(e, 0) = u[0]; GW(e, 1) = u[1]; GW(e, 2) = u[2]; GW(e, 3) = u[3]; GW(e, 4) = v[0]; GW(e, 5) = v[1];
+                    }
+                    const int left = g_left[g], right = g_right[g], tail = g_tail[g];
+                    long long base = 0; int left_NM = 0, rrel = 0, r_sid = 0, r_ld = 0, r_mf = 0, right_nm = 0;
+                    if (left >= 0) { const NodeS Fh = node_load(ns + left); base = Fh.pos; left_NM = g_hnm[left]; }
+                    if (tail) {
+                        const NodeS Rt = node_load(ns + right);
+                        if (left < 0) base = Rt.pos;
+                        rrel = (int)(Rt.pos - base); r_sid = Rt.sid; r_ld = Rt.len_dif8; r_mf = Rt.match_flag; right_nm = g_hnm[right];
+                    }
+                    O.r_from = left;
+                    if (left < 0) HP_STAT(3);
+                    gap_dp_core(K, strip, m, sp, left, g_lx[g], g_rx[g], tail, left_NM, tail != 0, rrel, r_sid, r_ld, r_mf, right_nm, O);
+                    if (O.n >= 0 && tail) {                        // the right anchor after its forced update (:1125-1134)
+                        g_from[right] = O.r_from; gd[right].score = O.r_score; gd[right].NM = O.r_NM; g_node_n[right] = O.r_nn; gd[right].match_flag = (uint8_t)O.r_mf;
+                    }
+                }
+            }
+            nn[l] = O.n; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0; gl[l] = g;
+            // the nodes of the lane's mini line, staged in its strip until the pool offsets of the group are known
+            for (int k = 0; k < HP_GAP_MCAP; ++k) { if (k < O.n) { cx.lds[(k * 6 + 0) * 64 + l] = O.ids[k]; cx.lds[(k * 6 + 1) * 64 + l] = O.mfs[k]; } }
+        }
+        wv::Lane<int> bad, wide, cntl;
+        WAVE_FOR(l) { bad[l] = nn[l] == -2; wide[l] = nn[l] == -1; cntl[l] = nn[l] > 0 ? nn[l] : 0; }
+        if (wv::ballot(bad) != 0) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); R.pool_n = -1; return R; }    // "[frag mini dp] BUG" exit, :1140
+        if (wv::ballot(wide) != 0) any_wide = true;
+        wv::Lane<int> pre = cntl;
+        wv::scan_add_excl(pre);
+        const int tot = wv::reduce_sum(cntl);
+        if (pool_n + tot > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
+        WAVE_FOR(l) {
+            if (nn[l] > 0) {
+                const int g = gl[l], off = pool_n + pre[l];
+                o_n[g] = nn[l]; o_off[g] = off;
+                for (int k = 0; k < nn[l]; ++k) {
+                    const int id = cx.lds[(k * 6 + 0) * 64 + l], mf = cx.lds[(k * 6 + 1) * 64 + l];
+                    pool[off + k] = id; pool_mf[off + k] = mf; gd[id].match_flag = (uint8_t)mf;
+                }
+            }
+        }
+        pool_n += tot;
+        d_score += wv::reduce_sum(ds); d_NM += wv::reduce_sum(dn);
+        wv::sync();
+    }
+#undef GW
+    // ---- gaps with more survivors than a lane holds: the wave-wide routine on the listed hits, one gap after the other
+    if (any_wide) {
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            wv::Lane<int> todo, lf, rt, rx, tl, s0l, ml;
+            WAVE_FOR(l) {
+                const int g = g0 + l;
+                todo[l] = g < G && !o_lane[g];
+                lf[l] = g < G ? g_left[g] : -1; rt[l] = g < G ? g_right[g] : -1; rx[l] = g < G ? g_rx[g] : 0; tl[l] = g < G ? g_tail[g] : 0;
+                s0l[l] = todo[l] ? o_s0[g] : 0; ml[l] = todo[l] ? o_m[g] : 0;
+            }
+            unsigned long long m = wv::ballot(todo);
+            while (m) {
+                const int q = __builtin_ctzll(m), g = g0 + q;
+                m &= m - 1;
+                int dsc = 0, dnm = 0;
+                const int left = wv::bcast(lf, q), right = wv::bcast(rt, q), right_x = wv::bcast(rx, q), tail = wv::bcast(tl, q), s0 = wv::bcast(s0l, q), cnt = wv::bcast(ml, q);
+                int n = cnt <= 64 ? mini_line_sets<1>(r, left, right, right_x, _line, &dsc, &dnm, 1, tail, cnt, s_id + s0)
+                      : (cnt <= 64 * HP_MS_MAX_SETS ? mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, _line, &dsc, &dnm, 1, tail, cnt, s_id + s0) : -1);
+                HP_STAT(4);
+                if (n < 0) { HP_STAT(5); dsc = 0; dnm = 0; n = mini_line_mem(r, left, right, right_x, _line, &dsc, &dnm, 1, tail); }
+                if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
+                if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
+                o_n[g] = n; o_off[g] = pool_n;
+                wv::sync();
+                for (int k0 = 0; k0 < n; k0 += 64) { WAVE_FOR(l) { if (k0 + l < n) pool[pool_n + k0 + l] = _line[k0 + l]; } }
+                pool_n += n; d_score += dsc; d_NM += dnm;
+                wv::sync();
+            }
+        }
+    }
+    arena_release(cx.tmp, mark);
+    R.pool_n = pool_n; R.d_score = d_score; R.d_NM = d_NM;
+    return R;
+}
+
 // ---------------------------------------------------------------- one line of frag_line_BCC's loop (:1370-1432)
 // The anchors of the line from its end node `max_node` back to START, the mini DPs of all its gaps (one per lane where
 // possible, mini_line otherwise), the nodes in read order in ln[], the inter-line triggers (:1384-1386, :1404-1414).  Returns the
 // number of nodes, or -1 (status flagged).  `_line`: scratch of H + 2 words for mini_line.
-HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i)
+HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i, const Clusters *C = nullptr)
 {
     Ctx &cx = r.cx;
     const int H = r.H, seed_out = r.seed_out;
@@ -313,59 +550,70 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
 #if defined(HP_PROF) && !defined(HP_PROF_TRACK)
     if (r.prof) { r.prof[23] += G; if (G < HP_GAP_MIN) r.prof[54] += G; r.prof[55] += 1; }
 #endif
-    // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
-    // (a lane walks the hit range of its gap by itself, one dependent load after the other: that pays when many gaps share the wait,
-    // not for the two or three gaps of a short line)
-    const bool use_lanes = HP_CL_CAP_RT(1) > 0 && G >= HP_GAP_MIN;
+    // ---- the mini DPs.  By cluster when the read's hits have been clustered (gaps_by_cluster above); else every gap scans its own seed range:
     int pool_n = 0, d_score = 0, d_NM = 0;
-    for (int g0 = 0; g0 < G; g0 += 64) {
-        wv::Lane<int> nn, ds, dn;
-        WAVE_FOR(l) {
-            const int g = g0 + l;
-            GapOut O; O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
-            if (g < G && g_left[g] >= 0 && use_lanes) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
-            nn[l] = g < G ? O.n : 0; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0;
-            if (g < G) {
-                o_n[g] = O.n; o_ds[g] = O.d_score; o_dn[g] = O.d_NM; o_rf[g] = O.r_from; o_rs[g] = O.r_score; o_rn[g] = O.r_NM; o_rnn[g] = O.r_nn; o_rmf[g] = O.r_mf; o_lane[g] = O.n >= 0;
-            }
-            // the nodes of the lane's mini line, staged in its strip until the pool offsets of the group are known
-            for (int k = 0; k < HP_GAP_MCAP; ++k) { if (g < G && k < O.n) { cx.lds[(k * 6 + 0) * 64 + l] = O.ids[k]; cx.lds[(k * 6 + 1) * 64 + l] = O.mfs[k]; } }
-        }
-        wv::Lane<int> bad, cntl;
-        WAVE_FOR(l) { bad[l] = nn[l] == -2; cntl[l] = nn[l] > 0 ? nn[l] : 0; }
-        if (wv::ballot(bad) != 0) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); return -1; }    // "[frag mini dp] BUG" exit, :1140
-        wv::Lane<int> pre = cntl;
-        wv::scan_add_excl(pre);
-        WAVE_FOR(l) {
-            const int g = g0 + l;
-            if (g < G && nn[l] >= 0) {
-                o_off[g] = pool_n + pre[l];
-                for (int k = 0; k < nn[l]; ++k) { pool[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 0) * 64 + l]; pool_mf[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 1) * 64 + l]; }
-            }
-        }
-        pool_n += wv::reduce_sum(cntl);
-        d_score += wv::reduce_sum(ds); d_NM += wv::reduce_sum(dn);
-        wv::sync();
+    bool by_cluster = false;
+    if (C) {
+        const GapRest gr = gaps_by_cluster(r, *C, max_node, G, gp, GA, pool, pool_mf, _line);
+        if (gr.pool_n == -1) { arena_release(cx.tmp, mark); return -1; }
+        if (gr.pool_n >= 0) { by_cluster = true; pool_n = gr.pool_n; d_score = gr.d_score; d_NM = gr.d_NM; HP_STAT(0); }
+        HP_LSTAMP(18);
     }
-    // right anchors and line nodes of the gaps the lanes have done
-    for (int g0 = 0; g0 < G; g0 += 64) {
-        WAVE_FOR(l) {
-            const int g = g0 + l;
-            if (g < G && o_lane[g]) {
-                if (g_tail[g]) {
-                    const int right = g_right[g];
-                    g_from[right] = o_rf[g]; gd[right].score = o_rs[g]; gd[right].NM = o_rn[g]; g_node_n[right] = o_rnn[g]; gd[right].match_flag = (uint8_t)o_rmf[g];
+    if (!by_cluster) {
+        HP_STAT(1);
+        // ---- the mini DPs: one gap per lane (hp_gaps.h); what a lane cannot take goes through mini_line afterwards
+        // (a lane walks the hit range of its gap by itself, one dependent load after the other: that pays when many gaps share the wait,
+        // not for the two or three gaps of a short line)
+        const bool use_lanes = HP_CL_CAP_RT(1) > 0 && G >= HP_GAP_MIN;
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            wv::Lane<int> nn, ds, dn;
+            WAVE_FOR(l) {
+                const int g = g0 + l;
+                GapOut O; O.n = -1; O.d_score = 0; O.d_NM = 0; O.r_from = -1; O.r_score = 0; O.r_NM = 0; O.r_nn = 1; O.r_mf = 0;
+                if (g < G && g_left[g] >= 0 && use_lanes) gap_lane(r, K, cx.lds + l, g_left[g], g_right[g], g_lx[g], g_rx[g], g_tail[g], O);
+                nn[l] = g < G ? O.n : 0; ds[l] = O.n >= 0 ? O.d_score : 0; dn[l] = O.n >= 0 ? O.d_NM : 0;
+                if (g < G) {
+                    o_n[g] = O.n; o_ds[g] = O.d_score; o_dn[g] = O.d_NM; o_rf[g] = O.r_from; o_rs[g] = O.r_score; o_rn[g] = O.r_NM; o_rnn[g] = O.r_nn; o_rmf[g] = O.r_mf; o_lane[g] = O.n >= 0;
                 }
-                for (int k = 0; k < o_n[g]; ++k) gd[pool[o_off[g] + k]].match_flag = (uint8_t)pool_mf[o_off[g] + k];
+                // the nodes of the lane's mini line, staged in its strip until the pool offsets of the group are known
+                for (int k = 0; k < HP_GAP_MCAP; ++k) { if (g < G && k < O.n) { cx.lds[(k * 6 + 0) * 64 + l] = O.ids[k]; cx.lds[(k * 6 + 1) * 64 + l] = O.mfs[k]; } }
+            }
+            wv::Lane<int> bad, cntl;
+            WAVE_FOR(l) { bad[l] = nn[l] == -2; cntl[l] = nn[l] > 0 ? nn[l] : 0; }
+            if (wv::ballot(bad) != 0) { cx.status |= ST_REFEXIT; arena_release(cx.tmp, mark); return -1; }    // "[frag mini dp] BUG" exit, :1140
+            wv::Lane<int> pre = cntl;
+            wv::scan_add_excl(pre);
+            WAVE_FOR(l) {
+                const int g = g0 + l;
+                if (g < G && nn[l] >= 0) {
+                    o_off[g] = pool_n + pre[l];
+                    for (int k = 0; k < nn[l]; ++k) { pool[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 0) * 64 + l]; pool_mf[pool_n + pre[l] + k] = cx.lds[((k) * 6 + 1) * 64 + l]; }
+                }
+            }
+            pool_n += wv::reduce_sum(cntl);
+            d_score += wv::reduce_sum(ds); d_NM += wv::reduce_sum(dn);
+            wv::sync();
+        }
+        // right anchors and line nodes of the gaps the lanes have done
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            WAVE_FOR(l) {
+                const int g = g0 + l;
+                if (g < G && o_lane[g]) {
+                    if (g_tail[g]) {
+                        const int right = g_right[g];
+                        g_from[right] = o_rf[g]; gd[right].score = o_rs[g]; gd[right].NM = o_rn[g]; g_node_n[right] = o_rnn[g]; gd[right].match_flag = (uint8_t)o_rmf[g];
+                    }
+                    for (int k = 0; k < o_n[g]; ++k) gd[pool[o_off[g] + k]].match_flag = (uint8_t)pool_mf[o_off[g] + k];
+                }
             }
         }
-    }
-    wv::sync();
-    HP_LSTAMP(18);
-    {                                                                                   // the others, one at a time
-        const GapRest gr = gaps_one_by_one(r, G, gp, GA, pool, pool_n, _line);
-        if (gr.pool_n < 0) { arena_release(cx.tmp, mark); return -1; }
-        pool_n = gr.pool_n; d_score += gr.d_score; d_NM += gr.d_NM;
+        wv::sync();
+        HP_LSTAMP(18);
+        {                                                                                   // the others, one at a time
+            const GapRest gr = gaps_one_by_one(r, G, gp, GA, pool, pool_n, _line);
+            if (gr.pool_n < 0) { arena_release(cx.tmp, mark); return -1; }
+            pool_n = gr.pool_n; d_score += gr.d_score; d_NM += gr.d_NM;
+        }
     }
     *line_score += d_score; *line_NM += d_NM;
     HP_LSTAMP(19);

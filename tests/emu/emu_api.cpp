@@ -6,6 +6,12 @@
 #include <vector>
 int g_emu_cl_cap = 1 << 30;            // tests: clusters larger than this take the HBM path of the main chaining pass (hp_cluster.h)
 #define HP_CL_CAP_RT(cap) (g_emu_cl_cap < (cap) ? g_emu_cl_cap : (cap))
+int g_emu_gaptab_cap = 1 << 30;        // tests: reads with more seed slots than this scan their gaps by seed range (hp_gaps.h)
+#define HP_GAPTAB_CAP_RT(cap) (g_emu_gaptab_cap < (cap) ? g_emu_gaptab_cap : (cap))
+int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than this take the wave-wide routine (hp_gaps.h)
+#define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
+long long g_emu_stat[16];              // path counters (HP_STAT slots of the device sources)
+#define HP_STAT(i) (++g_emu_stat[i])
 #include "hp_dp_batch.h"
 
 using namespace hp;
@@ -81,6 +87,9 @@ extern "C" long long emu_last_job_words() { return g_emu_job_words; }      // CI
 extern "C" void emu_set_lane_dp(int on) { g_emu_lane_dp = on; }           // 0: the fill runs every DP itself (one job per wave)
 extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
+extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab_cap > 0 ? tab_cap : (tab_cap < 0 ? 0 : 1 << 30); g_emu_gap_mcap = mcap > 0 ? mcap : (mcap < 0 ? 0 : 1 << 30); }
+extern "C" long long emu_stat(int i) { return g_emu_stat[i & 15]; }
+extern "C" void emu_stat_reset() { memset(g_emu_stat, 0, sizeof g_emu_stat); }
 extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
 
 extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, const lamsa_hp_batch *B, int scale, size_t slab_bytes,

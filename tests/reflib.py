@@ -370,13 +370,16 @@ def emu_lane_dp(jobs, hp_para, kind, w, h0):
     return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True):
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None):
     """Per-read result streams from the device sources compiled with the CPU lane emulation.
     phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
-    cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h)."""
+    cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h).
+    gaptab_cap / gap_mcap: reads with more seed slots scan the gaps of a line by seed range instead of by cluster / gaps with more
+    survivors take the wave-wide mini DP (hp_gaps.h); < 0 = none qualifies.  stats: a list that receives the HP_STAT path counters."""
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
     E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap)); E.emu_set_lane_dp(1 if lane_dp else 0)
+    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
     n = batch.n_reads
     hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
@@ -385,6 +388,9 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     off = np.zeros(max(n, 1), np.int64); ln = np.zeros(max(n, 1), np.int32); st = np.zeros(max(n, 1), np.int32)
     E.emu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     E.emu_align_batch(C.byref(hp_para), C.byref(hr), C.byref(hb), scale, slab_bytes, stream.ctypes.data, cap, C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
+    if stats is not None:
+        stats[:] = [int(E.emu_stat(i)) for i in range(16)]
+    E.emu_set_gap_caps(0, 0)
     return split_streams(stream, off[:n], ln[:n]), st[:n].copy()
 
 

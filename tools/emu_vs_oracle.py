@@ -18,12 +18,13 @@ def main():
                                  ("pb20k", "pacbio", 64, 20000, {"band_w": 200})):
         n = max(8, int(n * scale))
         B = simbatch.SimBatch(ref, n, L, prof, seed=77, threads=8)
-        s = reflib.emu_streams(B, hp.make_para(rt, **over))
+        stats = []
+        s = reflib.emu_streams(B, hp.make_para(rt, **over), stats=stats)
         s = s[0] if isinstance(s, tuple) else s
         want = reflib.oracle_streams(B, reflib.lo_para(rt, **over), 8)
         same = sum(1 for i in range(n) if list(want[i]) == list(s[i]))
         bad += n - same
-        print("%-8s emulated kernels == oracle on %d / %d reads" % (prof, same, n))
+        print("%-8s emulated kernels == oracle on %d / %d reads; path counters %s" % (prof, same, n, stats[:8]))
     return 1 if bad else 0
 
 
