@@ -702,7 +702,7 @@ HP_FN void cut_branch(ReadCtx &r, int f, NScore &ns)
     r.n_in_de[f] = 0;
     leaf_mark(r, f);                                  // f is complete: a track starts from it when its seed is reached
 }
-HP_NOINL void branch_track(ReadCtx &r, int n, NScore &ns)
+HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
 {   // branch_track_new, :873-920
     // The walk up a chain is a pointer chase through HBM: what a step needs (son count, score, predecessor) is requested together, one
     // memory round trip per step, and the nodes walked are kept in a lane register so that node_add_score need not chase them again.
@@ -1275,6 +1275,8 @@ struct LSet {
     int32_t *start, *len, *lb, *rb, *mf, *mh, *ls, *bs, *nm;   // per line (L_LB..L_NM, lamsa_aln.h:139-149)
     int32_t *rank, *sel;                  // line_rank / line_select_rank
     int n, cap;
+    int32_t *fx, *lx;                     // first / last seed slot of every line, when staged (lset_stage); else nullptr
+    int32_t *xtra; int xtra_n;            // staged: spare words of this wave's LDS for the temporaries of line_filter
 };
 HP_FN bool lset_alloc(Ctx &cx, LSet &L, int pool_cap, int line_cap)
 {
@@ -1285,17 +1287,49 @@ HP_FN bool lset_alloc(Ctx &cx, LSet &L, int pool_cap, int line_cap)
     L.start = m; L.len = m + c; L.lb = m + 2 * c; L.rb = m + 3 * c; L.mf = m + 4 * c; L.mh = m + 5 * c;
     L.ls = m + 6 * c; L.bs = m + 7 * c; L.nm = m + 8 * c; L.rank = m + 9 * c; L.sel = m + 10 * c;
     L.pool_cap = pool_cap; L.cap = line_cap; L.n = 0;
+    L.fx = L.lx = nullptr; L.xtra = nullptr; L.xtra_n = 0;
     return true;
 }
-HP_INL int firstx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.pool[L.start[l]]]; }
-HP_INL int lastx(const ReadCtx &r, const LSet &L, int l) { return r.n_seed[L.pool[L.start[l] + L.len[l] - 1]]; }
+HP_INL int firstx(const ReadCtx &r, const LSet &L, int l) { return L.fx ? L.fx[l] : r.n_seed[L.pool[L.start[l]]]; }
+HP_INL int lastx(const ReadCtx &r, const LSet &L, int l) { return L.lx ? L.lx[l] : r.n_seed[L.pool[L.start[l] + L.len[l] - 1]]; }
+
+// The per-line arrays of lines 0..n-1 copied into this wave's LDS (S points there; the node pool stays where it is), plus the first and
+// last seed slot of every line: line_set_bound and frag_dp_path (:425, :1152) are a few hundred dependent look-ups of single words per
+// read -- L.mf[L.rank[i]], the slot of a line's end node -- each a round trip to HBM otherwise.  False when they do not fit.
+HP_INL bool lset_stage(const ReadCtx &r, const LSet &L, int n, LSet &S)
+{
+    const int c = n + 1;
+    if (n <= 0 || 13 * c + 64 > r.cx.lds_words) return false;
+    HP_L int32_t *w = r.cx.lds;
+    wv::sync();                                                    // whatever used this LDS before is done
+    const HP_G int32_t *src[11] = { (const HP_G int32_t *)L.start, (const HP_G int32_t *)L.len, (const HP_G int32_t *)L.lb, (const HP_G int32_t *)L.rb, (const HP_G int32_t *)L.mf,
+                                    (const HP_G int32_t *)L.mh, (const HP_G int32_t *)L.ls, (const HP_G int32_t *)L.bs, (const HP_G int32_t *)L.nm, (const HP_G int32_t *)L.rank, (const HP_G int32_t *)L.sel };
+    const HP_G int32_t *g_pool = (const HP_G int32_t *)L.pool, *g_seed = (const HP_G int32_t *)r.n_seed;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        WAVE_FOR(l) {
+            const int i = i0 + l;
+            if (i < n) {
+#pragma unroll
+                for (int a = 0; a < 11; ++a) w[a * c + i] = src[a][i];
+                const int st = src[0][i], ln = src[1][i];
+                w[11 * c + i] = ln > 0 ? g_seed[g_pool[st]] : 0; w[12 * c + i] = ln > 0 ? g_seed[g_pool[st + ln - 1]] : 0;
+            }
+        }
+    }
+    wv::sync();
+    S = L;
+    int32_t *m = (int32_t *)w;
+    S.start = m; S.len = m + c; S.lb = m + 2 * c; S.rb = m + 3 * c; S.mf = m + 4 * c; S.mh = m + 5 * c;
+    S.ls = m + 6 * c; S.bs = m + 7 * c; S.nm = m + 8 * c; S.rank = m + 9 * c; S.sel = m + 10 * c; S.fx = m + 11 * c; S.lx = m + 12 * c;
+    S.xtra = m + 13 * c; S.xtra_n = r.cx.lds_words - 13 * c;
+    return true;
+}
 
 HP_FN void sort_endpos(ReadCtx &r, LSet &L, int ls, int len, int32_t *tmp_pos)
 {   // line_sort_endpos, :12 -- end slot descending, stable (the goldens come from glibc's merge sort).  Every line finds its own
     // place: the number of lines that end later, or as late and come first -- one line per lane, the keys of all lines streamed past
-    const HP_G int32_t *g_pool = (const HP_G int32_t *)L.pool, *g_start = (const HP_G int32_t *)L.start, *g_len = (const HP_G int32_t *)L.len, *g_seed = (const HP_G int32_t *)r.n_seed;
-    HP_G int32_t *g_tmp = (HP_G int32_t *)tmp_pos, *g_rank = (HP_G int32_t *)L.rank, *g_sel = (HP_G int32_t *)L.sel;
-    for (int i0 = 0; i0 < len; i0 += 64) { WAVE_FOR(l) { const int i = i0 + l; if (i < len) g_tmp[i] = g_seed[g_pool[g_start[ls + i] + g_len[ls + i] - 1]]; } }
+    int32_t *g_tmp = tmp_pos, *g_rank = L.rank, *g_sel = L.sel;          // generic pointers: the arrays may be staged in LDS (lset_stage)
+    for (int i0 = 0; i0 < len; i0 += 64) { WAVE_FOR(l) { const int i = i0 + l; if (i < len) g_tmp[i] = lastx(r, L, ls + i); } }
     wv::sync();
     for (int i0 = 0; i0 < len; i0 += 64) {
         wv::Lane<int> key, place;
@@ -1336,7 +1370,7 @@ HP_FN int line_merge(ReadCtx &r, LSet &L, int a, int b, float ovlp_r)
 }
 
 // best + secondaries of one cluster mb[0..mbn) (line indices); winners to mf[0..*mfn) when mf != nullptr
-HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, int per_max_multi, int32_t *tri_n, int32_t *mf, int *mfn)
+HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, int per_max_multi, int32_t *tri_n, int32_t *mf, int *mfn, int32_t *spare = nullptr, int spare_n = 0)
 {   // shared tail of line_filter (:166-235) and line_filter1 (:346-400)
     int b_score = 0, s_score = 0;
     for (int j = 0; j < mbn; ++j) {
@@ -1347,7 +1381,10 @@ HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, i
     if (s_score >= b_score / 2) {
         const size_t mark = arena_mark(r.cx.tmp);
         NScore ns;
-        if (!ns_alloc(r.cx, ns, per_max_multi + 1, per_max_multi)) { arena_release(r.cx.tmp, mark); return; }
+        if (spare && 3 * (per_max_multi + 2) <= spare_n) {             // the heap in the spare words of the staged line set (LDS)
+            ns.node = spare; ns.score = spare + (per_max_multi + 2); ns.NM = spare + 2 * (per_max_multi + 2);
+            ns.cap = per_max_multi + 1; ns.max_n = per_max_multi; ns.node_n = 0; ns.min_score_thd = 0;
+        } else if (!ns_alloc(r.cx, ns, per_max_multi + 1, per_max_multi)) { arena_release(r.cx.tmp, mark); return; }
         for (int j = 0; j < mbn; ++j) {
             const int li = mb[j];
             if (L.ls[li] >= b_score / 2) {
@@ -1397,11 +1434,17 @@ HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int p
 {
     const size_t mark = arena_mark(r.cx.tmp);
     // clusters are runs in rank order: cl_off[c] .. cl_off[c+1] index into mb[]; winners of cluster c at mfv[c*?]
-    int32_t *mb = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
-    int32_t *cl_off = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 2));
-    int32_t *cl_nm = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));      // 1: "not merged" cluster (y == -2)
-    int32_t *mfv = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(2 * len + 2));  // winners: cluster c at mfv[cl_off[c]+c ..]
-    int32_t *mfn = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    int32_t *mb, *cl_off, *cl_nm, *mfv, *mfn, *spare = nullptr; int spare_n = 0;
+    if (L.xtra && 6 * len + 7 <= L.xtra_n) {                           // staged line set: the temporaries next to it in LDS
+        mb = L.xtra; cl_off = mb + (len + 1); cl_nm = cl_off + (len + 2); mfv = cl_nm + (len + 1); mfn = mfv + (2 * len + 2);
+        spare = mfn + (len + 1); spare_n = L.xtra_n - (6 * len + 7);
+    } else {
+        mb = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+        cl_off = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 2));
+        cl_nm = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));      // 1: "not merged" cluster (y == -2)
+        mfv = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(2 * len + 2));  // winners: cluster c at mfv[cl_off[c]+c ..]
+        mfn = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    }
     if (!mb || !cl_off || !cl_nm || !mfv || !mfn) { arena_release(r.cx.tmp, mark); return; }
     int m_i = -1, nb = 0;
     for (int _i = ls; _i < ls + len; ++_i) {
@@ -1421,10 +1464,10 @@ HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int p
     for (int c = 0; c <= m_i; ++c) {
         int32_t *mf = mfv + cl_off[c] + c;             // room for (cluster size + 1) entries
         const int mbn = cl_off[c + 1] - cl_off[c];
-        if (!trg) { pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, nullptr, nullptr, nullptr); continue; }
+        if (!trg) { pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, nullptr, nullptr, nullptr, spare, spare_n); continue; }
         if (cl_nm[c]) { mf[0] = mb[cl_off[c]]; mfn[c] = 1; continue; }
         int n = 1;
-        pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, trg->cnt, mf, &n);
+        pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, trg->cnt, mf, &n, spare, spare_n);
         mfn[c] = n;
         for (int ii = 1; ii < n; ++ii) {               // inter-lines (candidate inversions), :236-273
             const int j = mf[ii], _j = L.sel[j];
@@ -1464,7 +1507,7 @@ HP_NOINL int set_bound(ReadCtx &r, LSet &L, int ls, int len, Trig *trg)
 {
     if (len <= 0) return len;
     const size_t mark = arena_mark(r.cx.tmp);
-    int32_t *tmp = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
+    int32_t *tmp = (L.xtra && len + 1 <= L.xtra_n) ? L.xtra : (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(len + 1));
     if (!tmp) return 0;
     sort_endpos(r, L, ls, len, tmp);
     arena_release(r.cx.tmp, mark);
@@ -1597,6 +1640,33 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F, FlStore *
 #include "hp_gaps.h"
 namespace hp {
 
+// The loop over the end nodes that branch tracking has left on the stack (:1370-1432): every one becomes a line -- its anchors, the mini
+// DPs of its gaps (hp_gaps.h), the inter-line triggers.  A function of its own, called once per read: what it keeps in registers does
+// not add to the pressure of the phases around it.  Returns the number of lines, or -1 (status flagged).
+HP_NOINL int lines_pop(ReadCtx &r, NScore &ns, LSet &L, Trig &T, int32_t *_line, const Clusters *C)
+{
+    int l_i = 0, next_start = 0, line_score = 0, line_NM = 0;
+    GapCache gc; gc.n = 0; gc.used = 0; gc.cap = 0; gc.ids = nullptr;
+    if (C) gapcache_init(r, gc);
+    for (;;) {
+        int max_node = ns_pop(ns, &line_score, &line_NM);
+        if (max_node < 0) break;
+        // pool never overflows: every node joins at most one line (TRACKED), plus one slack slot per line
+        int32_t *ln = L.pool + next_start;
+        T.off[l_i] = T.used; T.cnt[l_i] = 0;
+        const int node_i = line_build(r, max_node, ln, _line, &line_score, &line_NM, T, l_i, C, C ? &gc : nullptr);       // anchors, mini DPs of the gaps, triggers (hp_gaps.h)
+        if (node_i < 0) return -1;
+        { HP_G int32_t *g_ln = (HP_G int32_t *)ln; const int half = node_i / 2;                        // invert the line (:1419-1422), 64 pairs per step
+          for (int k0 = 0; k0 < half; k0 += 64) { WAVE_FOR(l) { const int k = k0 + l; if (k < half) { const int t = g_ln[k], u = g_ln[node_i - k - 1]; g_ln[k] = u; g_ln[node_i - k - 1] = t; } } }
+          wv::sync(); }
+        L.start[l_i] = next_start; L.len[l_i] = node_i; L.ls[l_i] = L.bs[l_i] = line_score; L.nm[l_i] = line_NM;
+        L.mf[l_i] = 0; L.mh[l_i] = 0; L.lb[l_i] = L.rb[l_i] = 0;
+        ++l_i; next_start += node_i + 1;
+        if (r.cx.status & ST_REFEXIT) return -1;
+    }
+    return l_i;
+}
+
 // ---------------------------------------------------------------- round 1: frag_line_BCC, :1305-1445
 #ifdef HP_PROF
 #define HP_CSTAMP(k) do { const long long now_ = wv::clock(); if (r.prof) r.prof[(k)] += now_ - tc_; tc_ = now_; } while (0)
@@ -1715,30 +1785,18 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
     T.cnt = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(o_l + 1));
     int32_t *_line = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(H + 2));
     if (!T.n1 || !T.n2 || !T.off || !T.cnt || !_line) return false;
-    int l_i = 0, next_start = 0, line_score = 0, line_NM = 0;
-#define HP_TRIG_PUSH(a, b) do { if (T.used < T.cap) { T.n1[T.used] = (a); T.n2[T.used] = (b); ++T.used; ++T.cnt[l_i]; } else r.cx.status |= ST_OVERFLOW; } while (0)
-    for (;;) {                                                                                    // :1370-1432
-        int max_node = ns_pop(ns, &line_score, &line_NM);
-        if (max_node < 0) break;
-        // pool never overflows: every node joins at most one line (TRACKED), plus one slack slot per line
-        int32_t *ln = L.pool + next_start;
-        T.off[l_i] = T.used; T.cnt[l_i] = 0;
-        const int node_i = line_build(r, max_node, ln, _line, &line_score, &line_NM, T, l_i, have_cl ? &C : nullptr);       // anchors, mini DPs of the gaps, triggers (hp_gaps.h)
-        if (node_i < 0) return false;
-        for (int k = 0; k < node_i / 2; ++k) { int t = ln[k]; ln[k] = ln[node_i - k - 1]; ln[node_i - k - 1] = t; }
-        L.start[l_i] = next_start; L.len[l_i] = node_i; L.ls[l_i] = L.bs[l_i] = line_score; L.nm[l_i] = line_NM;
-        L.mf[l_i] = 0; L.mh[l_i] = 0; L.lb[l_i] = L.rb[l_i] = 0;
-        ++l_i; next_start += node_i + 1;
-        if (r.cx.status & ST_REFEXIT) return false;
-    }
-#undef HP_TRIG_PUSH
+    const int l_i = lines_pop(r, ns, L, T, _line, have_cl ? &C : nullptr);                      // :1370-1432
+    if (l_i < 0) return false;
     L.n = l_i;
     HP_CSTAMP(9);
 #if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 4
     return true;
 #endif
-    const int line_n = set_bound(r, L, 0, l_i, &T);                   // :1435
-    const bool okf = build_flines(r, L, line_n, F, fs);
+    LSet S;
+    const bool staged = lset_stage(r, L, l_i, S);                     // the per-line arrays in LDS from here on, when they fit
+    LSet &LL = staged ? S : L;
+    const int line_n = set_bound(r, LL, 0, l_i, &T);                  // :1435
+    const bool okf = build_flines(r, LL, line_n, F, fs);
     HP_CSTAMP(10);
     if (r.prof) { r.prof[14] = o_l; r.prof[15] = H; }
     return okf;

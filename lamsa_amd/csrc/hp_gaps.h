@@ -25,6 +25,9 @@ static_assert(HP_GAP_MCAP >= 2, "the chaining kernels need at least 768 words of
 #ifndef HP_GAP_MIN
 #define HP_GAP_MIN 6              // lines with fewer gaps run them through the wave-wide routine
 #endif
+#ifndef HP_WALK_MIN
+#define HP_WALK_MIN 16            // clusters of at least this many hits have their lines' anchors walked in LDS
+#endif
 
 struct GapOut {                   // per lane
     int n;                        // nodes of the mini line (ascending), or -1: not handled here (fallback), -2: the reference's BUG exit
@@ -261,7 +264,16 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
 #define HP_GAP_MCAP_RT(cap) (cap)            // survivors of a gap a lane takes; the tests' CPU build lowers it
 #endif
 // HP_STAT slots: 0 lines by cluster, 1 lines by seed range, 2 gaps in lanes, 3 of them from START, 4 gaps through the wave-wide routine, 5 of them through memory
-HP_NOINL GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int G, int32_t *gp, int GA, int32_t *pool, int32_t *pool_mf, int32_t *_line)
+// The +-MULTI hits of the large clusters a read's lines have visited so far (ascending hit order, as in C.csrt): the ~20 lines of the read's
+// true locus share one cluster of several hundred hits, of which a few dozen are left for the mini DPs -- the first line lists them, the
+// others scan the list.  (A hit that a line has taken since is TRACKED; every scan tests the flag it loads anyway.)
+#ifndef HP_GAPCACHE_MIN
+#define HP_GAPCACHE_MIN 96           // clusters of fewer hits are scanned directly
+#endif
+struct GapCache { int n, used, cap; int lo[4], off[4], cnt[4]; int32_t *ids; };
+HP_INL void gapcache_init(ReadCtx &r, GapCache &gc) { gc.n = 0; gc.used = 0; gc.cap = r.H; gc.ids = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(r.H + 64)); if (!gc.ids) gc.cap = 0; }
+
+HP_HOT GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int G, int32_t *gp, int GA, int32_t *pool, int32_t *pool_mf, int32_t *_line, GapCache *gc = nullptr)
 {
     Ctx &cx = r.cx;
     const int H = r.H, seed_out = r.seed_out;
@@ -272,12 +284,11 @@ HP_NOINL GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, in
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
-    const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_csrt = (const HP_G int32_t *)C.csrt;
+    const HP_G int32_t *g_csrt = (const HP_G int32_t *)C.csrt;
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
     const int lo = C.cl_lo_r[r.rnk[max_node]], hi = C.ce[lo], n_c = hi - lo;
-    const NodeS N0 = node_load(ns + g_srt[lo]), N1 = node_load(ns + g_srt[hi - 1]);
-    if (N1.pos - N0.pos > 0x3fffffffll) return R;
-    const int sp = N0.strand;
+    if ((long long)(n_c - 1) * C.reach > 0x3fffffffll) return R;      // neighbours of a cluster are at most `reach` apart: its span fits 30 bits
+    const int sp = r.h_strand[max_node];
     const HP_G int32_t *g_left = (const HP_G int32_t *)gp, *g_right = (const HP_G int32_t *)(gp + GA), *g_lx = (const HP_G int32_t *)(gp + 2 * GA),
                        *g_rx = (const HP_G int32_t *)(gp + 3 * GA), *g_tail = (const HP_G int32_t *)(gp + 4 * GA);
     HP_G int32_t *o_n = (HP_G int32_t *)(gp + 6 * GA), *o_off = (HP_G int32_t *)(gp + 7 * GA), *o_s0 = (HP_G int32_t *)(gp + 8 * GA), *o_m = (HP_G int32_t *)(gp + 9 * GA),
@@ -300,16 +311,46 @@ HP_NOINL GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, in
         }
     }
     wv::sync();
-    // ---- one pass over the cluster's hits: frag_dp_per_init (:766-784, :1086-1091) for every gap at once
+    // ---- the hits to look at: the cluster's, or the +-MULTI ones among them listed by an earlier line of this read
+    const HP_G int32_t *g_src = g_csrt + lo; int n_src = n_c;
+    if (gc && n_c >= HP_GAPCACHE_MIN && gc->cap > 0) {
+        int e = -1, e_off = 0, e_cnt = 0;                              // (constant indices only: the directory stays in registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (q < gc->n && gc->lo[q] == lo) { e = q; e_off = gc->off[q]; e_cnt = gc->cnt[q]; }
+        if (e < 0 && gc->n < 4 && gc->used + n_c <= gc->cap) {
+            e = gc->n++; e_off = gc->used;
+            HP_G int32_t *g_dst = (HP_G int32_t *)(gc->ids + gc->used);
+            int cnt = 0;
+            for (int i0 = 0; i0 < n_c; i0 += 64) {
+                wv::Lane<int> isml, idl;
+                WAVE_FOR(l) {
+                    const int i = i0 + l;
+                    int v = 0, id = 0;
+                    if (i < n_c) { id = g_csrt[lo + i]; int b[4]; hp_load16((const HP_G char *)(ns + id) + 16, b); const int df = (int)(int8_t)(b[1] & 0xff); v = df == MULTI_FLAG || df == 0 - MULTI_FLAG; }
+                    isml[l] = v; idl[l] = id;
+                }
+                const unsigned long long m = wv::ballot(isml);
+                WAVE_FOR(l) { if (isml[l]) g_dst[cnt + __builtin_popcountll(m & ((1ull << l) - 1))] = idl[l]; }
+                cnt += __builtin_popcountll(m);
+            }
+            e_cnt = cnt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (q == e) { gc->lo[q] = lo; gc->off[q] = e_off; gc->cnt[q] = cnt; }
+            gc->used += cnt;
+            wv::sync();
+        }
+        if (e >= 0) { g_src = (const HP_G int32_t *)(gc->ids + e_off); n_src = e_cnt; }
+    }
+    // ---- one pass over them: frag_dp_per_init (:766-784, :1086-1091) for every gap at once
     int n_surv = 0, n_eval = 0;
-    for (int i0 = 0; i0 < n_c; i0 += 64) {
+    for (int i0 = 0; i0 < n_src; i0 += 64) {
         wv::Lane<int> keep, u0, u1, u2, u3, u4, u5, ug, evl;
         WAVE_FOR(l) {
             const int i = i0 + l;
             int ev = 0;
             int kp = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, wg = 0;
-            if (i < n_c) {
-                const int id = g_csrt[lo + i];
+            if (i < n_src) {
+                const int id = g_src[i];
                 int a[4], b[4];
                 hp_load16(ns + id, a); hp_load16((const HP_G char *)(ns + id) + 16, b);
                 const int df = (int)(int8_t)(b[1] & 0xff);
@@ -467,7 +508,7 @@ HP_NOINL GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, in
 // The anchors of the line from its end node `max_node` back to START, the mini DPs of all its gaps (one per lane where
 // possible, mini_line otherwise), the nodes in read order in ln[], the inter-line triggers (:1384-1386, :1404-1414).  Returns the
 // number of nodes, or -1 (status flagged).  `_line`: scratch of H + 2 words for mini_line.
-HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i, const Clusters *C = nullptr)
+HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int *line_score, int *line_NM, Trig &T, int l_i, const Clusters *C = nullptr, GapCache *gc = nullptr)
 {
     Ctx &cx = r.cx;
     const int H = r.H, seed_out = r.seed_out;
@@ -487,8 +528,38 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
 #else
 #define HP_LSTAMP(k) do { } while (0)
 #endif
-    for (int right = max_node; right >= 0 && A <= H; right = g_from[right]) anc[A++] = right;
     HP_G int32_t *g_anc = (HP_G int32_t *)anc, *g_ancx = (HP_G int32_t *)anc_x;
+    bool walked = false;
+    if (C) {
+        // A line of a large cluster (the read's true locus: a few hundred anchors) is a pointer chase of that many dependent loads.  Its
+        // cluster's predecessors are fetched into LDS first -- as places in the cluster's rank range, 64 hits per step -- and chased there.
+        const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
+        const int rk = r.rnk[max_node], lo = C->cl_lo_r[rk], n_c = C->ce[lo] - lo;
+        // (worth it for a long line only: the number of nodes the main pass counted up to the end node says how long)
+        if (n_c <= 6) HP_STAT(6); else if (n_c <= 16) HP_STAT(7); else HP_STAT(8);
+        if (n_c >= HP_WALK_MIN && n_c <= cx.lds_words && r.n_node_n[max_node] >= HP_WALK_MIN) {
+            wv::sync();                                                // whatever used this LDS before is done
+            for (int i0 = 0; i0 < n_c; i0 += 64) {
+                WAVE_FOR(l) {
+                    const int i = i0 + l;
+                    if (i < n_c) { const int f = g_from[g_srt[lo + i]]; const int p = f >= 0 ? g_rnk[f] - lo : -1; cx.lds[i] = (unsigned)p < (unsigned)n_c ? p : -1; }
+                }
+            }
+            wv::sync();
+            int cur = rk - lo;
+            while (cur >= 0 && A <= H) {
+                wv::Lane<int> pl;
+                WAVE_FOR(l) pl[l] = 0;
+                int cnt = 0;
+                while (cur >= 0 && cnt < 64 && A + cnt <= H) { WAVE_FOR(l) { if (l == cnt) pl[l] = cur; } ++cnt; cur = wv::uni(cx.lds[cur]); }
+                WAVE_FOR(l) { if (l < cnt) g_anc[A + l] = g_srt[lo + pl[l]]; }
+                A += cnt;
+            }
+            wv::sync();
+            walked = true;
+        }
+    }
+    if (!walked) for (int right = max_node; right >= 0 && A <= H; right = g_from[right]) anc[A++] = right;
     for (int i0 = 0; i0 < A; i0 += 64) { WAVE_FOR(l) { if (i0 + l < A) g_ancx[i0 + l] = g_seed[g_anc[i0 + l]]; } }
     wv::sync();
     HP_LSTAMP(16);
@@ -554,7 +625,7 @@ HP_NOINL int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, i
     int pool_n = 0, d_score = 0, d_NM = 0;
     bool by_cluster = false;
     if (C) {
-        const GapRest gr = gaps_by_cluster(r, *C, max_node, G, gp, GA, pool, pool_mf, _line);
+        const GapRest gr = gaps_by_cluster(r, *C, max_node, G, gp, GA, pool, pool_mf, _line, gc);
         if (gr.pool_n == -1) { arena_release(cx.tmp, mark); return -1; }
         if (gr.pool_n >= 0) { by_cluster = true; pool_n = gr.pool_n; d_score = gr.d_score; d_NM = gr.d_NM; HP_STAT(0); }
         HP_LSTAMP(18);
