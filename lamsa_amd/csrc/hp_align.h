@@ -113,32 +113,61 @@ HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, co
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
     r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.rc_read = nullptr; r.t_bases = 0;
-    r.prof = r.cx.prof; r.leaf_bits = nullptr; r.leaf_on = false;
+    r.prof = r.cx.prof; r.leaf_bits = nullptr; r.leaf_on = false; r.nodes_ready = false;
 }
 
-// the packed 32-byte record and the seed slot of every hit, one hit per lane: its slot by binary search in the read's
-// hit offsets (a few hundred entries, cache-resident)
+// The packed 32-byte record, the seed slot and the initial chaining state of every hit, one hit per lane.  A hit's slot comes from a
+// binary search in the read's hit offsets, which are staged in LDS first (nine dependent look-ups per hit otherwise).  The state is what
+// frag_line_BCC starts from (:1315-1334: fnode_set(START, 1, NM, F_MATCH) with the pass flag MIN for the hits of seeds with at most
+// first_loci_thd hits -- or for every hit when fewer than a third of the seeds are such), written here once instead of a second pass
+// over the records; chain_first finds r.nodes_ready set.  The side arrays (aux_bind) must be bound.
 HP_FN void nodes_fill(ReadCtx &r)
 {
     const HP_G int64_t *g_hoff = (const HP_G int64_t *)r.hit_off;
     const HP_G int32_t *g_sid = (const HP_G int32_t *)r.seed_id;
+    const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     const int64_t hb = r.hb;
-    const int H = r.H;
+    const int H = r.H, S = r.seed_out;
+    const lamsa_hp_para *P = r.cx.P;
+    HP_L int32_t *lo_ = r.cx.lds;
+    const bool in_lds = S + 1 <= r.cx.lds_words;
+    int min_num = 0;
+    if (in_lds) wv::sync();                                        // whatever used this LDS before is done
+    for (int s0 = 0; s0 <= S; s0 += 64) {
+        wv::Lane<int> few;
+        WAVE_FOR(l) {
+            const int s = s0 + l;
+            int f = 0;
+            if (s <= S) { const int o = (int)(g_hoff[s] - hb); if (in_lds) lo_[s] = o; if (s < S) f = (int)(g_hoff[s + 1] - hb) - o <= P->first_loci_thd; }
+            few[l] = f;
+        }
+        min_num += __builtin_popcountll(wv::ballot(few));
+    }
+    wv::sync();
+    const bool all_min = min_num == 0 || min_num * 3 < S;          // :1324-1331
+    HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_in_de = (HP_G int32_t *)r.n_in_de, *g_son_n = (HP_G int32_t *)r.n_son_n, *g_first = (HP_G int32_t *)r.n_first,
+                 *g_last = (HP_G int32_t *)r.n_last, *g_ms = (HP_G int32_t *)r.n_max_score, *g_mn = (HP_G int32_t *)r.n_max_NM, *g_mx = (HP_G int32_t *)r.n_max_node,
+                 *g_nn = (HP_G int32_t *)r.n_node_n, *g_seed = (HP_G int32_t *)r.n_seed;
+    HP_G NodeS *gd = (HP_G NodeS *)r.nd;
     for (int k0 = 0; k0 < H; k0 += 64) {
         WAVE_FOR(l) {
             const int k = k0 + l;
             if (k < H) {
-                int lo = 0, hi = r.seed_out;                 // largest slot s with hit_off[s] - hb <= k
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)(g_hoff[mid] - hb) <= k) lo = mid; else hi = mid; }
-                const int s = lo, b = (int)(g_hoff[s] - hb);
-                r.n_seed[k] = s;
-                NodeS q; q.pos = r.h_pos[k]; q.chr = r.h_chr[k]; q.slot_j = (s << 14) | (k - b); q.sid = (int16_t)g_sid[s];
-                q.strand = r.h_strand[k]; q.len_dif8 = (int8_t)r.h_len_dif[k]; q.pad_ = 0;
-                q.dp_flag = 0; q.son_flag = F_INIT; q.match_flag = 0; q.score = 0; q.NM = 0;
-                r.nd[k] = q;
+                int lo = 0, hi = S;                          // largest slot s with hit_off[s] - hb <= k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((in_lds ? lo_[mid] : (int)(g_hoff[mid] - hb)) <= k) lo = mid; else hi = mid; }
+                const int s = lo, b = in_lds ? lo_[s] : (int)(g_hoff[s] - hb), e = in_lds ? lo_[s + 1] : (int)(g_hoff[s + 1] - hb);
+                const int nm = g_hnm[k];
+                g_seed[k] = s;
+                const int64_t pos = r.h_pos[k];
+                const int w4 = ((int)g_sid[s] & 0xffff) | (((int)r.h_strand[k] & 0xff) << 16) | (((int)r.h_len_dif[k] & 0xff) << 24);
+                const int flag = (all_min || e - b <= P->first_loci_thd) ? MIN_FLAG : MULTI_FLAG;
+                hp_store16(gd + k, (int)(pos & 0xffffffffll), (int)(pos >> 32), r.h_chr[k], (s << 14) | (k - b));
+                hp_store16((HP_G char *)(gd + k) + 16, w4, (flag & 0xff) | (F_INIT << 8) | (F_MATCH << 16), 1, nm);       // dp_flag | son_flag | match_flag, score, NM
+                g_from[k] = -1; g_nn[k] = 1; g_in_de[k] = 0; g_son_n[k] = 0; g_first[k] = -1; g_last[k] = -1; g_ms[k] = 1; g_mn[k] = nm; g_mx[k] = k;      // fnode_set, :636
             }
         }
     }
+    r.nodes_ready = true;
     wv::sync();
 }
 

@@ -74,6 +74,7 @@ struct ReadCtx {
     int32_t *n_max_score, *n_max_NM, *n_max_node, *n_node_n, *n_seed;
     NodeS *nd;                  // 32-byte hot record per hit (static facts + score/NM/flags)
     const int32_t *srt, *rnk;   // hits sorted by (contig, strand, position) and the inverse permutation (local indices)
+    bool nodes_ready;           // nodes_fill has written the initial chaining state of every hit (hp_align.h); chain_first need not
     HP_L int32_t *leaf_bits; bool leaf_on;   // while track_leaves runs (leaf_on): one bit per seed slot that may hold a hit to start a track from, in LDS
                                 // (a flag of its own: the wave's LDS starts at offset 0, which is what a null LDS pointer compares equal to)
     long long *prof;            // diagnostic build only
@@ -1696,13 +1697,16 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
 #ifdef HP_PROF
     long long tq_ = wv::clock(); if (r.prof) r.prof[56] += tq_ - tc_;
 #endif
-    for (int base = 0; base < H; base += 64) {
-        WAVE_FOR(l) {
-            const int k = base + l;
-            if (k < H) node_set(r, k, -1, 1, r.h_nm[k], F_MATCH, (all_min || mapn(r, r.n_seed[k]) <= min_n) ? MIN_FLAG : MULTI_FLAG);
+    if (!r.nodes_ready) {
+        for (int base = 0; base < H; base += 64) {
+            WAVE_FOR(l) {
+                const int k = base + l;
+                if (k < H) node_set(r, k, -1, 1, r.h_nm[k], F_MATCH, (all_min || mapn(r, r.n_seed[k]) <= min_n) ? MIN_FLAG : MULTI_FLAG);
+            }
         }
+        wv::sync();
     }
-    wv::sync();
+    r.nodes_ready = false;
 #ifdef HP_PROF
     { const long long t2_ = wv::clock(); if (r.prof) r.prof[57] += t2_ - tq_; tq_ = t2_; }
 #endif
@@ -1715,9 +1719,9 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
         have_cl = clusters_build(r, C, (HP_L uint64_t *)r.cx.lds, r.cx.lds_words / 2);
         if (!have_cl && (r.cx.status & ST_OVERFLOW)) return false;
     }
-    if (min_n != P->per_aln_m && seed_out > 1) {                                                  // :1335-1343
-        if (have_cl) min_extend_clusters(r, C); else min_extend_all(r, min_n);
-    }
+    // frag_min_extend (:1335-1343): cluster by cluster, together with the main pass below; for the whole read when there are no clusters
+    const bool do_me = min_n != P->per_aln_m && seed_out > 1;
+    if (do_me && !have_cl) min_extend_all(r, min_n);
 #ifdef HP_PROF
     { const long long t2_ = wv::clock(); if (r.prof) { r.prof[58] += t2_ - tq_; r.prof[59] += all_min ? 0 : 1; } }
 #endif
@@ -1742,14 +1746,15 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
                 if (geo32 && HP_CL_CAP_RT(1 << 20) >= HP_CLL_MCAP) {                                   // clusters of two to six hits: one per lane
                     const EdgeK K = edge_consts(P);
                     wv::sync();
-                    WAVE_FOR(l) { const int n = csn[l] - csl[l]; if (l < cn && n >= 2 && n <= HP_CLL_MCAP) cluster_lane(r, K, C, r.cx.lds + l, csl[l], n); }
+                    WAVE_FOR(l) { const int n = csn[l] - csl[l]; if (l < cn && n >= 2 && n <= HP_CLL_MCAP) cluster_lane(r, K, C, r.cx.lds + l, csl[l], n, do_me); }
                     wv::sync();
                 }
                 for (int q = 0; q < cn; ++q) {
                     const int lo = wv::bcast(csl, q), n = wv::bcast(csl, q + 1) - lo;
                     if (n < 2) continue;                                                          // a lone hit has no predecessor
                     if (geo32 && HP_CL_CAP_RT(1 << 20) >= HP_CLL_MCAP && n <= HP_CLL_MCAP) continue;   // done above
-                    if (n <= HP_CL_CAP_RT(r.cx.lds_words / 5) && dp_cluster_lds(r, C, lo, n)) continue;
+                    if (n <= HP_CL_CAP_RT(r.cx.lds_words / 5) && dp_cluster_lds(r, C, lo, n, do_me)) continue;
+                    if (do_me) min_extend_clusters(r, C, lo, lo + n);                             // the cluster goes through HBM: so does its MIN extension
                     for (int i0 = 0; i0 < n; i0 += 64) { WAVE_FOR(l) { if (i0 + l < n) g_big[g_srt[lo + i0 + l]] = 1; } }
                     any_big = true;
                 }

@@ -121,7 +121,9 @@ HP_NOINL bool clusters_build(ReadCtx &r, Clusters &C, HP_L uint64_t *lw, int lds
 // the order of C.csrt (cluster by cluster, ascending hit index inside a cluster: the hits of one seed inside one cluster
 // are consecutive and ascending), 64 MIN candidates per outer step against the 64-hit chunks that overlap their
 // clusters; "first within its seed" is a segmented ballot over runs of equal (cluster, seed), carried across chunks.
-HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
+// p_lo .. p_hi: the places in C.csrt to take MIN hits from (a cluster's rank range = its range of places): the whole read, or one
+// cluster whose node state could not be packed into LDS (dp_cluster_lds does the same on the packed records otherwise).
+HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C, int p_lo, int p_hi)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
@@ -133,9 +135,9 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
     uint8_t *mk = (uint8_t *)arena_alloc(r.cx, (size_t)H + 64);
     if (!mk) return;
     HP_G uint8_t *gmk = (HP_G uint8_t *)mk;
-    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { if (b0 + l < H) gmk[b0 + l] = 0; } }
+    for (int b0 = p_lo; b0 < p_hi; b0 += 64) { WAVE_FOR(l) { if (b0 + l < p_hi) gmk[g_csrt[b0 + l]] = 0; } }
     wv::sync();
-    for (int mbase = 0; mbase < H; mbase += 64) {
+    for (int mbase = p_lo; mbase < p_hi; mbase += 64) {
         // the MIN hits of this chunk of the cluster order, one per lane; hits that are alone in their cluster have no partner
         wv::Lane<int> Ma0, Ma1, Ma2, Ma3, Mb0, ism, mcl;
         WAVE_FOR(l) {
@@ -147,7 +149,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
             const int cl = g_lo[pp];
             const bool lone = cl == pp && (pp + 1 >= H || g_lo[pp + 1] == pp + 1);
             mcl[l] = cl;
-            ism[l] = p < H && !lone && (int)(int8_t)(b[1] & 0xff) == MIN_FLAG;
+            ism[l] = p < p_hi && !lone && (int)(int8_t)(b[1] & 0xff) == MIN_FLAG;
         }
         const unsigned long long mset = wv::ballot(ism);
         if (!mset) continue;
@@ -217,7 +219,7 @@ HP_NOINL void min_extend_clusters(ReadCtx &r, const Clusters &C)
     }
     wv::sync();
     r.n_pairs += pairs_;
-    for (int b0 = 0; b0 < H; b0 += 64) { WAVE_FOR(l) { const int k = b0 + l; if (k < H && gmk[k]) gd[k].dp_flag = MIN_FLAG; } }
+    for (int b0 = p_lo; b0 < p_hi; b0 += 64) { WAVE_FOR(l) { if (b0 + l < p_hi) { const int k = g_csrt[b0 + l]; if (gmk[k]) gd[k].dp_flag = MIN_FLAG; } } }
     wv::sync();
     arena_release(r.cx.tmp, mark_);
 }
@@ -242,7 +244,9 @@ HP_INL int gap_edge(const EdgeK &K, int sp, int qpos, int qsid, int qld, int tpo
     return F_UNCONNECT;
 }
 
-HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int32_t *strip, int lo, int n)
+// do_me: frag_min_extend (:1031-1066, :1335-1343) for the cluster first -- then every hit of the cluster is kept, and for every MIN hit and
+// every repetitive seed the first hit (ascending) of that seed that is match-class colinear with it joins the MIN pass.
+HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int32_t *strip, int lo, int n, bool do_me)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
@@ -250,23 +254,46 @@ HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
 #define CW(e, w) strip[((e) * 6 + (w)) * 64]
     int m = 0, sp = 0; int64_t pos0 = 0;
-    for (int i = 0; i < n; ++i) {                                                       // the cluster's MIN hits, ascending hit order
+    unsigned is_min = 0, promoted = 0;                                                  // bit e: entry e is a MIN hit / has just become one
+    for (int i = 0; i < n; ++i) {                                                       // the cluster's hits (do_me) or its MIN hits, ascending hit order
         const int id = g_csrt[lo + i];
         const NodeS Q = node_load(ns + id);
-        if (Q.dp_flag != MIN_FLAG) continue;
+        if (Q.dp_flag != MIN_FLAG && !(do_me && Q.dp_flag == MULTI_FLAG)) continue;
         if (m == 0) { pos0 = Q.pos; sp = Q.strand; }
+        if (Q.dp_flag == MIN_FLAG) is_min |= 1u << m;
         CW(m, 0) = (int)(Q.pos - pos0); CW(m, 1) = Q.slot_j; CW(m, 2) = ((int)Q.sid & 0xffff) | (((int)Q.len_dif8 & 0xff) << 16);
         CW(m, 3) = (int)(((unsigned)Q.score << 16) | (unsigned)(Q.NM & 0xffff));
         CW(m, 4) = id; CW(m, 5) = (0xff << 24) | (1 << 16) | ((int)Q.son_flag << 8) | Q.match_flag;     // from (0xff = START) | node_n | son_flag | match_flag
         ++m;
     }
+    if (do_me && is_min != 0 && is_min != (1u << m) - 1) {
+        for (int a = 0; a < m; ++a) {
+            if (!((is_min >> a) & 1)) continue;
+            const int apos = CW(a, 0), a2 = CW(a, 2), ax = CW(a, 1) >> 14;
+            const int asid = (int)(short)(a2 & 0xffff), ald = (int)(int8_t)((a2 >> 16) & 0xff);
+            int run_seed = -1; bool run_done = false;
+            for (int q = 0; q < m; ++q) {
+                if ((is_min >> q) & 1) continue;
+                const int qx = CW(q, 1) >> 14;
+                if (qx != run_seed) { run_seed = qx; run_done = false; }                 // the hits of one seed are consecutive
+                if (run_done || qx == ax) continue;
+                const int q2 = CW(q, 2), qpos = CW(q, 0);
+                const int qsid = (int)(short)(q2 & 0xffff), qld = (int)(int8_t)((q2 >> 16) & 0xff);
+                const int flag = qx < ax ? gap_edge(K, sp, qpos, qsid, qld, apos, asid, ald) : gap_edge(K, sp, apos, asid, ald, qpos, qsid, qld);     // the hit of the earlier seed is `pre`
+                if (flag <= F_LONG_MISMATCH) { promoted |= 1u << q; run_done = true; }
+            }
+        }
+    }
+    const unsigned in_pass = is_min | promoted;                                          // the entries the MIN pass works on
     bool any = false;
     for (int a = 1; a < m; ++a) {
+        if (!((in_pass >> a) & 1)) continue;
         const int tpos = CW(a, 0), tsj = CW(a, 1), t2 = CW(a, 2), t3 = CW(a, 3);
         const int tslot = tsj >> 14, tsid = (int)(short)(t2 & 0xffff), tld = (int)(int8_t)((t2 >> 16) & 0xff);
         const int t_score = t3 >> 16, t_NM = t3 & 0xffff;
         int best_hi = -0x7fffffff, best_lo = -1, best_b = -1, best_f = 0, neg_p = -0x7fffffff, neg_b = -1, neg_f = 0, neg_hi = 0;
         for (int b = 0; b < a; ++b) {
+            if (!((in_pass >> b) & 1)) continue;
             const int qsj = CW(b, 1), qslot = qsj >> 14;
             if (qslot >= tslot) continue;
             const int q5 = CW(b, 5);
@@ -294,8 +321,9 @@ HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int
             any = true;
         }
     }
-    if (any) {
+    if (any || promoted) {
         for (int a = 0; a < m; ++a) {
+            if (!((in_pass >> a) & 1) || !(any || ((promoted >> a) & 1))) continue;
             const int id = CW(a, 4), w2 = CW(a, 2), w3 = CW(a, 3), w5 = CW(a, 5);
             const int b0 = (w2 & 0xffff) | ((sp & 0xff) << 16) | (((w2 >> 16) & 0xff) << 24);
             hp_store16((HP_G char *)(gd + id) + 16, b0, MIN_FLAG | (((w5 >> 8) & 0xff) << 8) | ((w5 & 0xff) << 16), w3 >> 16, w3 & 0xffff);
@@ -325,7 +353,10 @@ HP_INL NodeS cl_unpack(int w0, int w1, int w2, int w3, int chr, int strand)
 
 // One cluster [lo, lo + n) (ranks), n <= lds_words / 5: frag_dp_update (:701-764) for its MIN hits, out of LDS.
 // Returns false when the cluster cannot be packed (span or NM beyond the field widths): the caller marks it big.
-HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
+// do_me: frag_min_extend (:1031-1066, :1335-1343) for the cluster first, on the packed records: the cluster's repetitive (MULTI) hits are
+// listed in ascending hit order -- a few dozen at a read's true locus, where most hits are the only ones of their seeds -- and every MIN
+// hit is compared with that list only; "first hit of its seed" is a segmented ballot over the list, carried across its 64-hit chunks.
+HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n, bool do_me)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     HP_G NodeS *gd = (HP_G NodeS *)r.nd;
@@ -370,10 +401,97 @@ HP_NOINL bool dp_cluster_lds(ReadCtx &r, const Clusters &C, int lo, int n)
     if (bad || nm_sum > 65535 || n > 64 * 64) return false;       // a chain's NM is at most the sum over the cluster: 16 bits suffice
     wv::sync();
     const int sp = strand, POSMAX = (1 << 28) - 1, NEG = -0x7fffffff;
+    long long pairs_ = 0;                                      // accounting, flushed once (a counter in r is a memory round trip per use)
+    if (do_me) {
+        const size_t mark = arena_mark(r.cx.tmp);
+        int32_t *ml = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * 2 * (size_t)(n + 64));      // places of the MULTI hits, then one mark each
+        if (!ml) return false;
+        HP_G int32_t *g_ml = (HP_G int32_t *)ml, *g_mk = (HP_G int32_t *)(ml + n + 64);
+        int nml = 0, n_min = 0;
+        for (int o0 = 0; o0 < n; o0 += 64) {
+            wv::Lane<int> ism, isu, tll;
+            WAVE_FOR(l) {
+                const int o = o0 + l; const int tl = o < n ? g_rnk[g_csrt[lo + o]] - lo : 0;
+                const int dpf = (int)((unsigned)L.w1[tl] << 28) >> 28;
+                tll[l] = tl; isu[l] = o < n && dpf == MULTI_FLAG; ism[l] = o < n && dpf == MIN_FLAG;
+            }
+            const unsigned long long mu = wv::ballot(isu);
+            WAVE_FOR(l) { if (isu[l]) { const int at = nml + __builtin_popcountll(mu & ((1ull << l) - 1)); g_ml[at] = tll[l]; g_mk[at] = 0; } }
+            nml += __builtin_popcountll(mu); n_min += __builtin_popcountll(wv::ballot(ism));
+        }
+        wv::sync();
+        if (nml > 0 && n_min > 0) {
+            for (int o0 = 0; o0 < n; o0 += 64) {
+                // the MIN hits of this chunk of the ascending hit order
+                wv::Lane<int> ism, T0, T1, T2;
+                WAVE_FOR(l) {
+                    const int o = o0 + l; const int tl = o < n ? g_rnk[g_csrt[lo + o]] - lo : 0;
+                    T0[l] = L.w0[tl]; T1[l] = L.w1[tl]; T2[l] = L.w2[tl];
+                    ism[l] = o < n && ((int)((unsigned)T1[l] << 28) >> 28) == MIN_FLAG;
+                }
+                const unsigned long long mset = wv::ballot(ism);
+                if (!mset) continue;
+                unsigned long long carry = 0;                     // bit j: MIN hit j already found its hit in the run of seed carry_seed
+                int carry_seed = -1;
+                for (int b0 = 0; b0 < nml; b0 += 64) {
+                    wv::Lane<int> sd, q0, qsid, qld, hit;
+                    WAVE_FOR(l) {
+                        const int at = b0 + l;
+                        int s_ = -1, p_ = 0, i_ = 0, d_ = 0;
+                        if (at < nml) { const int tl = g_ml[at]; const int w1 = L.w1[tl], w2 = L.w2[tl]; s_ = (int)((unsigned)w1 >> 18); p_ = L.w0[tl]; i_ = (int)((unsigned)w2 >> 17); d_ = (int)(int8_t)((w2 >> 9) & 0xff); }
+                        sd[l] = s_; q0[l] = p_; qsid[l] = i_; qld[l] = d_; hit[l] = 0;
+                    }
+                    wv::Lane<int> psd = sd, rs, seg;
+                    wv::shr1(psd, -2);
+                    WAVE_FOR(l) rs[l] = psd[l] != sd[l];
+                    const unsigned long long rsm = wv::ballot(rs) | 1ull;
+                    WAVE_FOR(l) seg[l] = 63 - __builtin_clzll(rsm & ((2ull << l) - 1));
+                    const int last = nml - 1 - b0 < 63 ? nml - 1 - b0 : 63;
+                    pairs_ += (long long)__builtin_popcountll(mset) * (last + 1);
+                    const int s_last = wv::bcast(sd, last), st_last = wv::bcast(seg, last);
+                    unsigned long long next_carry = 0;
+                    for (unsigned long long mm = mset; mm; mm &= mm - 1) {
+                        const int j = __builtin_ctzll(mm);
+                        const int m0 = wv::bcast(T0, j), m1 = wv::bcast(T1, j), m2 = wv::bcast(T2, j);
+                        const int xm = (int)((unsigned)m1 >> 18), msid = (int)((unsigned)m2 >> 17), mld = (int)(int8_t)((m2 >> 9) & 0xff);
+                        wv::Lane<int> q;
+                        WAVE_FOR(l) {
+                            int v = 0;
+                            if (sd[l] >= 0 && sd[l] != xm) {
+                                const bool q_first = sd[l] < xm;                       // the hit of the earlier seed is `pre` (get_fseed_dis :607-619)
+                                const int dsid = q_first ? msid - qsid[l] : qsid[l] - msid, span = dsid * K.seed_step;
+                                const int dis = (q_first ? sp * (m0 - q0[l]) : sp * (q0[l] - m0)) - span - (sp > 0 ? (q_first ? qld[l] : mld) : (q_first ? mld : qld[l]));
+                                const int mat_dis = K.match_dis * (K.high_err ? dsid : 1);
+                                v = span >= K.seed_len && dis <= mat_dis && dis >= -mat_dis;
+                            }
+                            q[l] = v;
+                        }
+                        const unsigned long long qb = wv::ballot(q);
+                        const bool cj = (carry >> j) & 1, run_on = carry_seed == s_last;
+                        if (!qb) { if (run_on && cj) next_carry |= 1ull << j; continue; }
+                        WAVE_FOR(l) {
+                            if (q[l]) {
+                                const unsigned long long earlier = qb & ((1ull << l) - 1) & ~((1ull << seg[l]) - 1);
+                                if (earlier == 0 && !(sd[l] == carry_seed && cj)) hit[l] = 1;
+                            }
+                        }
+                        if ((qb >> st_last) != 0 || (run_on && cj)) next_carry |= 1ull << j;
+                    }
+                    WAVE_FOR(l) { if (hit[l]) g_mk[b0 + l] = 1; }
+                    carry = next_carry; carry_seed = s_last;
+                }
+            }
+            wv::sync();
+            for (int b0 = 0; b0 < nml; b0 += 64) {
+                WAVE_FOR(l) { const int at = b0 + l; if (at < nml && g_mk[at]) { const int tl = g_ml[at]; L.w1[tl] = (L.w1[tl] & ~15) | MIN_FLAG; } }
+            }
+            wv::sync();
+        }
+        arena_release(r.cx.tmp, mark);
+    }
     // ---- targets in ascending hit order (C.csrt), 64 at a time: their places in the cluster and their records.  A target's
     // record is still what was loaded when its turn comes: only later targets (higher hit index) can choose it as their
     // predecessor and touch its son_flag.
-    long long pairs_ = 0;                                      // accounting, flushed once (a counter in r is a memory round trip per use)
     for (int o0 = 0; o0 < n; o0 += 64) {
         wv::Lane<int> tloc, T0, T1, T2, T3;
         WAVE_FOR(l) {
