@@ -138,6 +138,26 @@ __global__ __launch_bounds__(64, 1) void k_filldp_big(const PhaseArgs *ap, int r
     __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
     filldp_loop<HP_LJ_QCAP, 0, LJ_NBIG, 7>(*ap, round, (HP_L int32_t *)lds);
 }
+// the junction jobs of the "big" queues, four per wave (hp_stripdp.h): registers only, no LDS
+#ifndef HP_STRIP_WAVES_PER_SIMD
+#define HP_STRIP_WAVES_PER_SIMD 6
+#endif
+__global__ __launch_bounds__(64, HP_STRIP_WAVES_PER_SIMD) void k_filldp_strip(const PhaseArgs *ap, int round)
+{
+    const PhaseArgs &a = *ap;
+    int n = 0;
+    for (int b = 0; b < LJ_NCLS_BIG; ++b) n += (a.ctl->lj_bucket_n[round][b] + 3) >> 2;
+    n = wv::uni(n);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[7], 1);
+        g = wv::uni(g);
+        if (g >= n) break;
+        int b = 0;
+        for (; b < LJ_NCLS_BIG - 1; ++b) { const int gb = (a.ctl->lj_bucket_n[round][b] + 3) >> 2; if (g < gb) break; g -= gb; }
+        phase_filldp_strip(a, round, b, g * 4, blockIdx.x);
+    }
+}
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;
@@ -526,15 +546,17 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     int pdb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pdb, k_filldp_big, 64, 0) != hipSuccess || pdb < 1) pdb = 2;
+    int pds = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pds, k_filldp_strip, 64, 0) != hipSuccess || pds < 1) pds = 4;
     // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU cap the persistent grids below what fits a CU, so that the launches of two
     // batches in flight can share the CUs instead of the later one waiting for the earlier one's waves to exit
     { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0;
       if (cf > 0 && cf < pf) pf = cf;
       if (cc > 0 && cc < pc) pc = cc; }
-    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb;
+    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb, w_dps = h->n_cu * pds;
     int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
     n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
-    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves);
+    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves); w_dps = std::min(w_dps, n_waves);
     const PhasedLayout Y = phased_layout(n, n_hits, T.n_bases, O.stream_cap);
     const int unit_cap = Y.unit_cap, lj_cap = Y.lj_cap; const int64_t fl_cap = Y.fl_cap, line_cap = Y.line_cap, job_cap = Y.job_cap;
     const size_t off = Y.bytes, o_args = Y.o[0], o_ctl = Y.o[1], o_meta = Y.o[2], o_nd = Y.o[3], o_ns = Y.o[4], o_sx = Y.o[5], o_un = Y.o[6], o_bq = Y.o[7], o_fl = Y.o[8], o_ln = Y.o[9],
@@ -567,7 +589,12 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
-    if (!g_nolane) { hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 0); if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 0); hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 0); }
+    if (!g_nolane) {
+        hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 0);
+        if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 0);
+        else if (HP_STRIP_RT) hipLaunchKernelGGL(k_filldp_strip, dim3(w_dps), dim3(64), 0, s, da, 0);
+        hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 0);
+    }
     HIPCHK(h, hipEventRecord(Ln.ep[4], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
     HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
@@ -575,7 +602,10 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
     if (!g_nolane) {
         HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 12, s), LAMSA_HP_EKERNEL);          // the three queue heads of the lane DP launches
-        hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 1); if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 1); hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);
+        hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 1);
+        if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 1);
+        else if (HP_STRIP_RT) hipLaunchKernelGGL(k_filldp_strip, dim3(w_dps), dim3(64), 0, s, da, 1);
+        hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);
     }
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 1);
     HIPCHK(h, hipEventRecord(Ln.ep[3], s), LAMSA_HP_EKERNEL);

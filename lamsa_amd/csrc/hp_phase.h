@@ -19,6 +19,7 @@
 #pragma once
 #include "hp_align.h"
 #include "hp_lanedp.h"
+#include "hp_stripdp.h"
 
 namespace hp {
 
@@ -259,13 +260,20 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
 #define HP_LJ_QLIST HP_LJ_QSMALL
 #define HP_LJ_TLIST HP_LJ_TSMALL
 #endif
+// Junction jobs (type 1) beyond that, up to HP_ST_QMAX query bases, can be listed for the four-jobs-per-wave routine of hp_stripdp.h (into
+// the "big" queues).  OFF in the product: measured on the MI355X (profiles/r03_strip_dp.txt) the routine takes 28 ms per step for the
+// 1.0 M jobs of the ont10k batch and saves the fill kernel 19 ms -- a cell costs ~25 lane operations however the lanes are dealt out, and
+// the 27 % of the jobs whose left extension does not end the call are computed twice.  The tests' CPU build runs it both ways.
+#ifndef HP_STRIP_RT
+#define HP_STRIP_RT 0
+#endif
 struct LjRec { int64_t qaddr, tk, slot; int32_t rd; uint16_t tlen; uint8_t qlen; int8_t type_comp; };      // type_comp: type (1: ksw_bi_extend(100, 100), 2: ksw_global2) | complement << 4
 // queues: [big jobs (query > HP_LJ_QSMALL): kind 1 longest first, kind 2 longest first][short jobs: the same]; LJ_NBIG queues are "big"
 enum { LJ_NCLS_BIG = (HP_LJ_QCAP - HP_LJ_QSMALL) / 16, LJ_NCLS_SMALL = HP_LJ_QSMALL / 16, LJ_NBIG = 2 * LJ_NCLS_BIG, LJ_NBUCKET = 2 * (LJ_NCLS_BIG + LJ_NCLS_SMALL) };
 HP_INL int lj_bucket_of(int type, int qlen, int tlen)
 {
     const int cls = (qlen > 0 ? qlen - 1 : 0) >> 4;                            // 0 .. HP_LJ_QCAP / 16 - 1
-    if (qlen > HP_LJ_QSMALL || tlen > HP_LJ_TSMALL) { const int c = cls < LJ_NCLS_SMALL ? LJ_NCLS_SMALL : cls; return (type == 1 ? 0 : LJ_NCLS_BIG) + (LJ_NCLS_BIG - 1 - (c - LJ_NCLS_SMALL)); }
+    if (qlen > HP_LJ_QSMALL || tlen > HP_LJ_TSMALL) { int c = cls < LJ_NCLS_SMALL ? LJ_NCLS_SMALL : cls; if (c > LJ_NCLS_SMALL + LJ_NCLS_BIG - 1) c = LJ_NCLS_SMALL + LJ_NCLS_BIG - 1; return (type == 1 ? 0 : LJ_NCLS_BIG) + (LJ_NCLS_BIG - 1 - (c - LJ_NCLS_SMALL)); }
     return LJ_NBIG + (type == 1 ? 0 : LJ_NCLS_SMALL) + (LJ_NCLS_SMALL - 1 - cls);
 }
 
@@ -280,6 +288,7 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
     pers_bind(r, a, rd);
     const lamsa_hp_para *P = r.cx.P;
     if (!lj_params_ok(P)) return;
+    const bool strip_ok = st_params_ok(P, 100) && (size_t)HP_ST_SLAB_BYTES <= a.slab_per_wave;
     FLines F;
     F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
     flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
@@ -318,13 +327,14 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                 const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
                 const int dis = (int)(at2_off - exp);
                 const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
-                if (s_qlen > 0 && s_qlen <= HP_LJ_QLIST && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
+                const int q_list = (HP_STRIP_RT && strip_ok && HP_ST_QMAX > HP_LJ_QLIST) ? HP_ST_QMAX : HP_LJ_QLIST;
+                if (s_qlen > 0 && s_qlen <= q_list && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
                     const int64_t start0 = at1_off + P->seed_len + at1_ld - 1;
                     const int32_t clen = r.ref.seq_len[at1_chr - 1];
                     if (start0 <= clen && start0 >= 0) {                        // pac2fa_core, bntseq.c:469-474
                         int tl_ = s_qlen + dis;
                         if (start0 + tl_ > clen) tl_ = (int)(clen - start0);
-                        if (tl_ <= HP_LJ_TLIST) {
+                        if ((s_qlen <= HP_LJ_QLIST && tl_ <= HP_LJ_TLIST) || (HP_STRIP_RT && strip_ok && s_qlen <= HP_ST_QMAX && tl_ <= HP_ST_TMAX)) {
                             type = 1; qlen = s_qlen; tlen = tl_; slot = (F.jt + 4 * jf) - a.fl_base; k0 = r.ref.seq_off[at1_chr - 1] + start0;
                             qoff = (strand == 1 ? 0 : r.last_len) + id1 * P->seed_step - P->seed_inv;      // get_read_intv, :116
                         }
@@ -434,6 +444,82 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
             int32_t *slot = a.fl_base + (slotl[l] & 0xffffffffffffll);
             slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = (int32_t)(slotl[l] >> 48); slot[3] = 1;
             if (cel[l] > 0) atomicAdd(&a.meta[rdl[l]].cells, cel[l]);
+        }
+    }
+    wv::sync();
+}
+
+// four jobs of one of the round's "big" junction queues (type 1: ksw_bi_extend(100, 100)) through hp_stripdp.h: the left extension, and
+// when it ends the call (ksw.c:875-880) the CIGAR into the job arena and its slot into FLines::jt, where the fill finds it.  A job whose
+// left extension stops inside both sequences is left alone: the fill runs its ksw_bi_extend as before.
+HP_INL void phase_filldp_strip(const PhaseArgs &a, int round, int bucket, int off, int wave_slot)
+{
+    const lamsa_hp_para *P = &a.P;
+    const int left = a.ctl->lj_bucket_n[round][bucket] - off;
+    const int cnt = left < 4 ? left : 4;
+    char *slab = a.slab + (size_t)wave_slot * a.slab_per_wave;
+    if ((size_t)HP_ST_SLAB_BYTES > a.slab_per_wave || cnt <= 0) return;
+    uint32_t *zbuf = (uint32_t *)slab;
+    cig_t *cbuf = (cig_t *)(slab + (size_t)4 * HP_ST_ZROWS * 16 * 4);
+    const int32_t *bq = a.lj_bucket + (size_t)bucket * a.lj_cap + off;
+    StripJob J; wv::Lane<int> rdl; wv::Lane<long long> slotl;
+    wv::sync();
+    WAVE_FOR(l) {
+        const int g = l >> 4;
+        J.on[l] = g < cnt; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0; rdl[l] = -1; slotl[l] = 0;
+        if (g < cnt) {
+            const LjRec R = a.ljobs[bq[g]];
+            const int comp = (R.type_comp >> 4) & 1;
+            J.q[l] = (long long)(a.in.read_seq + R.qaddr); J.qs[l] = comp ? -1 : 1; J.qcomp[l] = comp; J.qlen[l] = R.qlen; J.tlen[l] = R.tlen; J.tk[l] = R.tk;
+            rdl[l] = R.rd; slotl[l] = R.slot;
+            if (R.qlen > HP_ST_QMAX || R.tlen > HP_ST_TMAX || (R.type_comp & 15) != 1) J.on[l] = 0;      // never listed; a guard for the buffers
+        }
+    }
+    StripRes O;
+    strip_extend(P, (const HP_G uint8_t *)a.ref.pac, J, 100, zbuf, cbuf, O);
+    // ksw_bi_extend after the left extension, :874-880
+    wv::Lane<int> nw;
+    WAVE_FOR(l) {
+        int n = 0;
+        if (J.on[l]) {
+            const int ql = J.qlen[l], tl = J.tlen[l], res = O.qle[l] == ql ? 0 : (O.tle[l] == tl ? 1 : 2);
+            if (res < 2) {
+                HP_G cig_t *c = (HP_G cig_t *)cbuf + (size_t)(l >> 4) * HP_ST_CIG;
+                n = O.n_cig[l];
+                const cig_t tail = res == 0 ? (cig_t)(((tl - O.tle[l]) << 4) | C_D) : (cig_t)(((ql - O.qle[l]) << 4) | C_I);
+                if ((tail >> 4) != 0) {                                                  // _push_cigar1
+                    if (n > 0 && (c[n - 1] & 0xf) == (tail & 0xf)) { if ((l & 15) == 0) c[n - 1] += (tail >> 4) << 4; }
+                    else { c[n] = tail; ++n; }
+                }
+                HP_STAT(9);
+            } else HP_STAT(10);
+        }
+        nw[l] = n;
+    }
+    wv::sync();
+    // publish: one reservation in the job arena per wave
+    wv::Lane<int> nw0, pre;
+    WAVE_FOR(l) nw0[l] = (l & 15) == 0 ? nw[l] : 0;
+    pre = nw0;
+    wv::scan_add_excl(pre);
+    const int total = wv::reduce_sum(nw0);
+    WAVE_FOR(l) { if ((l & 15) != 0) pre[l] = -1; }
+    wv::row16_allmax(pre);
+    unsigned long long base = 0;
+    if (total > 0) {
+        if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)total);
+        base = (unsigned long long)wv::uni64((long long)base);
+    }
+    const bool room = (int64_t)(base + (unsigned long long)total) <= a.job_cap;       // arena full: these stay with the fill
+    WAVE_FOR(l) {
+        if (J.on[l]) {
+            if (nw[l] > 0 && room) {
+                const HP_G cig_t *src = (const HP_G cig_t *)cbuf + (size_t)(l >> 4) * HP_ST_CIG;
+                HP_G int32_t *dst = (HP_G int32_t *)(a.job_base + base + pre[l]);
+                for (int k = l & 15; k < nw[l]; k += 16) dst[k] = src[k];
+                if ((l & 15) == 0) { int32_t *slot = a.fl_base + slotl[l]; slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = J.tlen[l]; slot[3] = 1; }
+            }
+            if ((l & 15) == 0 && O.cells[l] > 0) atomicAdd(&a.meta[rdl[l]].cells, O.cells[l]);
         }
     }
     wv::sync();

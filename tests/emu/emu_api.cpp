@@ -10,6 +10,8 @@ int g_emu_gaptab_cap = 1 << 30;        // tests: reads with more seed slots than
 #define HP_GAPTAB_CAP_RT(cap) (g_emu_gaptab_cap < (cap) ? g_emu_gaptab_cap : (cap))
 int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than this take the wave-wide routine (hp_gaps.h)
 #define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
+int g_emu_strip = 0;                   // tests: 1 = junction jobs of 65 .. 127 query bases go to the four-jobs-per-wave routine (hp_stripdp.h; off in the product)
+#define HP_STRIP_RT g_emu_strip
 long long g_emu_stat[16];              // path counters (HP_STAT slots of the device sources)
 #define HP_STAT(i) (++g_emu_stat[i])
 #include "hp_dp_batch.h"
@@ -88,6 +90,7 @@ extern "C" void emu_set_lane_dp(int on) { g_emu_lane_dp = on; }           // 0: 
 extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab_cap > 0 ? tab_cap : (tab_cap < 0 ? 0 : 1 << 30); g_emu_gap_mcap = mcap > 0 ? mcap : (mcap < 0 ? 0 : 1 << 30); }
+extern "C" void emu_set_strip(int on) { g_emu_strip = on; }
 extern "C" long long emu_stat(int i) { return g_emu_stat[i & 15]; }
 extern "C" void emu_stat_reset() { memset(g_emu_stat, 0, sizeof g_emu_stat); }
 extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
@@ -140,8 +143,10 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
             if (g_emu_lane_dp) {
                 for (int b = 0; b < PH_NBUCKET; ++b)
                     for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filllist(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
-                for (int b = 0; b < LJ_NBUCKET; ++b)
+                for (int b = 0; b < LJ_NBUCKET; ++b) {
+                    if (b < LJ_NCLS_BIG && HP_LJ_QLIST <= HP_LJ_QSMALL) { for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 4) phase_filldp_strip(p, round, b, off, 0); continue; }
                     for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 64) phase_filldp(p, round, b, off, 0, lds_lj, b < LJ_NBIG ? HP_LJ_QCAP : HP_LJ_QSMALL);
+                }
             }
             for (int b = 0; b < PH_NBUCKET; ++b)
                 for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
@@ -158,6 +163,35 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     a.slab = slab.data(); a.slab_per_wave = slab_bytes; a.counter = nullptr; a.order = nullptr; a.n_units = B->n_reads; a.scale = scale; a.prof = nullptr;
     for (int r = 0; r < B->n_reads; ++r) align_read(a, r, 0, lds);
     *n_words = (int64_t)cursor;
+    return 0;
+}
+
+// ---------------------------------------------------------------- the four-jobs-per-wave extension (hp_stripdp.h) on explicit jobs:
+// ksw_extend_core(w = max(|qlen - tlen| + 3, band_w), h0) with traceback; targets packed 2 bits per base as the kernel reads them
+extern "C" int emu_strip_extend(const lamsa_hp_para *P, int n, const uint8_t *seq, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,
+                                int h0, int32_t *score, int32_t *qle, int32_t *tle, int32_t *cig_n, int32_t *cig /* n * HP_ST_CIG words */)
+{
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += tlen[i];
+    std::vector<uint8_t> pac((size_t)tot / 4 + 8, 0); std::vector<int64_t> tk((size_t)n + 1, 0);
+    { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } }
+    std::vector<char> slab(HP_ST_SLAB_BYTES + 64);
+    if (!st_params_ok(P, h0)) return -2;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        StripJob J;
+        for (int l = 0; l < 64; ++l) {
+            const int i = j0 + (l >> 4);
+            J.on[l] = i < n; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0;
+            if (i < n) { if (qlen[i] > HP_ST_QMAX || tlen[i] > HP_ST_TMAX) return -1; J.q[l] = (long long)(seq + q_off[i]); J.qlen[l] = qlen[i]; J.tlen[l] = tlen[i]; J.tk[l] = tk[i]; }
+        }
+        StripRes O;
+        strip_extend(P, pac.data(), J, h0, (uint32_t *)slab.data(), (cig_t *)(slab.data() + (size_t)4 * HP_ST_ZROWS * 16 * 4), O);
+        for (int g = 0; g < 4 && j0 + g < n; ++g) {
+            const int i = j0 + g, l = 16 * g;
+            score[i] = O.score[l]; qle[i] = O.qle[l]; tle[i] = O.tle[l]; cig_n[i] = O.n_cig[l];
+            memcpy(cig + (size_t)i * HP_ST_CIG, (cig_t *)(slab.data() + (size_t)4 * HP_ST_ZROWS * 16 * 4) + (size_t)g * HP_ST_CIG, sizeof(cig_t) * (size_t)O.n_cig[l]);
+        }
+    }
     return 0;
 }
 

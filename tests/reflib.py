@@ -370,7 +370,22 @@ def emu_lane_dp(jobs, hp_para, kind, w, h0):
     return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None):
+def emu_strip_extend(jobs, hp_para, h0):
+    """ksw_extend_core(max(|qlen - tlen| + 3, band_w), h0) through the four-jobs-per-wave routine of hp_stripdp.h, CPU lane emulation."""
+    from lamsa_amd.hp import pack_jobs
+    E = emu()
+    n = len(jobs)
+    seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
+    CIG = 127 + 255 + 8
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(n * CIG + 4, np.int32)
+    p = lambda a: a.ctypes.data
+    E.emu_strip_extend.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
+    rc = E.emu_strip_extend(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), int(h0), p(score), p(qle), p(tle), p(cn), p(cig))
+    assert rc == 0, rc
+    return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
+
+
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None, strip=False):
     """Per-read result streams from the device sources compiled with the CPU lane emulation.
     phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
     cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h).
@@ -379,7 +394,7 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
     E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap)); E.emu_set_lane_dp(1 if lane_dp else 0)
-    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
+    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_set_strip(1 if strip else 0); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
     n = batch.n_reads
     hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
@@ -390,7 +405,7 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     E.emu_align_batch(C.byref(hp_para), C.byref(hr), C.byref(hb), scale, slab_bytes, stream.ctypes.data, cap, C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
     if stats is not None:
         stats[:] = [int(E.emu_stat(i)) for i in range(16)]
-    E.emu_set_gap_caps(0, 0)
+    E.emu_set_gap_caps(0, 0); E.emu_set_strip(0)
     return split_streams(stream, off[:n], ln[:n]), st[:n].copy()
 
 

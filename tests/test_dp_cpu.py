@@ -168,3 +168,26 @@ def test_lane_per_job_dp_matches_oracle(preset):
         got = reflib.emu_lane_dp(jobs, P, kind, w, max(h0, 1))
         bad = goldenlib.same_dp(want, got, kind)
         assert bad == [], (kind, w, h0, bad[:5])
+
+
+@pytest.mark.parametrize("preset", ["default", "pacbio", "ont2d"])
+def test_four_jobs_per_wave_extension_matches_oracle(preset):
+    """hp_stripdp.h (a junction's left extension on a quarter of a wave, eight columns per lane in registers) against the oracle's
+    ksw_extend_core with the band ksw_bi_extend gives it, on ragged jobs up to the routine's capacity (127 x 255)."""
+    from lamsa_amd.hp import HpPara
+    lp = reflib.lo_para(preset)
+    P = HpPara()
+    for n, _ in HpPara._fields_:
+        setattr(P, n, getattr(lp, n))
+    jobs = [(q, t) for q, t in dpjobs.make_jobs(777, 700, 130, (0.05, 0.05, 0.05)) if len(q) <= 127 and len(t) <= 255 and (len(t) == 0 or t.max() < 4)]
+    assert len(jobs) > 400
+    for h0 in (100, 10):
+        got = reflib.emu_strip_extend(jobs, P, h0)
+        # the oracle one job at a time: every job has its own band, max(|qlen - tlen| + 3, band_w) (src/ksw.c:873)
+        by_w = {}
+        for i, (q, t) in enumerate(jobs):
+            by_w.setdefault(max(abs(len(q) - len(t)) + 3, lp.band_w), []).append(i)
+        for w, idx in by_w.items():
+            want = reflib.oracle_dp([jobs[i] for i in idx], lp, 1, w, h0)
+            for k, i in enumerate(idx):
+                assert (want["score"][k], want["qle"][k], want["tle"][k], list(want["cigars"][k])) == (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i])), (preset, h0, i)
