@@ -761,7 +761,8 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
 // edges therefore lie in the run around `node` in which consecutive hits are at most Rcap apart: two hits within Rcap
 // of each other have only gaps <= Rcap between them.  Hits outside that run never connect to a hit inside it, so the DP
 // state of the run (predecessors, scores, the son_flag side effects) is the same whether or not they are processed.
-HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi)
+struct RunR { int lo, hi; };     // results come back by value, in registers: no caller's local is handed by address to a non-inlined routine (hazards)
+HP_NOINL RunR reach_run(ReadCtx &r, int node, long long Rcap)
 {
     const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
     const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt;
@@ -789,7 +790,8 @@ HP_NOINL void reach_run(ReadCtx &r, int node, long long Rcap, int *rlo, int *rhi
         }
         if (dir < 0) lo = edge; else hi = edge;
     }
-    *rlo = lo; *rhi = hi;
+    RunR rr; rr.lo = lo; rr.hi = hi;
+    return rr;
 }
 
 // The driver loop of branch tracking (:1356-1361, :961-966): seeds from last to first, hits of a seed in ascending
@@ -908,9 +910,10 @@ template <int NS> HP_INL int ms_pick(const wv::Lane<int> *f, int c) {
     return v;
 }
 // ids: list ? list[idx] : k_lo + idx, idx < n_ids <= 64 * NS
+struct MiniR { int n, d_score, d_NM; };     // nodes written to line[] (-1: the hits do not fit this routine), score and NM gained over the plain edge
 template <int NS>
-HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail,
-                            int n_ids, const int32_t *list)
+HP_NOINL MiniR mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_t *line, int _head, int _tail,
+                              int n_ids, const int32_t *list)
 {
     left = wv::uni(left); right = wv::uni(right); right_x = wv::uni(right_x); _head = wv::uni(_head); _tail = wv::uni(_tail);
     const int head = _head ? left : -1;
@@ -1115,24 +1118,25 @@ HP_NOINL int mini_line_sets(ReadCtx &r, int left, int right, int right_x, int32_
 #undef HP_MS_Q
 #undef HP_MS_SCAN
     r.n_pairs += pairs_;
-    if (bad) { r.cx.status |= ST_REFEXIT; return 0; }
-    *de_score += max_score - old_score;
-    *de_NM += max_NM - old_NM;
-    return max_n;
+    MiniR R_; R_.n = 0; R_.d_score = 0; R_.d_NM = 0;
+    if (bad) { r.cx.status |= ST_REFEXIT; return R_; }
+    R_.n = max_n; R_.d_score = max_score - old_score; R_.d_NM = max_NM - old_NM;
+    return R_;
 }
 
-HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+HP_INL MiniR mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t *line, int _head, int _tail)
 {
+    MiniR none; none.n = -1; none.d_score = 0; none.d_NM = 0;
     const int head = _head ? left : -1;
     const int left_x = nx(r, left);
     const int k_lo = hoff(r, left_x + 1), k_hi = hoff(r, right_x);
-    if (k_hi - k_lo <= 64) return mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, k_hi - k_lo, nullptr);
+    if (k_hi - k_lo <= 64) return mini_line_sets<1>(r, left, right, right_x, line, _head, _tail, k_hi - k_lo, nullptr);
     // A longer seed range.  The hits that take part are those that can be connected to the pass's anchor: the head when
     // there is one (frag_dp_per_init keeps only hits that connect to it, :766-784), else the right anchor (pass from
     // START, see reach_run).  They lie in the anchor's run of the sorted order; the hits of that run that belong to the
     // seed range and to this kind of pass are listed, and if at most 256 remain the pass runs on registers.
     const int anchor = head >= 0 ? head : ((_tail != 0 && right >= 0) ? right : -1);
-    if (anchor < 0) return k_hi - k_lo <= 64 * HP_MS_MAX_SETS ? mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, k_hi - k_lo, nullptr) : -1;
+    if (anchor < 0) return k_hi - k_lo <= 64 * HP_MS_MAX_SETS ? mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, _head, _tail, k_hi - k_lo, nullptr) : none;
     const lamsa_hp_para *P = r.cx.P;
     const int sid_hi = right_x < r.seed_out ? r.seed_id[right_x] : r.seed_id[r.seed_out - 1];
     const int did_max = sid_hi - (head >= 0 ? r.seed_id[left_x] : r.seed_id[left_x + 1]);
@@ -1140,13 +1144,13 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
     long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
     if (mdm + 1 > Rw) Rw = mdm + 1;
     Rw += 128 + (long long)did_max * P->seed_step;
-    int rlo, rhi;
-    reach_run(r, anchor, Rw, &rlo, &rhi);
+    const RunR rr_ = reach_run(r, anchor, Rw);
+    const int rlo = rr_.lo, rhi = rr_.hi;
     const int R = rhi - rlo + 1;
-    if (R > 2048) return -1;
+    if (R > 2048) return none;
     const size_t mark = arena_mark(r.cx.tmp);
     int32_t *list = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(R + 64));
-    if (!list) { arena_release(r.cx.tmp, mark); return -1; }
+    if (!list) { arena_release(r.cx.tmp, mark); return none; }
     int n = 0;
     {
         const HP_G NodeS *ns = (const HP_G NodeS *)r.nd;
@@ -1172,9 +1176,9 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
         }
         wv::sync();
     }
-    int ret = -1;
-    if (n <= 64) ret = mini_line_sets<1>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);
-    else if (n <= 64 * HP_MS_MAX_SETS) ret = mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, de_score, de_NM, _head, _tail, n, list);
+    MiniR ret = none;
+    if (n <= 64) ret = mini_line_sets<1>(r, left, right, right_x, line, _head, _tail, n, list);
+    else if (n <= 64 * HP_MS_MAX_SETS) ret = mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, line, _head, _tail, n, list);
     arena_release(r.cx.tmp, mark);
     return ret;
 }
@@ -1182,8 +1186,9 @@ HP_INL int mini_line_regs(ReadCtx &r, int left, int right, int right_x, int32_t 
 // ---------------------------------------------------------------- frag_mini_dp_line, :1068-1150
 // left / right are node indices (left may be -1 = START); right_x is right's slot, which may be the
 // virtual slot seed_out (then right < 0 and _tail == 0).  Returns the number of nodes written to line[].
-HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+HP_NOINL MiniR mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t *line, int _head, int _tail)
 {
+    MiniR R_; R_.n = 0; R_.d_score = 0; R_.d_NM = 0;
     const int head = _head ? left : -1;
     const int left_x = nx(r, left), head_x = nx(r, head);
     const int left_NM = left < 0 ? 0 : r.h_nm[left];
@@ -1201,7 +1206,7 @@ HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t
         long long Rw = P->SV_len_thd > did_max * P->seed_step ? P->SV_len_thd : did_max * P->seed_step;
         if (mdm + 1 > Rw) Rw = mdm + 1;
         Rw += 128 + (long long)did_max * P->seed_step;
-        reach_run(r, right, Rw, &rlo, &rhi);
+        const RunR rr_ = reach_run(r, right, Rw); rlo = rr_.lo; rhi = rr_.hi;
     }
     nodes_per_init(r, hoff(r, left_x + 1), hoff(r, right_x), head, dp_flag, 0, rlo, rhi);
     dp_update_range(r, hoff(r, left_x + 2), hoff(r, right_x), left_x + 1, dp_flag, false, false);      // callers guarantee left_x + 2 <= right_x
@@ -1245,29 +1250,29 @@ HP_NOINL int mini_line_mem(ReadCtx &r, int left, int right, int right_x, int32_t
     }
     int cur = max_node, node_i = max_n - 1;
     while (nx(r, cur) != head_x) {
-        if (node_i < 0) { r.cx.status |= ST_REFEXIT; return 0; }     // "[frag mini dp] BUG" exit, :1140
+        if (node_i < 0) { r.cx.status |= ST_REFEXIT; return R_; }     // "[frag mini dp] BUG" exit, :1140
         line[node_i--] = cur;
         cur = r.n_from[cur];
     }
-    if (node_i >= 0) { r.cx.status |= ST_REFEXIT; return 0; }
-    *de_score += max_score - old_score;
-    *de_NM += max_NM - old_NM;
+    if (node_i >= 0) { r.cx.status |= ST_REFEXIT; return R_; }
+    R_.d_score = max_score - old_score; R_.d_NM = max_NM - old_NM;
 #ifdef HP_PROF
     if (r.prof) r.prof[13] += 1;
 #endif
-    return max_n;
+    R_.n = max_n;
+    return R_;
 }
 
-HP_INL int mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+HP_INL MiniR mini_line(ReadCtx &r, int left, int right, int right_x, int32_t *line, int _head, int _tail)
 {
 #ifdef HP_PROF
     const long long t0_ = wv::clock();
 #endif
-    const int n = mini_line_regs(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+    const MiniR m = mini_line_regs(r, left, right, right_x, line, _head, _tail);
 #ifdef HP_PROF
     if (r.prof) { r.prof[44] += wv::clock() - t0_; r.prof[45] += 1; }
 #endif
-    return n >= 0 ? n : mini_line_mem(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+    return m.n >= 0 ? m : mini_line_mem(r, left, right, right_x, line, _head, _tail);
 }
 
 // ---------------------------------------------------------------- lines
@@ -1371,21 +1376,22 @@ HP_FN int line_merge(ReadCtx &r, LSet &L, int a, int b, float ovlp_r)
 }
 
 // best + secondaries of one cluster mb[0..mbn) (line indices); winners to mf[0..*mfn) when mf != nullptr
-HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, int per_max_multi, int32_t *tri_n, int32_t *mf, int *mfn, int32_t *spare = nullptr, int spare_n = 0)
-{   // shared tail of line_filter (:166-235) and line_filter1 (:346-400)
+// returns the number of winners written to mf[] (mf may be null: nothing is written)
+HP_NOINL int pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, int per_max_multi, int32_t *tri_n, int32_t *mf, int32_t *spare = nullptr, int spare_n = 0)
+{
+    int mfn_ = 1; int *mfn = &mfn_;   // (a pointer to this routine's own local, never handed on) -- shared tail of line_filter (:166-235) and line_filter1 (:346-400)
     int b_score = 0, s_score = 0;
     for (int j = 0; j < mbn; ++j) {
         const int y = L.ls[mb[j]];
         if (y > b_score) { s_score = b_score; b_score = y; } else if (y > s_score) s_score = y;
     }
-    if (mfn) *mfn = 1;
     if (s_score >= b_score / 2) {
         const size_t mark = arena_mark(r.cx.tmp);
         NScore ns;
         if (spare && 3 * (per_max_multi + 2) <= spare_n) {             // the heap in the spare words of the staged line set (LDS)
             ns.node = spare; ns.score = spare + (per_max_multi + 2); ns.NM = spare + 2 * (per_max_multi + 2);
             ns.cap = per_max_multi + 1; ns.max_n = per_max_multi; ns.node_n = 0; ns.min_score_thd = 0;
-        } else if (!ns_alloc(r.cx, ns, per_max_multi + 1, per_max_multi)) { arena_release(r.cx.tmp, mark); return; }
+        } else if (!ns_alloc(r.cx, ns, per_max_multi + 1, per_max_multi)) { arena_release(r.cx.tmp, mark); return mfn_; }
         for (int j = 0; j < mbn; ++j) {
             const int li = mb[j];
             if (L.ls[li] >= b_score / 2) {
@@ -1415,6 +1421,7 @@ HP_NOINL void pick_in_cluster(ReadCtx &r, LSet &L, const int32_t *mb, int mbn, i
             else { L.mf[li] |= L_DUMP; if (tri_n) tri_n[li] = 0; }
         }
     }
+    return mfn_;
 }
 
 struct Trig { int32_t *n1, *n2, *off, *cnt; int cap, used; };   // inter-triggers per line (trig_node, lamsa_aln.h:326)
@@ -1465,10 +1472,9 @@ HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int p
     for (int c = 0; c <= m_i; ++c) {
         int32_t *mf = mfv + cl_off[c] + c;             // room for (cluster size + 1) entries
         const int mbn = cl_off[c + 1] - cl_off[c];
-        if (!trg) { pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, nullptr, nullptr, nullptr, spare, spare_n); continue; }
+        if (!trg) { pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, nullptr, nullptr, spare, spare_n); continue; }
         if (cl_nm[c]) { mf[0] = mb[cl_off[c]]; mfn[c] = 1; continue; }
-        int n = 1;
-        pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, trg->cnt, mf, &n, spare, spare_n);
+        const int n = pick_in_cluster(r, L, mb + cl_off[c], mbn, per_max_multi, trg->cnt, mf, spare, spare_n);
         mfn[c] = n;
         for (int ii = 1; ii < n; ++ii) {               // inter-lines (candidate inversions), :236-273
             const int j = mf[ii], _j = L.sel[j];

@@ -203,9 +203,9 @@ HP_INL void gap_lane(const ReadCtx &r, const EdgeK &K, HP_L int32_t *strip, int 
 // kernel's HBM traffic: the scratch of 4 096 waves does not stay in L2); here it is the handful of values this loop needs.
 // gp: the per-gap arrays of line_build (GA entries each, in the order left, right, lx, rx, tail, after, o_n, o_off, ..., o_lane at 15).
 struct GapRest { int pool_n, d_score, d_NM; };
-HP_NOINL int mini_line_far(ReadCtx &r, int left, int right, int right_x, int32_t *line, int *de_score, int *de_NM, int _head, int _tail)
+HP_NOINL MiniR mini_line_far(ReadCtx &r, int left, int right, int right_x, int32_t *line, int _head, int _tail)
 {
-    return mini_line(r, left, right, right_x, line, de_score, de_NM, _head, _tail);
+    return mini_line(r, left, right, right_x, line, _head, _tail);
 }
 HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t *pool, int pool_n, int32_t *_line)
 {
@@ -225,13 +225,14 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
         while (m) {
             const int q = __builtin_ctzll(m), g = g0 + q;
             m &= m - 1;
-            int ds = 0, dn = 0;
             // the usual case straight into the register routine; everything else (longer ranges: reach_run and the listing, the memory
             // version) behind a call of its own, so that this loop's frame stays small
             const int left = wv::bcast(lf, q), right = wv::bcast(rt, q), right_x = wv::bcast(rx, q), tail = wv::bcast(tl, q);
             const int k_n = hoff(r, right_x) - hoff(r, nx(r, left) + 1);
-            int n = k_n <= 64 ? mini_line_sets<1>(r, left, right, right_x, _line, &ds, &dn, 1, tail, k_n, nullptr) : -1;
-            if (n < 0) { ds = 0; dn = 0; n = mini_line_far(r, left, right, right_x, _line, &ds, &dn, 1, tail); }
+            MiniR mr; mr.n = -1; mr.d_score = 0; mr.d_NM = 0;
+            if (k_n <= 64) mr = mini_line_sets<1>(r, left, right, right_x, _line, 1, tail, k_n, nullptr);
+            if (mr.n < 0) mr = mini_line_far(r, left, right, right_x, _line, 1, tail);
+            const int n = mr.n, ds = mr.d_score, dn = mr.d_NM;
             if (cx.status & ST_REFEXIT) { R.pool_n = -1; return R; }
             if (R.pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; R.pool_n = -1; return R; }
             o_n[g] = n; o_off[g] = R.pool_n;
@@ -483,12 +484,13 @@ HP_HOT GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int 
             while (m) {
                 const int q = __builtin_ctzll(m), g = g0 + q;
                 m &= m - 1;
-                int dsc = 0, dnm = 0;
                 const int left = wv::bcast(lf, q), right = wv::bcast(rt, q), right_x = wv::bcast(rx, q), tail = wv::bcast(tl, q), s0 = wv::bcast(s0l, q), cnt = wv::bcast(ml, q);
-                int n = cnt <= 64 ? mini_line_sets<1>(r, left, right, right_x, _line, &dsc, &dnm, 1, tail, cnt, s_id + s0)
-                      : (cnt <= 64 * HP_MS_MAX_SETS ? mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, _line, &dsc, &dnm, 1, tail, cnt, s_id + s0) : -1);
+                MiniR mr; mr.n = -1; mr.d_score = 0; mr.d_NM = 0;
+                if (cnt <= 64) mr = mini_line_sets<1>(r, left, right, right_x, _line, 1, tail, cnt, s_id + s0);
+                else if (cnt <= 64 * HP_MS_MAX_SETS) mr = mini_line_sets<HP_MS_MAX_SETS>(r, left, right, right_x, _line, 1, tail, cnt, s_id + s0);
                 HP_STAT(4);
-                if (n < 0) { HP_STAT(5); dsc = 0; dnm = 0; n = mini_line_mem(r, left, right, right_x, _line, &dsc, &dnm, 1, tail); }
+                if (mr.n < 0) { HP_STAT(5); mr = mini_line_mem(r, left, right, right_x, _line, 1, tail); }
+                const int n = mr.n, dsc = mr.d_score, dnm = mr.d_NM;
                 if (cx.status & ST_REFEXIT) { arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
                 if (pool_n + n > H + 8) { cx.status |= ST_OVERFLOW; arena_release(cx.tmp, mark); R.pool_n = -1; return R; }
                 o_n[g] = n; o_off[g] = pool_n;

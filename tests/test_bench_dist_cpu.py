@@ -62,3 +62,18 @@ def test_single_rank_is_identity():
     import bench
     dt, tot = bench.reduce_job(1.5, [4, 3, 2, 1], 1)
     assert dt == 1.5 and tot.tolist() == [4, 3, 2, 1]
+
+
+def test_simulator_refuses_a_reference_without_room_for_the_read():
+    """tools/simhits.c draws a read's locus by rejection; with no contig longer than twice the read it used to draw for ever (a GPU-box run
+    was killed for silence over exactly that).  It now says so."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pytest
+    import simbatch
+    simbatch.build()
+    ref = simbatch.SimRef(400_000, n_contigs=4, seed=3, threads=2, repeats=False)          # four contigs of 100 kbp
+    with pytest.raises(ValueError, match="no contig"):
+        simbatch.SimBatch(ref, 4, 60_000, "ont2d", seed=1, threads=2)
+    B = simbatch.SimBatch(ref, 4, 20_000, "ont2d", seed=1, threads=2)                        # twice 20 kbp fits
+    assert B.n_reads == 4

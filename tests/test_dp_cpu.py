@@ -191,3 +191,19 @@ def test_four_jobs_per_wave_extension_matches_oracle(preset):
             want = reflib.oracle_dp([jobs[i] for i in idx], lp, 1, w, h0)
             for k, i in enumerate(idx):
                 assert (want["score"][k], want["qle"][k], want["tle"][k], list(want["cigars"][k])) == (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i])), (preset, h0, i)
+
+
+def test_no_caller_local_is_handed_by_address_to_a_non_inlined_device_routine(tmp_path):
+    """tools/noinl_guard.py over the device sources: every address-of argument at a call of an HP_NOINL routine is one of the accepted
+    context structures (tools/noinl_allow.txt); and the guard does see a planted violation."""
+    import subprocess
+    import sys
+    guard = os.path.join(reflib.ROOT, "tools", "noinl_guard.py")
+    q = subprocess.run([sys.executable, guard, "--report", os.devnull], capture_output=True, text=True)
+    assert q.returncode == 0, q.stderr
+    sys.path.insert(0, os.path.join(reflib.ROOT, "tools"))
+    import noinl_guard
+    src = "HP_NOINL int callee(ReadCtx &r, int *out)\n{\n    return 0;\n}\nHP_FN void caller(ReadCtx &r)\n{\n    int lo = 0, hi;\n    callee(r, &lo);\n}\n"
+    t = noinl_guard.strip_comments(src)
+    assert "callee" in noinl_guard.noinl_names({"x": t})
+    assert "lo" in noinl_guard.local_scalars_before(t, t.index("callee(r, &lo)"))

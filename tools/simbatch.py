@@ -97,6 +97,9 @@ class SimBatch:
         p = PROFILES[profile]
         cfg = SimCfg(n_reads, length, p["sub"], p["ins"], p["dele"], p.get("sv_frac", 0.0), 50, p["seed_step"], p["max_edit"], p["max_mis"], p["min_match"], 3, 200)
         bp = L.sim_reads_new(ref._p, seed, C.byref(cfg), threads)
+        if not bp:
+            need = 2 * length + 16 + (10016 if p.get("sv_frac", 0.0) > 0 else 0)
+            raise ValueError("no contig of the reference is longer than %d bp: a read of %d bases (profile %s) has no locus to be drawn from" % (need, length, profile))
         b = bp.contents
         n, ns, nh = b.n_reads, b.n_slots, b.n_hits
 

@@ -186,8 +186,14 @@ static void *read_worker(void *arg)
         rng_t g = { J->seed * 0x2545f4914f6cdd1dull + (uint64_t)r * 0x9e3779b97f4a7c15ull + 12345 };
         /* locus */
         int ci; int64_t pos;
-        for (;;) { int64_t gp = (int64_t)rndn(&g, (uint64_t)R->l_pac); ci = 0; while (ci + 1 < R->n_seqs && gp >= R->seq_off[ci + 1]) ++ci;
-                   pos = gp - R->seq_off[ci]; if (pos + (int64_t)L0 * 2 + 16 + (C->sv_frac > 0 ? 10016 : 0) < R->seq_len[ci]) break; }
+        /* rejection sampling over the whole reference; sim_reads_new has checked that some contig is long enough, and after a million
+         * misses (a reference that is nearly all short contigs) the read starts at the beginning of the first contig that is */
+        const int64_t need = (int64_t)L0 * 2 + 16 + (C->sv_frac > 0 ? 10016 : 0);
+        for (int tries = 0;; ++tries) {
+            int64_t gp = (int64_t)rndn(&g, (uint64_t)R->l_pac); ci = 0; while (ci + 1 < R->n_seqs && gp >= R->seq_off[ci + 1]) ++ci;
+            pos = gp - R->seq_off[ci]; if (pos + need < R->seq_len[ci]) break;
+            if (tries >= 1000000) { ci = 0; while (ci + 1 < R->n_seqs && need >= R->seq_len[ci]) ++ci; pos = 0; break; }
+        }
         const int strand = (rnd(&g) & 1) ? 1 : -1;
         /* one structural variant at the middle of the read: a deletion of U[1k,10k] reference
          * bases or a novel insertion of U[1k,5k] random bases.  No random number is drawn when sv_frac is 0, so the other
@@ -298,6 +304,11 @@ typedef struct {
 
 sim_batch *sim_reads_new(const sim_ref *R, uint64_t seed, const sim_cfg *C, int n_threads)
 {
+    /* a read of L0 bases needs a contig with room for its locus (twice its length, plus the largest structural variant): NULL when the
+     * reference has none -- the caller raises -- instead of a worker that draws loci for ever */
+    { const int64_t need = (int64_t)C->length * 2 + 16 + (C->sv_frac > 0 ? 10016 : 0); int ok = 0;
+      for (int c = 0; c < R->n_seqs; ++c) if (need < R->seq_len[c]) ok = 1;
+      if (!ok) return NULL; }
     if (n_threads < 1) n_threads = 1;
     if (n_threads > C->n_reads) n_threads = C->n_reads > 0 ? C->n_reads : 1;
     rd_job *jobs = (rd_job*)calloc((size_t)n_threads, sizeof(rd_job)); pthread_t *th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
