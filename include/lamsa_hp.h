@@ -83,6 +83,10 @@ const char *lamsa_hp_last_error(const lamsa_hp_handle *h);
  *   kind 0: ksw_global2      src/ksw.c:543   (global gap penalties, band w)
  *   kind 1: ksw_extend_core  src/ksw.c:667   (extension gap penalties, band w, h0)
  *   kind 2: ksw_bi_extend    src/ksw.c:862   (lh0 = rh0 = h0; w ignored)
+ *   kind 4, 5, 6: the same three by the one-job-per-lane routines the read path runs its small jobs on (queries up to 160, targets up
+ *           to 256 bases without N); kind 7: ksw_extend_core with ksw_bi_extend's band max(|qlen - tlen| + 3, band_w), four jobs per
+ *           wavefront (queries up to 127, targets up to 255, one h0 per call).  One class per call.  When the handle's penalties do
+ *           not keep 16-bit cells exact these kinds run on the routines of kinds 0-2, as the read path does.
  * Sequences are 1 byte/base codes 0..4; job i uses query seq[q_off[i] .. q_off[i]+qlen[i])
  * and target seq[t_off[i] .. t_off[i]+tlen[i]).
  * ---------------------------------------------------------------------------------- */
@@ -148,7 +152,8 @@ typedef struct lamsa_hp_result {
     const int32_t *read_len;      /* [n_reads] its length in words      */
     const int32_t *read_status;   /* [n_reads] LAMSA_HP_ST_* bits       */
     const int32_t *read_tbases;   /* [n_reads] reference bases the read's DP jobs fetched from the packed reference (accounting) */
-    const int32_t *read_work;     /* [2*n_reads] per read: DP cells updated, chaining edge classes evaluated (accounting: GCUPS, pair evaluations/s) */
+    const int32_t *read_work;     /* [4*n_reads] per read: DP cells updated, chaining edge classes evaluated, seed-CIGAR words read by the gap fill, 0
+                                     (accounting: GCUPS, pair evaluations/s, the algorithmic bytes of the fill launches) */
 } lamsa_hp_result;
 
 int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *batch, lamsa_hp_result *res);

@@ -14,6 +14,7 @@
 #define HP_FN  __device__
 #define HP_INL __device__ __forceinline__
 #define HP_NOINL __device__ __noinline__
+#define HP_HD __host__ __device__ inline         // parameter checks that the host side of the API makes too
 // routines called once per line / per track of a read (~100 calls per read) are inlined into the routine of their phase: a call costs its
 // frame -- the callee-saved registers of the callee, the live ones of the caller -- through scratch on EVERY call (measured on k_chain1:
 // 40 % of the kernel's HBM writes were such frames).  The phases themselves stay HP_NOINL, one call per read each: one function holding

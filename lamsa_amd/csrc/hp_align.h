@@ -112,7 +112,7 @@ HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, co
     r.H = (int)(r.hit_off[r.seed_out] - r.hb);
     r.h_pos = in.h_pos + r.hb; r.h_chr = in.h_chr + r.hb; r.h_cig_off = in.h_cig_off + r.hb; r.h_nm = in.h_nm + r.hb;
     r.h_len_dif = in.h_len_dif + r.hb; r.h_strand = in.h_strand + r.hb; r.h_cig_n = in.h_cig_n + r.hb; r.cig = in.cig;
-    r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.rc_read = nullptr; r.t_bases = 0;
+    r.flip = false; r.cur_read = r.read; r.rc_ready = false; r.rc_read = nullptr; r.t_bases = 0; r.cs_words = 0;
     r.prof = r.cx.prof; r.leaf_bits = nullptr; r.leaf_on = false; r.nodes_ready = false;
 }
 
@@ -265,8 +265,10 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     HP_STAMP(5);
     if (a.out.read_tbases) a.out.read_tbases[rd] = (int32_t)(r.t_bases > 0x7fffffffLL ? 0x7fffffffLL : r.t_bases);
     if (a.out.read_work) {
-        a.out.read_work[2 * rd] = (int32_t)(cx.n_cells > 0x7fffffffLL ? 0x7fffffffLL : cx.n_cells);
-        a.out.read_work[2 * rd + 1] = (int32_t)(r.n_pairs > 0x7fffffffLL ? 0x7fffffffLL : r.n_pairs);
+        a.out.read_work[4 * rd] = (int32_t)(cx.n_cells > 0x7fffffffLL ? 0x7fffffffLL : cx.n_cells);
+        a.out.read_work[4 * rd + 1] = (int32_t)(r.n_pairs > 0x7fffffffLL ? 0x7fffffffLL : r.n_pairs);
+        a.out.read_work[4 * rd + 2] = (int32_t)(r.cs_words > 0x7fffffffLL ? 0x7fffffffLL : r.cs_words);
+        a.out.read_work[4 * rd + 3] = 0;
     }
 }
 

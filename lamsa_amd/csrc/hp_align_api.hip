@@ -249,7 +249,7 @@ struct HostBuf {                  // page-locked host memory, mapped into the de
 // grid is running (a 0.6 GB copy took 10 ms beside it, five 0.5 MB ones 380 ms).
 struct OutDev {
     DevBuf buf; HostBuf host; int64_t stream_cap = 0; int n_cap = 0;
-    static size_t hdr(int n) { return 2 * al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256; }      // + 16 words of launch accounting
+    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256 + al256(16 * (size_t)n); }      // offsets, three int arrays, 16 words of launch accounting, four accounting words per read
     int ensure(int n, int64_t cap) { stream_cap = cap; n_cap = n; return buf.ensure(4 * (size_t)cap + 256) || host.ensure(hdr(n) + 256); }
     // device-visible addresses (kernel arguments)
     int64_t *off() const { return (int64_t *)host.dev; }
@@ -687,7 +687,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
 {
     const int n = T.n_reads;
     for (float &v : h->kernel_ms) v = 0;
-    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0); S->r_work.assign(2 * (size_t)n + 2, 0);   // never empty: pointers stay valid
+    S->r_st.assign((size_t)n + 1, 0); S->r_off.assign((size_t)n + 1, 0); S->r_len.assign((size_t)n + 1, 0); S->r_tb.assign((size_t)n + 1, 0); S->r_work.assign(4 * (size_t)n + 4, 0);   // never empty: pointers stay valid
     if (S->stream.ensure(64)) { h->err = "hipHostMalloc(results)"; return LAMSA_HP_ENOMEM; }
     if (n == 0) {
         if (R) { R->stream = (const int32_t *)S->stream.p; R->stream_words = 0; R->read_off = S->r_off.data(); R->read_len = S->r_len.data(); R->read_status = S->r_st.data(); R->read_tbases = S->r_tb.data(); R->read_work = S->r_work.data(); }
@@ -711,7 +711,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
     // the per-read arrays are in mapped host memory already (OutDev); the slot may be reused while the caller still
     // reads the results, so they are copied out
     memcpy(S->r_off.data(), Ln.out1.h_off(), 8 * (size_t)n); memcpy(S->r_len.data(), Ln.out1.h_len(n), 4 * (size_t)n);
-    memcpy(S->r_st.data(), Ln.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), Ln.out1.h_tb(n), 4 * (size_t)n); memcpy(S->r_work.data(), Ln.out1.h_work(n), 8 * (size_t)n);
+    memcpy(S->r_st.data(), Ln.out1.h_st(n), 4 * (size_t)n); memcpy(S->r_tb.data(), Ln.out1.h_tb(n), 4 * (size_t)n); memcpy(S->r_work.data(), Ln.out1.h_work(n), 16 * (size_t)n);
     unsigned long long used1 = 0;                        // the arena is handed out front to back: its fill is the largest end
     for (int r = 0; r < n; ++r) if (S->r_off[r] >= 0 && (unsigned long long)(S->r_off[r] + S->r_len[r]) > used1) used1 = (unsigned long long)(S->r_off[r] + S->r_len[r]);
     if ((int64_t)used1 > Ln.out1.stream_cap) used1 = (unsigned long long)Ln.out1.stream_cap;
@@ -732,7 +732,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
         const int64_t *off2 = S->out2.h_off(); const int32_t *len2 = S->out2.h_len(n), *st2 = S->out2.h_st(n), *tb2 = S->out2.h_tb(n), *wk2 = S->out2.h_work(n);
         for (int r : again) if (off2[r] >= 0 && (unsigned long long)(off2[r] + len2[r]) > used2) used2 = (unsigned long long)(off2[r] + len2[r]);
         if ((int64_t)used2 > cap2) used2 = (unsigned long long)cap2;
-        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; S->r_work[2 * r] = wk2[2 * r]; S->r_work[2 * r + 1] = wk2[2 * r + 1]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
+        for (int r : again) { S->r_st[r] = st2[r]; S->r_len[r] = len2[r]; S->r_tb[r] = tb2[r]; for (int q = 0; q < 4; ++q) S->r_work[4 * r + q] = wk2[4 * r + q]; S->r_off[r] = off2[r] < 0 ? -1 : (int64_t)used1 + off2[r]; }
     }
     for (int r = 0; r < n; ++r) if (S->r_off[r] < 0) { S->r_off[r] = 0; S->r_len[r] = 0; S->r_st[r] |= LAMSA_HP_ST_OVERFLOW; }
     if (!R) return LAMSA_HP_OK;

@@ -9,6 +9,7 @@
 #include <vector>
 #include <string>
 #include "hp_dp_batch.h"
+#include "hp_stripdp.h"
 
 using namespace hp;
 
@@ -24,6 +25,73 @@ __global__ __launch_bounds__(64) void k_dp_batch(DpBatchArgs a)
         job = wv::uni(job);
         if (job >= a.n_jobs) break;
         dp_run_job(a, job, slot, (HP_L int32_t *)lds);
+    }
+}
+
+// The same jobs by the routines the read path's small-job launches use: kinds 4 / 5 / 6 = ksw_global2 / ksw_extend_core / ksw_bi_extend one
+// job per LANE (hp_lanedp.h, what k_filldp_small runs), kind 7 = ksw_extend_core with ksw_bi_extend's band, four jobs per wave
+// (hp_stripdp.h).  Targets come 2 bits per base (tk: first base of every job in `pac`), as those routines read the reference.
+__global__ __launch_bounds__(64, 1) void k_dp_batch_lane(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
+{
+    __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+    const lamsa_hp_para *P = &a.P;
+    char *slab = a.slab + (size_t)blockIdx.x * a.slab_per_wave;
+    cig_t *cbuf = (cig_t *)slab;
+    uint8_t *zbuf = (uint8_t *)(slab + sizeof(cig_t) * 3 * HP_LJ_CIG * 64);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(a.counter, 1);
+        g = wv::uni(g);
+        if (g * 64 >= a.n_jobs) break;
+        wv::sync();
+        WAVE_FOR(l) {
+            const int job = g * 64 + l;
+            if (job < a.n_jobs) {
+                LaneJob J;
+                J.q = (const HP_G uint8_t *)(a.seq + a.q_off[job]); J.qs = 1; J.qcomp = 0; J.qlen = a.qlen[job]; J.pac = (const HP_G uint8_t *)pac; J.tk = tk[job]; J.ts = 1; J.tlen = a.tlen[job];
+                J.z = (HP_G uint8_t *)zbuf; J.zl = l; J.zs = HP_LJ_QCAP; J.cells = 0; J.row = (HP_L int32_t *)lds + l; J.qrow = (HP_L uint8_t *)((HP_L int32_t *)lds + (HP_LJ_QCAP + 2) * 64) + l; J.rev = 0;
+                lj_stage_query(J);
+                LCig out, Lc, Rc;
+                out.c = cbuf + (size_t)l * 3 * HP_LJ_CIG; out.n = 0; Lc.c = out.c + HP_LJ_CIG; Lc.n = 0; Rc.c = Lc.c + HP_LJ_CIG; Rc.n = 0;
+                int sc = 0, qle = 0, tle = 0;
+                const int kind = a.kind[job];
+                if (kind == 4) sc = lj_global(P, J, P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, a.w[job], &out);
+                else if (kind == 5) sc = lj_extend(P, J, a.w[job], a.h0[job], &qle, &tle, &out);
+                else sc = lj_bi_extend(P, J, a.h0[job], a.h0[job], Lc, Rc, out);
+                a.score[job] = sc; a.qle[job] = qle; a.tle[job] = tle; a.status[job] = 0; a.cig_n[job] = out.n;
+                cig_t *dst = a.cig + a.cig_cap_off[job];
+                for (int k = 0; k < out.n; ++k) dst[k] = out.c[k];
+            }
+        }
+        wv::sync();
+    }
+}
+__global__ __launch_bounds__(64, 4) void k_dp_batch_strip(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
+{
+    char *slab = a.slab + (size_t)blockIdx.x * a.slab_per_wave;
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(a.counter, 1);
+        g = wv::uni(g);
+        if (g * 4 >= a.n_jobs) break;
+        StripJob J;
+        WAVE_FOR(l) {
+            const int job = g * 4 + (l >> 4);
+            J.on[l] = job < a.n_jobs; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0;
+            if (job < a.n_jobs) { J.q[l] = (long long)(a.seq + a.q_off[job]); J.qlen[l] = a.qlen[job]; J.tlen[l] = a.tlen[job]; J.tk[l] = tk[job]; }
+        }
+        StripRes O;
+        cig_t *cb = (cig_t *)(slab + (size_t)4 * HP_ST_ZROWS * 16 * 4);
+        strip_extend(&a.P, (const HP_G uint8_t *)pac, J, wv::uni(a.h0[g * 4]), (uint32_t *)slab, cb, O);
+        WAVE_FOR(l) {
+            const int job = g * 4 + (l >> 4);
+            if (job < a.n_jobs) {
+                if ((l & 15) == 0) { a.score[job] = O.score[l]; a.qle[job] = O.qle[l]; a.tle[job] = O.tle[l]; a.status[job] = 0; a.cig_n[job] = O.n_cig[l]; }
+                cig_t *dst = a.cig + a.cig_cap_off[job]; const cig_t *src = cb + (size_t)(l >> 4) * HP_ST_CIG;
+                for (int k = l & 15; k < O.n_cig[l]; k += 16) dst[k] = src[k];
+            }
+        }
+        wv::sync();
     }
 }
 
@@ -66,7 +134,7 @@ extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
     if (h->d_pac) hipFree(h->d_pac);
     if (h->d_seq_off) hipFree(h->d_seq_off);
     if (h->d_seq_len) hipFree(h->d_seq_len);
-    h->in.release(); h->out.release(); h->slab.release(); h->misc.release();
+    h->in.release(); h->out.release(); h->slab.release(); h->misc.release(); h->pac2.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -99,8 +167,44 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         size_t need = 2 * 4 * ((size_t)ql + 18) + 8 * ((size_t)tl + 17) + ncol * tl + 64 + 3 * 4 * ((size_t)ql + tl + 24) + 1024;
         if (need > z_need) z_need = need;
     }
+    // kinds 4..7: the lane-per-job / four-per-wave routines (one class per call); they take jobs up to their buffers' sizes and, like the
+    // read path, only when the handle's penalties keep their 16-bit cells exact -- else the jobs run on the wave routines (kind & 3)
+    int cls = 0;                                          // 0: wave routines, 1: a job per lane, 2: four jobs per wave
+    std::vector<int32_t> kind_v;
+    std::vector<uint8_t> pac; std::vector<int64_t> tkv;
+    if (n > 0 && J->kind[0] >= 4) {
+        cls = J->kind[0] == 7 ? 2 : 1;
+        for (int i = 0; i < n; ++i) {
+            const int k = J->kind[i];
+            if (k < 4 || k > 7 || (k == 7) != (cls == 2)) { h->err = "dp batch mixes job classes"; return LAMSA_HP_EINVAL; }
+            if (cls == 2 && J->h0[i] != J->h0[0]) { h->err = "kind 7 jobs of one call share h0"; return LAMSA_HP_EINVAL; }
+            const int qcap = cls == 1 ? HP_LJ_QCAP : HP_ST_QMAX, tcap = cls == 1 ? HP_LJ_TCAP : HP_ST_TMAX;
+            if (J->qlen[i] < 0 || J->qlen[i] > qcap || J->tlen[i] < 0 || J->tlen[i] > tcap || (k != 4 && J->h0[i] <= 0)) { h->err = "dp job beyond the lane routines' buffers"; return LAMSA_HP_EINVAL; }
+        }
+        const bool ok16 = cls == 1 ? lj_params_ok(&h->para) : st_params_ok(&h->para, J->h0[0]);
+        if (!ok16) {                                       // as the read path does: these parameters stay on the wave routines
+            kind_v.assign(J->kind, J->kind + n);
+            for (int i = 0; i < n; ++i) kind_v[i] = kind_v[i] == 7 ? 1 : kind_v[i] - 4;
+            cls = 0;
+        } else {
+            int64_t tot = 0;
+            for (int i = 0; i < n; ++i) tot += J->tlen[i];
+            pac.assign((size_t)tot / 4 + 16, 0); tkv.assign((size_t)n + 1, 0);
+            int64_t k = 0;
+            for (int i = 0; i < n; ++i) {
+                tkv[i] = k;
+                for (int j = 0; j < J->tlen[i]; ++j, ++k) {
+                    const uint8_t b = J->seq[J->t_off[i] + j];
+                    if (b > 3) { h->err = "the lane routines read the target 2 bits per base: no N"; return LAMSA_HP_EINVAL; }
+                    pac[(size_t)(k >> 2)] |= (uint8_t)(b << ((~k & 3) << 1));
+                }
+            }
+            z_need = cls == 1 ? sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 : (size_t)HP_ST_SLAB_BYTES;
+        }
+    }
+    const int32_t *kind_src = kind_v.empty() ? J->kind : kind_v.data();
     const size_t slab_per_wave = al256(z_need);
-    int n_waves = h->n_cu * 8;
+    int n_waves = h->n_cu * (cls == 1 ? 3 : (cls == 2 ? 16 : 8));
     if (n_waves > n) n_waves = n > 0 ? n : 1;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)64 << 30)) n_waves /= 2;
 
@@ -122,7 +226,13 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         HIPCHK(h, hipMemcpyAsync(din + o_cap, cap_off.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_ql, J->qlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_tl, J->tlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
-        HIPCHK(h, hipMemcpyAsync(din + o_kind, J->kind, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpyAsync(din + o_kind, kind_src, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
+        std::vector<int32_t> w_v;
+        if (!kind_v.empty()) {                              // a kind-7 job on the wave routines: the band ksw_bi_extend gives it (src/ksw.c:873)
+            w_v.assign(J->w, J->w + n);
+            for (int i = 0; i < n; ++i) if (J->kind[i] == 7) { const int d = abs(J->qlen[i] - J->tlen[i]) + 3; w_v[i] = d > h->para.band_w ? d : h->para.band_w; }
+            HIPCHK(h, hipMemcpy(din + o_w, w_v.data(), 4 * (size_t)n, hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
+        } else
         HIPCHK(h, hipMemcpyAsync(din + o_w, J->w, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_h0, J->h0, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
     }
@@ -139,7 +249,15 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
     a.slab = (char *)h->slab.p; a.slab_per_wave = slab_per_wave; a.counter = (int32_t *)h->misc.p;
 
     HIPCHK(h, hipEventRecord(h->ev0, s), LAMSA_HP_EKERNEL);
-    if (n > 0) hipLaunchKernelGGL(k_dp_batch, dim3(n_waves), dim3(64), 0, s, a);
+    if (n > 0 && cls == 0) hipLaunchKernelGGL(k_dp_batch, dim3(n_waves), dim3(64), 0, s, a);
+    else if (n > 0) {
+        const size_t pb = al256(pac.size()), tb = al256(8 * ((size_t)n + 1));
+        if (h->pac2.ensure(pb + tb)) { h->err = "hipMalloc(pac)"; return LAMSA_HP_ENOMEM; }
+        HIPCHK(h, hipMemcpy(h->pac2.p, pac.data(), pac.size(), hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
+        HIPCHK(h, hipMemcpy((char *)h->pac2.p + pb, tkv.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
+        if (cls == 1) hipLaunchKernelGGL(k_dp_batch_lane, dim3(n_waves), dim3(64), 0, s, a, (const uint8_t *)h->pac2.p, (const int64_t *)((char *)h->pac2.p + pb));
+        else hipLaunchKernelGGL(k_dp_batch_strip, dim3(n_waves), dim3(64), 0, s, a, (const uint8_t *)h->pac2.p, (const int64_t *)((char *)h->pac2.p + pb));
+    }
     HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(h->ev1, s), LAMSA_HP_EKERNEL);
 

@@ -47,7 +47,7 @@ struct BatchOut {
     int32_t *read_out_len;       // [n_reads]
     int32_t *read_status;        // [n_reads]
     int32_t *read_tbases;        // [n_reads] reference bases fetched (2-bit windows), or nullptr
-    int32_t *read_work;          // [2 * n_reads] per read: DP cells updated, chaining edge classifications executed; or nullptr
+    int32_t *read_work;          // [4 * n_reads] per read: DP cells updated, chaining edge classifications executed, seed-CIGAR words read, 0; or nullptr
     unsigned long long *diag;    // 16 words of launch accounting (hp_phase.h), or nullptr
 };
 

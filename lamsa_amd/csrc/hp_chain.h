@@ -63,6 +63,7 @@ struct ReadCtx {
     const uint8_t *cur_read;    // strand-appropriate read of the line being filled
     long long t_bases;          // reference bases fetched for this read (sum of DP target / NM window lengths): roofline accounting
     long long n_pairs;          // edge classifications (get_fseed_dis evaluations) executed for this read: accounting
+    long long cs_words;         // seed-CIGAR words the fill has read (the hits on the read's lines): roofline accounting
     bool flip;                  // seed ids flipped (k -> seed_all+1-k) while a '-' line is filled (frag_check.c:926,953)
     const int32_t *seed_id;     // [seed_out]
     const int64_t *hit_off;     // [seed_out+1], global; local hit index = global - hb

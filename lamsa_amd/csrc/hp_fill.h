@@ -176,7 +176,7 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
     if (strand == 1) { i = seed_n - 1; last = seed[i]; rs = (sid(r, r.n_seed[last]) - 1) * P->seed_step + 1; }
     else { i = 0; last = seed[0]; rs = r.last_len + (sid(r, r.n_seed[last]) - 1) * P->seed_step + 1; }
     re = rs - 1 + P->seed_len;
-    cig_pushv(cx, fc, r.cig + r.h_cig_off[last], r.h_cig_n[last]);
+    cig_pushv(cx, fc, r.cig + r.h_cig_off[last], r.h_cig_n[last]); r.cs_words += r.h_cig_n[last];
     const int64_t ref_start = r.h_pos[last];
     int64_t ref_end = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
     const int step = strand == 1 ? -1 : 1;
@@ -188,7 +188,7 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
             if (gt && gt[3] && F.jarena) {                                      // the gap's CIGAR was computed ahead (hp_lanedp.h)
                 const uint8_t *qp0; const int len1p = read_gap(r, last, s, &qp0);
                 ok = merge_cigar(r, fc, &ref_end, &re, chr, F.jarena + gt[0], gt[1], gt[2], len1p) &&
-                     merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len);
+                     (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
                 last = s;
                 continue;
             }
@@ -207,7 +207,7 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
         if (!cig_alloc(cx, g, len1 + len2 + 8)) { ok = false; break; }
         ksw_global(cx, len1, seq_fwd(qp), len2, seq_fwd(tb ? tb : qp), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &g);
         ok = merge_cigar(r, fc, &ref_end, &re, chr, g.c, g.n, len2, len1) &&
-             merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len);
+             (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
         last = s;
         arena_release(cx.tmp, m2);
     }
@@ -224,6 +224,7 @@ HP_INL bool frag_extend(ReadCtx &r, const FLines &F, int frag, Rec &res)
     if (o1 - o0 != 1) return frag_extend_multi(r, F, frag, res);
     const lamsa_hp_para *P = r.cx.P;
     const int s = F.fr_seed[o0];
+    r.cs_words += r.h_cig_n[s];
     const bool ok = merge_cigar(r, res.cig, &res.refend, &res.readend, r.h_chr[s], r.cig + r.h_cig_off[s], r.h_cig_n[s],
                                 P->seed_len + r.h_len_dif[s], P->seed_len);
     return ok && !(r.cx.status & (ST_REFEXIT | ST_OVERFLOW));
@@ -466,6 +467,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
     wv::sync();
     int tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
     bool ok = true, ovf = false;
+    long long cs_ = 0;                               // seed-CIGAR words appended (accounting, flushed once)
     MergeLoc ml; mloc_in(ml, res);                   // the record's running state, in registers
     for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
         // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
@@ -507,6 +509,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                 MergeSrc S;
                 S.p = r.cig + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
                 S.reflen = wv::bcast(V[6], q); S.readlen = P->seed_len;
+                cs_ += S.n;
                 ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[7], q), S);
             } else {
                 mloc_out(ml, res);
@@ -535,6 +538,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
         }
     }
     mloc_out(ml, res);
+    r.cs_words += cs_;
     if (ovf) cx.status |= ST_OVERFLOW;
     wv::sync();
     arena_release(cx.tmp, mark);

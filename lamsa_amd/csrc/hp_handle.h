@@ -33,7 +33,7 @@ struct lamsa_hp_handle {
     uint8_t *d_pac = nullptr; int64_t l_pac = 0; int32_t n_seqs = 0;
     int64_t *d_seq_off = nullptr; int32_t *d_seq_len = nullptr;
     // reusable device buffers
-    DevBuf in, out, slab, misc;
+    DevBuf in, out, slab, misc, pac2;      // pac2: the targets of a lane-kind DP batch, 2 bits per base
     // host-side result storage (callee-owned outputs)
     std::vector<int32_t> h_i32; std::vector<int64_t> h_i64; std::vector<int32_t> h_cig;
     std::vector<int32_t> h_score, h_qle, h_tle, h_status;

@@ -90,7 +90,7 @@ HP_INL void lj_backtrack(const LaneJob &J, int n_col, int w, int i, int k, LCig 
 // -20000 for MINUS_INF and F < 10000 the two kinds stay apart (-20000 + F < -F) and nothing leaves the 16 bits (-20000 - F > -32768),
 // and the offsets from MINUS_INF are the reference's own, so every comparison of the recurrence (and with it every direction bit) is
 // the one the reference makes with 32-bit cells.  ksw_extend_core's cells lie in [0, h0 + qlen * match].
-HP_INL bool lj_params_ok(const lamsa_hp_para *P)
+HP_HD bool lj_params_ok(const lamsa_hp_para *P)
 {
     int mx = P->match;
     const int v[] = {P->mis, P->ins_gapo, P->ins_gape, P->del_gapo, P->del_gape, P->ins_ext_o, P->ins_ext_e, P->del_ext_o, P->del_ext_e, 1};

@@ -23,13 +23,14 @@
 
 namespace hp {
 
-struct RdMeta {                  // 64 bytes per read, zeroed before chain1
+struct RdMeta {                  // 72 bytes per read, zeroed before chain1
     int64_t fl_off[2];           // the FLines block of each round in the fragment arena (words)
     int32_t fl_n[2], fl_tot[2], fl_nfrag[2];
     int32_t unit_base[2];        // first fill unit of each round (units of a read and round are consecutive, in line order)
     int32_t status;              // ST_* bits, OR-ed in by every phase
     int32_t tbases;              // reference bases fetched by the read's DP jobs (roofline accounting)
     int32_t cells, pairs;        // DP cells updated / chaining edge classifications executed (accounting)
+    int32_t cs_words, pad_;      // seed-CIGAR words the fill read (accounting)
 };
 
 struct UnitRec {                 // one line to fill
@@ -84,11 +85,12 @@ HP_INL void drain_stamp(const PhaseArgs &a, int k)
 HP_INL void meta_flag(const PhaseArgs &a, int rd, const ReadCtx &r)
 {
     if (wv::leader()) {
-        const long long tb = r.t_bases, nc = r.cx.n_cells, np = r.n_pairs;
+        const long long tb = r.t_bases, nc = r.cx.n_cells, np = r.n_pairs, cw = r.cs_words;
         if (r.cx.status) atomicOr(&a.meta[rd].status, r.cx.status);
         if (tb > 0) atomicAdd(&a.meta[rd].tbases, (int)(tb > 0x3fffffffLL ? 0x3fffffffLL : tb));
         if (nc > 0) atomicAdd(&a.meta[rd].cells, (int)(nc > 0x3fffffffLL ? 0x3fffffffLL : nc));
         if (np > 0) atomicAdd(&a.meta[rd].pairs, (int)(np > 0x3fffffffLL ? 0x3fffffffLL : np));
+        if (cw > 0) atomicAdd(&a.meta[rd].cs_words, (int)(cw > 0x3fffffffLL ? 0x3fffffffLL : cw));
     }
 }
 
@@ -601,7 +603,7 @@ HP_NOINL void phase_publish(const PhaseArgs &a, int rd)
     } else { a.out.read_out_off[rd] = -1; a.out.read_out_len[rd] = 0; }
     a.out.read_status[rd] = st;
     if (a.out.read_tbases) a.out.read_tbases[rd] = M.tbases;
-    if (a.out.read_work) { a.out.read_work[2 * rd] = M.cells; a.out.read_work[2 * rd + 1] = M.pairs; }
+    if (a.out.read_work) { a.out.read_work[4 * rd] = M.cells; a.out.read_work[4 * rd + 1] = M.pairs; a.out.read_work[4 * rd + 2] = M.cs_words; a.out.read_work[4 * rd + 3] = 0; }
 }
 
 // launch accounting for the host: the earlier launches are complete when publish starts

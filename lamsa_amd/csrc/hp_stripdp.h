@@ -274,7 +274,7 @@ HP_INL void strip_extend(const lamsa_hp_para *P, const HP_G uint8_t *pac, const 
 }
 
 // Do this handle's parameters keep ksw_extend_core's cells -- [0, h0 + qlen * match] -- and the keys of the row maximum inside their fields?
-HP_INL bool st_params_ok(const lamsa_hp_para *P, int h0)
+HP_HD bool st_params_ok(const lamsa_hp_para *P, int h0)
 {
     return lj_params_ok(P) && h0 > 0 && h0 + HP_ST_QMAX * P->match < 32000 && P->ins_ext_e > 0 && P->del_ext_e > 0;
 }

@@ -63,12 +63,25 @@ EXPORTS = ("lamsa_hp_para_init", "lamsa_hp_para_finish", "lamsa_hp_create", "lam
 _lib = None
 
 
-def load_library(path=LIB_PATH):
-    """Load liblamsa_hp.so; raises if it has not been built (no fallback).  LAMSA_HP_LIB names another build of the same
-    library (diagnostic builds with cycle counters: make -C lamsa_amd/csrc OUT=... EXTRA=-DHP_PROF)."""
-    global _lib
-    path = os.environ.get("LAMSA_HP_LIB", path)
+_lib_path = None
+
+
+def loaded_library():
+    """(path, sha256 of the file) of the library load_library has loaded -- bench.py puts both into its JSON line."""
+    import hashlib
+    if _lib_path is None:
+        return None, None
+    return _lib_path, hashlib.sha256(open(_lib_path, "rb").read()).hexdigest()
+
+
+def load_library(path=None):
+    """Load liblamsa_hp.so; raises if it has not been built (no fallback).  Without an explicit path, LAMSA_HP_LIB may name another
+    build of the same library (diagnostic builds with cycle counters: make -C lamsa_amd/csrc OUT=... EXTRA=-DHP_PROF)."""
+    global _lib, _lib_path
+    if path is None:
+        path = os.environ.get("LAMSA_HP_LIB", LIB_PATH)
     if _lib is None:
+        _lib_path = os.path.abspath(path)
         if not os.path.exists(path):
             raise RuntimeError("HIP hot-path library missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
         L = C.CDLL(path)
@@ -218,7 +231,7 @@ class LamsaHp:
         st = np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n].copy()
         stream = np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)).copy()
         self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n].copy()
-        self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n].copy()
+        self.last_work = np.ctypeslib.as_array(R.read_work, (max(4 * n, 4),))[:4 * n].copy()
         self.last_stream_words = int(R.stream_words)
         return [stream[int(off[i]):int(off[i]) + int(ln[i])].tolist() for i in range(n)], st
 
@@ -250,7 +263,7 @@ class LamsaHp:
         if raw:
             n = self._n_up
             self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
-            self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n]
+            self.last_work = np.ctypeslib.as_array(R.read_work, (max(4 * n, 4),))[:4 * n]
             self.last_stream_words = int(R.stream_words)
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])
@@ -273,7 +286,7 @@ class LamsaHp:
         n = self._n_up
         if raw:
             self.last_tbases = np.ctypeslib.as_array(R.read_tbases, (max(n, 1),))[:n]
-            self.last_work = np.ctypeslib.as_array(R.read_work, (max(2 * n, 2),))[:2 * n]
+            self.last_work = np.ctypeslib.as_array(R.read_work, (max(4 * n, 4),))[:4 * n]
             self.last_stream_words = int(R.stream_words)
             return (np.ctypeslib.as_array(R.stream, (max(int(R.stream_words), 1),)), np.ctypeslib.as_array(R.read_off, (max(n, 1),))[:n],
                     np.ctypeslib.as_array(R.read_len, (max(n, 1),))[:n], np.ctypeslib.as_array(R.read_status, (max(n, 1),))[:n])

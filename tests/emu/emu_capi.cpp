@@ -61,7 +61,7 @@ extern "C" int lamsa_hp_align_batch(lamsa_hp_handle *h, const lamsa_hp_batch *B,
     h->stream.clear();
     for (int r = 0; r < n; ++r) { h->off[r] = (int64_t)h->stream.size(); h->len[r] = (int32_t)per[r].size(); h->stream.insert(h->stream.end(), per[r].begin(), per[r].end()); }
     res->stream = h->stream.data(); res->stream_words = (int64_t)h->stream.size(); res->read_off = h->off.data(); res->read_len = h->len.data();
-    res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(2 * h->tb.size() + 2, 0); res->read_work = h->work.data();
+    res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(4 * h->tb.size() + 4, 0); res->read_work = h->work.data();
     return LAMSA_HP_OK;
 }
 
@@ -90,7 +90,7 @@ extern "C" int lamsa_hp_collect_batch(lamsa_hp_handle *h, lamsa_hp_result *res)
     h->fifo.pop_front();
     if (h->stream.empty()) h->stream.push_back(0);
     res->stream = h->stream.data(); res->stream_words = 0; for (size_t r = 0; r + 1 < h->len.size(); ++r) res->stream_words += h->len[r];
-    res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(2 * h->tb.size() + 2, 0); res->read_work = h->work.data();
+    res->read_off = h->off.data(); res->read_len = h->len.data(); res->read_status = h->status.data(); res->read_tbases = h->tb.data(); h->work.assign(4 * h->tb.size() + 4, 0); res->read_work = h->work.data();
     return LAMSA_HP_OK;
 }
 extern "C" int lamsa_hp_reserve(lamsa_hp_handle *, int32_t, int64_t, int64_t, int64_t, int32_t, int32_t) { return LAMSA_HP_OK; }

@@ -9,6 +9,7 @@
 #define HP_FN  static
 #define HP_INL static inline
 #define HP_NOINL static
+#define HP_HD static inline
 #define HP_HOT static inline
 
 #define HP_G

@@ -210,3 +210,40 @@ def test_index_files_identical_to_the_reference(cli, tmp_path):
     q = subprocess.run([cli, "aln", "-N"] + args + [ref, str(tmp_path / "reads.fa")], capture_output=True, text=True)
     assert q.returncode == 0, q.stderr[-2000:]
     assert G.strip_pg(q.stdout) == G.strip_pg(G.golden_full("c7_rescue"))
+
+
+REF_BIN = os.path.join(reflib.ROOT, "oracle", "_ref", "lamsa")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="the compiled reference (oracle/_ref/lamsa) is only built where /root/reference exists")
+@pytest.mark.parametrize("workload,n_reads", [("ont10k", 24), ("pb5k", 32), ("sv10k", 32), ("mol5k", 32)])
+def test_bench_shaped_reads_against_the_reference_binary(cli, workload, n_reads, tmp_path):
+    """The bench's own inputs -- simulated reads and seed hits of a bench workload against a repeat-planted stand-in, written as the files
+    `lamsa aln` reads -- through the REFERENCE binary and through the product's host program over the (emulated) device sources: the same
+    SAM.  tests/test_cli_gpu.py does the same with the HIP library at 200-500 reads per workload, bench.py on its CPU-baseline sample."""
+    import shutil
+    import sys
+    sys.path.insert(0, reflib.ROOT); sys.path.insert(0, os.path.join(reflib.ROOT, "tools"))
+    import bench
+    import simbatch
+    import simfiles
+    simbatch.build()
+    wl = bench.WORKLOADS[workload]
+    ref = simbatch.SimRef(120_000_000, n_contigs=6, seed=5, threads=8)
+    B = simbatch.SimBatch(ref, n_reads, wl["length"], wl["profile"], seed=99, threads=8)
+    d = str(tmp_path)
+    simfiles.write_index(d + "/ref.fa", ref)
+    for ext in ("bwt", "sa"):
+        shutil.copy(os.path.join(reflib.ROOT, "tests", "golden", "ref", "ref.fa." + ext), d + "/ref.fa." + ext)
+    p = simbatch.PROFILES[wl["profile"]]
+    simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"])
+    with open(d + "/reads.fa.seed.info", "w") as f:
+        for r in range(n_reads):
+            f.write("r%d %d %d %d\n" % (r, int(B.seed_all[r]), int(B.last_len[r]), int(B.read_off[r + 1] - B.read_off[r])))
+    args = [] if wl["read_type"] == "default" else ["-T", wl["read_type"]]
+    for k, v in wl["over"].items():
+        args += [{"band_w": "-w", "SV_len_thd": "-V"}[k], str(v)]
+    want = subprocess.run([REF_BIN, "aln"] + args + ["-t", "4", "-N", "-I", "-R", "0", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True, timeout=900)
+    assert want.returncode == 0, want.stderr[-2000:]
+    res = bench.compare_with_product(d, args, 4, n_reads, exe=cli)
+    assert res == "%d/%d reads" % (n_reads, n_reads), res

@@ -103,3 +103,39 @@ def test_map_is_read_while_the_mapper_writes_it_on_the_gpu(tmp_path):
         assert "gem-mapper done!" in p.stderr
         assert G.strip_pg(p.stdout) == G.strip_pg(gold)
         os.remove(reads + ".seed.gem.map")
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "lamsa")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="the compiled reference (oracle/_ref/lamsa, built where /root/reference exists) did not travel")
+@pytest.mark.parametrize("workload,n_reads", [("ont10k", 500), ("pb5k", 500), ("pb20k", 200), ("sv10k", 500)])
+def test_sam_identical_to_the_reference_binary_at_bench_shapes(workload, n_reads, tmp_path):
+    """At-scale parity against the reference ITSELF (not the oracle): reads and seed hits of a bench workload (bench.WORKLOADS: read length,
+    error profile, options) written as the files `lamsa aln` reads, aligned by the compiled reference (`oracle/_ref/lamsa aln -N -I -R 0`,
+    from /root/reference/src, CPU) and by the product binary on the MI355X -- the same SAM, record for record."""
+    import shutil
+    import sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import simbatch
+    import simfiles
+    wl = bench.WORKLOADS[workload]
+    ref = simbatch.SimRef(600_000_000, n_contigs=12, seed=5, threads=16)
+    B = simbatch.SimBatch(ref, n_reads, wl["length"], wl["profile"], seed=4242, threads=16)
+    d = str(tmp_path)
+    simfiles.write_index(d + "/ref.fa", ref)
+    for ext in ("bwt", "sa"):                       # loaded by the reference at start-up, never searched with -R 0 (src/lamsa_aln.c:1233)
+        shutil.copy(os.path.join(ROOT, "tests", "golden", "ref", "ref.fa." + ext), d + "/ref.fa." + ext)
+    p = simbatch.PROFILES[wl["profile"]]
+    simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"], workers=16)
+    with open(d + "/reads.fa.seed.info", "w") as f:
+        for r in range(n_reads):
+            f.write("r%d %d %d %d\n" % (r, int(B.seed_all[r]), int(B.last_len[r]), int(B.read_off[r + 1] - B.read_off[r])))
+    args = [] if wl["read_type"] == "default" else ["-T", wl["read_type"]]
+    for k, v in wl["over"].items():
+        args += [{"band_w": "-w", "SV_len_thd": "-V"}[k], str(v)]
+    want = subprocess.run([REF_BIN, "aln"] + args + ["-t", "16", "-N", "-I", "-R", "0", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True, timeout=900)
+    assert want.returncode == 0, want.stderr[-2000:]
+    res = bench.compare_with_product(d, args, 16, n_reads)
+    assert res == "%d/%d reads" % (n_reads, n_reads), res

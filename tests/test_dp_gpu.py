@@ -98,3 +98,63 @@ def test_hip_wide_band_uses_hbm_rows(handles):
     for kind, w, h0 in ((0, 400, 0), (1, 600, 5000), (1, 300, 20000)):
         got = handles["default"].dp_batch(jobs, kind, w, h0)
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (kind, w)
+
+
+def _lane_jobs(seed, err, qmax, tmax):
+    return [(q, t) for q, t in dpjobs.make_jobs(seed, 1400, 150, err) if len(q) <= qmax and len(t) <= tmax and (len(t) == 0 or t.max() < 4)]
+
+
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_hip_lane_per_job_routines_match_oracle(handles, rt):
+    """hp_lanedp.h on the MI355X, driven directly: kinds 4 / 5 / 6 of lamsa_hp_dp_batch run ksw_global2 / ksw_extend_core /
+    ksw_bi_extend one job per LANE with 16-bit cells in lane-strided LDS -- the routines k_filldp_small runs for the read path, whose
+    LDS strides and lane-interleaved direction matrix the CPU emulation cannot see.  Against the oracle, bit for bit."""
+    lp = reflib.lo_para(rt)
+    jobs = _lane_jobs(900 + len(rt), ERR[rt], 160, 256)
+    assert len(jobs) > 600
+    for kind, w, h0 in ((0, lp.band_w, 0), (0, 7, 0), (1, lp.band_w, 50), (1, 12, 8), (2, 0, 100), (2, 0, 10)):
+        got = handles[rt].dp_batch(jobs, kind + 4, w, max(h0, 1))
+        want = reflib.oracle_dp(jobs, lp, kind, w, max(h0, 1))
+        assert goldenlib.same_dp(want, got, kind) == [], (rt, kind, w, h0)
+
+
+@pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
+def test_hip_four_jobs_per_wave_extension_matches_oracle(handles, rt):
+    """hp_stripdp.h on the MI355X (kind 7 of lamsa_hp_dp_batch): a junction's left extension on one 16-lane DPP row -- row_shr scans and
+    row all-reduces confined to the row, which the CPU emulation only models."""
+    lp = reflib.lo_para(rt)
+    jobs = _lane_jobs(300 + len(rt), ERR[rt], 127, 255)
+    for h0 in (100, 10):
+        got = handles[rt].dp_batch(jobs, 7, 0, h0)
+        by_w = {}
+        for i, (q, t) in enumerate(jobs):
+            by_w.setdefault(max(abs(len(q) - len(t)) + 3, lp.band_w), []).append(i)
+        for w, idx in by_w.items():
+            want = reflib.oracle_dp([jobs[i] for i in idx], lp, 1, w, h0)
+            for k, i in enumerate(idx):
+                assert (want["score"][k], want["qle"][k], want["tle"][k], list(want["cigars"][k])) == (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i])), (rt, h0, i)
+
+
+def test_hip_lane_kinds_fall_back_when_sixteen_bit_cells_are_not_exact():
+    """Penalties beyond lj_params_ok (a gap extension of 60 makes 16-bit cells unsafe): the read path keeps such a handle's small jobs on
+    the wave routines, and so do kinds 4-7 -- same results as the oracle with those penalties."""
+    from lamsa_amd import hp
+    over = dict(ins_gape=60, del_gape=60, ins_ext_e=60, del_ext_e=60)
+    lp = reflib.lo_para("ont2d", **over)
+    h = hp.LamsaHp(hp.make_para("ont2d", **over))
+    try:
+        jobs = _lane_jobs(61, ERR["ont2d"], 127, 255)[:300]
+        for kind, w, h0 in ((0, lp.band_w, 1), (1, lp.band_w, 50), (2, 0, 100)):
+            got = h.dp_batch(jobs, kind + 4, w, h0)
+            assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (kind, w, h0)
+    finally:
+        h.close()
+
+
+def test_hip_lane_kinds_refuse_what_their_buffers_cannot_hold(handles):
+    rng = np.random.default_rng(3)
+    long_q = rng.integers(0, 4, 200, dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="beyond the lane routines"):
+        handles["ont2d"].dp_batch([(long_q, long_q[:100])], 5, 100, 50)
+    with pytest.raises(RuntimeError, match="mixes job classes"):
+        handles["ont2d"].dp_batch([(long_q[:50], long_q[:60]), (long_q[:50], long_q[:60])], np.array([4, 1], np.int32), 100, 50)
