@@ -58,6 +58,7 @@ HP_NOINL void regs_remain(ReadCtx &r, Regs &G, int min_thd, int max_thd)
         if (i < G.n) { gs = i; g_beg = G.beg[i]; g_end = G.end[i]; }
     }
     if (r.L - prev_end > min_thd && r.L - prev_end <= max_thd) {
+        HP_STAT(10);
         const int m = G.m++; G.r_beg[m] = prev_end + 1; G.r_end[m] = r.L; G.r_bs[m] = prev_gs; G.r_bn[m] = prev_ge - prev_gs; G.r_es[m] = 0; G.r_en[m] = 0;
     }
 }

@@ -1430,7 +1430,7 @@ struct Trig { int32_t *n1, *n2, *off, *cnt; int cap, used; };   // inter-trigger
 HP_FN void dump_edge_cluster(LSet &L, int ls, int len, const int32_t *mf_row, int mfn_row)
 {   // :289-297 / :306-314
     for (int i = 1; i < mfn_row; ++i) {
-        L.mf[mf_row[i]] = L_DUMP;
+        L.mf[mf_row[i]] = L_DUMP; HP_STAT(15);
         for (int _j = ls; _j < ls + len; ++_j) {
             const int j = L.rank[_j];
             if (!(L.mf[j] & L_NMERG) && !(L.mf[j] & L_MERGH) && !(L.mf[j] & L_DUMP) && L.mh[j] == mf_row[i]) L.mf[j] = L_DUMP;
@@ -1492,7 +1492,7 @@ HP_NOINL void line_filter(ReadCtx &r, LSet &L, int ls, int len, Trig *trg, int p
                             const int st = r.h_strand[s];
                             if (st == r.h_strand[n1] || r.h_chr[s] != r.h_chr[n1] ||
                                 st * r.h_pos[s] < st * r.h_pos[n2] || st * r.h_pos[e] > st * r.h_pos[n1]) continue;
-                            L.mf[l] = L_INTER;
+                            L.mf[l] = L_INTER; HP_STAT(14);
                             if (head == -1) { L.mf[l] |= L_NMERG; head = l; }
                             else { L.mf[l] |= L_MERGB; L.mh[l] = head; L.mf[head] = L_INTER | L_MERGH; }
                         }

@@ -494,7 +494,7 @@ HP_INL void phase_filldp_strip(const PhaseArgs &a, int round, int bucket, int of
                     else { c[n] = tail; ++n; }
                 }
                 HP_STAT(9);
-            } else HP_STAT(10);
+            }
         }
         nw[l] = n;
     }

@@ -45,9 +45,11 @@ HP_FN int hnode_dis(const HCtx &c, int a_i, int a_offset, int b_i, int b_offset)
     if (dis <= -(c.P->split_len / 2)) {
         if (ref_offset > 0) {
             if (b_i > a_i) return (read_len - ref_len + b_offset >= -(a_i + hash_len - 1) && read_len - a_offset >= b_i) ? F_INSERT : F_UNCONNECT;
+            HP_STAT(11);
             return (read_len - ref_len + a_offset >= -(b_i + hash_len - 1) && read_len - b_offset >= a_i) ? F_INSERT : F_UNCONNECT;
         }
         if (b_i > a_i) return (b_offset >= -(a_i - 1) && ref_len - a_offset >= b_i) ? F_INSERT : F_UNCONNECT;
+        HP_STAT(12);
         return (a_offset >= -(b_i - 1) && ref_len - b_offset >= a_i) ? F_INSERT : F_UNCONNECT;
     }
     return F_UNCONNECT;
@@ -149,7 +151,7 @@ HP_FN int hmain_line(Ctx &cx, HCtx &c, int hash_seed_n, int32_t *line)
     }
     for (int i = 2; i <= hash_seed_n; ++i)
         for (int k = c.nstart[i], e = c.nstart[i] + c.len_a[i]; k < e; ++k)
-            if (c.h_dp[k] == MULTI_FLAG) hdp_update(c, k, 1, MULTI_FLAG);
+            if (c.h_dp[k] == MULTI_FLAG) { HP_STAT(13); hdp_update(c, k, 1, MULTI_FLAG); }
     hdp_update(c, tail, 1, MULTI_FLAG);
     node_i = c.h_node_n[tail] - 1;
     int cur = c.h_from[tail];

@@ -166,6 +166,20 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     return 0;
 }
 
+// ---------------------------------------------------------------- the k-mer split mapper (hp_split.h) on one read gap / reference window
+extern "C" int emu_split_indel_map(const lamsa_hp_para *P, const uint8_t *read, int read_len, const uint8_t *ref, int ref_len, int ref_offset,
+                                   int32_t *cig, int cig_cap, int32_t *ret, int32_t *status)
+{
+    std::vector<char> slab((size_t)64 << 20);
+    static thread_local int32_t lds[HP_BOTH_LDS_WORDS];
+    Ctx cx; cx.P = P; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr; cx.lds = lds; cx.lds_words = HP_LDS_WORDS;
+    arena_init(cx.tmp, slab.data(), slab.size());
+    CigV out; cig_bind(out, cig, cig_cap);
+    *ret = split_indel_map(cx, out, read, read_len, ref, ref_len, ref_offset);
+    *status = cx.status;
+    return out.n;
+}
+
 // ---------------------------------------------------------------- the four-jobs-per-wave extension (hp_stripdp.h) on explicit jobs:
 // ksw_extend_core(w = max(|qlen - tlen| + 3, band_w), h0) with traceback; targets packed 2 bits per base as the kernel reads them
 extern "C" int emu_strip_extend(const lamsa_hp_para *P, int n, const uint8_t *seq, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,

@@ -370,6 +370,36 @@ def emu_lane_dp(jobs, hp_para, kind, w, h0):
     return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
 
 
+def split_indel_map_three_ways(read, refw, ref_offset, lp, rp, hp_para, ref_start=0, ref_len=None):
+    """split_indel_map (src/split_mapping.c:829) on one read gap and reference window: (oracle, reference or None, emulated device code),
+    each as (return value, CIGAR words).  The window is refw[ref_start : ref_start + ref_len] (default: all of refw); the DUP branch of
+    split_mapping hands over a window with hash_len - dis fetched bases on either side of it (src/frag_check.c:529-545)."""
+    L = oracle(); E = emu()
+    _r, rptr = u8(read); _t, tbase = u8(refw)
+    full = refw
+    refw = full[ref_start:ref_start + (len(full) - ref_start if ref_len is None else ref_len)]
+    tptr = C.c_void_p(C.cast(tbase, C.c_void_p).value + int(ref_start))
+    v = LoCigv(); L.lo_cigv_init(C.byref(v))
+    L.lo_split_indel_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    o_ret = L.lo_split_indel_map(C.byref(v), rptr, len(read), tptr, len(refw), int(ref_offset), C.byref(lp))
+    o = (int(o_ret), cig_list(v)); L.lo_cigv_free(C.byref(v))
+    r = None
+    if rp is not None:
+        Rf = ref(); libc = C.CDLL(None)
+        libc.calloc.restype = C.c_void_p; libc.calloc.argtypes = [C.c_size_t, C.c_size_t]
+        hash_num = C.c_void_p(libc.calloc(rp.hash_size, 4)); hash_node = C.c_void_p(libc.calloc(rp.hash_size, 8))
+        cg = C.POINTER(C.c_int32)(); nc, mc = C.c_int(0), C.c_int(0)
+        Rf.split_indel_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        rr = Rf.split_indel_map(C.byref(cg), C.byref(nc), C.byref(mc), rptr, len(read), tptr, len(refw), int(ref_offset), C.byref(rp), C.byref(hash_num), C.byref(hash_node))
+        r = (int(rr), [int(cg[k]) for k in range(nc.value)])
+    cap = 2 * (len(read) + len(refw)) + 64
+    cig = np.zeros(cap, np.int32); ret = C.c_int32(0); st = C.c_int32(0)
+    E.emu_split_indel_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    n = E.emu_split_indel_map(C.byref(hp_para), rptr, len(read), tptr, len(refw), int(ref_offset), cig.ctypes.data, cap, C.byref(ret), C.byref(st))
+    e = (int(ret.value), cig[:n].tolist(), int(st.value))
+    return o, r, e
+
+
 def emu_strip_extend(jobs, hp_para, h0):
     """ksw_extend_core(max(|qlen - tlen| + 3, band_w), h0) through the four-jobs-per-wave routine of hp_stripdp.h, CPU lane emulation."""
     from lamsa_amd.hp import pack_jobs

@@ -207,3 +207,73 @@ def test_no_caller_local_is_handed_by_address_to_a_non_inlined_device_routine(tm
     t = noinl_guard.strip_comments(src)
     assert "callee" in noinl_guard.noinl_names({"x": t})
     assert "lo" in noinl_guard.local_scalars_before(t, t.index("callee(r, &lo)"))
+
+
+def _split_cases(rng, hash_len):
+    """(read gap, fetched reference bases, window start, window length, ref_offset) as split_mapping hands them to split_indel_map
+    (src/frag_check.c:475-545): deletions (window = the fetched bases), duplications (a window inside hash_len - dis more bases on either
+    side, ref_offset = -dis), and gaps over tandem repeats and two-copy repeats, where no k-mer of the gap is unique in the window."""
+    def mut(s, p):
+        out = []
+        for c in s:
+            x = rng.random()
+            if x < p:
+                out.append((int(c) + 1 + int(rng.integers(0, 3))) % 4)
+            elif x < 2 * p:
+                out += [int(c), int(rng.integers(0, 4))]
+            elif x >= 3 * p:
+                out.append(int(c))
+        return np.array(out, np.uint8)
+    for it in range(400):
+        kind = it % 5
+        if kind == 0:      # deletion
+            refw = rng.integers(0, 4, int(rng.integers(200, 3000)), dtype=np.uint8)
+            a = int(rng.integers(20, len(refw) // 2)); b = int(rng.integers(len(refw) // 2, len(refw) - 20))
+            yield mut(np.concatenate([refw[:a], refw[b:]]), 0.01), refw, 0, len(refw), 0
+        elif kind == 1:    # a tandem repeat all over: every k-mer of the gap occurs many times
+            unit = rng.integers(0, 4, int(rng.integers(2, 7)), dtype=np.uint8)
+            refw = np.tile(unit, 120)[:int(rng.integers(150, 500))]
+            yield np.tile(unit, 120)[:int(rng.integers(60, len(refw)))], refw, 0, len(refw), 0
+        elif kind == 2:    # duplication in the read: the window of the DUP branch
+            g = rng.integers(0, 4, 4000, dtype=np.uint8)
+            s_tlen = int(rng.integers(2 * 10 + 1, 600)); dup = int(rng.integers(15, 500)); dis = -dup
+            gs = 1500; a = int(rng.integers(0, s_tlen)); w = min(dup, s_tlen - a) if s_tlen - a > 0 else 0
+            gap = g[gs:gs + s_tlen]
+            read = mut(np.concatenate([gap[:a + w], g[gs + a + w - dup:gs + a + w], gap[a + w:]]), 0.01)
+            margin = hash_len - dis
+            tb = g[gs - margin:gs + s_tlen + margin].copy()
+            yield read, tb, margin, s_tlen, (-dis if rng.random() < 0.8 else 0)
+        elif kind == 3:    # two copies of a block around the deleted stretch
+            blk = rng.integers(0, 4, 60, dtype=np.uint8)
+            refw = np.concatenate([rng.integers(0, 4, 80, dtype=np.uint8), blk, rng.integers(0, 4, int(rng.integers(50, 400)), dtype=np.uint8), blk, rng.integers(0, 4, 80, dtype=np.uint8)])
+            yield mut(np.concatenate([refw[:100], refw[-100:]]), 0.01), refw, 0, len(refw), 0
+        else:              # microsatellites on both flanks
+            unit = rng.integers(0, 4, 3, dtype=np.uint8)
+            refw = np.concatenate([np.tile(unit, 40), rng.integers(0, 4, int(rng.integers(30, 300)), dtype=np.uint8), np.tile(unit, 40)])
+            yield mut(np.concatenate([np.tile(unit, 30), np.tile(unit, 30)]), 0.01), refw, 0, len(refw), 0
+
+
+@pytest.mark.parametrize("preset", ["default", "ont2d"])
+def test_kmer_split_mapper_three_ways(preset):
+    """split_indel_map (src/split_mapping.c:829: k-mer index of the window, bucket matching, hash DP, indel CIGAR) on crafted gaps: the
+    device code under the lane emulation == the oracle == the REFERENCE itself (oracle/_ref, when built).  The gaps without a unique
+    k-mer run the MULTI pass of the hash DP (hp_split.h hmain_line, src/split_mapping.c:570-581), which no read of the corpus reaches."""
+    from lamsa_amd.hp import HpPara
+    import ctypes
+    lp = reflib.lo_para(preset)
+    rp = reflib.ref_para(preset) if reflib.ref() is not None else None
+    P = HpPara()
+    for n, _ in HpPara._fields_:
+        setattr(P, n, getattr(lp, n))
+    E = reflib.emu(); E.emu_stat_reset(); E.emu_stat.restype = ctypes.c_longlong
+    rng = np.random.default_rng(11)
+    n = 0
+    for read, tb, start, ref_len, off in _split_cases(rng, lp.hash_len):
+        if len(read) < lp.hash_len + 2 or ref_len < lp.hash_len + 2:
+            continue
+        o, r, e = reflib.split_indel_map_three_ways(read, tb, off, lp, rp, P, ref_start=start, ref_len=ref_len)
+        assert e[2] == 0 and (e[0], e[1]) == o, ("emulation vs oracle", n, len(read), ref_len, off)
+        if r is not None:
+            assert r == o, ("oracle vs reference", n, len(read), ref_len, off)
+        n += 1
+    assert n > 300 and E.emu_stat(13) > 0

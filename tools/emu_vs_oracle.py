@@ -24,7 +24,7 @@ def main():
         want = reflib.oracle_streams(B, reflib.lo_para(rt, **over), 8)
         same = sum(1 for i in range(n) if list(want[i]) == list(s[i]))
         bad += n - same
-        print("%-8s emulated kernels == oracle on %d / %d reads; path counters %s" % (prof, same, n, stats[:11]))
+        print("%-8s emulated kernels == oracle on %d / %d reads; path counters %s" % (prof, same, n, stats[:16]))
     return 1 if bad else 0
 
 

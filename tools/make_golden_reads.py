@@ -32,7 +32,42 @@ SCEN = [  # name, args, n_reads, length, profile, extra
     # stage 4 (BWT rescue): reads carrying 40-320 bp pieces of other loci between their flanks; default -R
     ("c7_rescue", [], 100, 4000, "lowerr", {"rescue": True}),
     ("c8_rescue_ont", ["-T", "ont2d"], 100, 6000, "ont", {"rescue": True}),
+    # rearranged reads: an inversion, a tandem duplication or a foreign tail each (the inter-line, DUP and tail-region branches of the path)
+    ("c9_rearr", [], 120, 6000, "lowerr", {"rearr": True}),
+    ("c10_rearr_ont", ["-T", "ont2d"], 80, 6000, "ont", {"rearr": True}),
 ]
+
+
+def rearranged_reads(rng, contigs, n, length, sub, ins, dele, copies=()):
+    """Reads of contig 0, one rearrangement each: the middle 300-900 bases inverted; 100-1500 bases at the middle duplicated in tandem;
+    the last 100-600 bases replaced by random sequence; or 150-360 bases of the other contig at one end.  Independent errors; half of the reads reverse-complemented."""
+    reads = []
+    for k in range(n):
+        p = int(rng.integers(10000, 220000)); base = contigs[0][p:p + length].copy()
+        kind = ("inv", "dup", "tail", "ftail")[k % 4]
+        mid = length // 2 + int(rng.integers(-800, 800))
+        if kind == "inv":
+            w = int(rng.integers(300, 900)); base[mid:mid + w] = simdata.COMP[base[mid:mid + w][::-1]]
+        elif kind == "dup":
+            w = int(rng.integers(100, 1500)); base = np.concatenate([base[:mid + w], base[mid:mid + w], base[mid + w:]])[:length + w]
+        elif kind == "tail":
+            w = int(rng.integers(100, 600)); base[length - w:] = rng.integers(0, 4, w, dtype=np.uint8)
+        else:              # two or three seeds' worth of another locus at one end: a tiny line of its own at the edge of the read
+            w = int(rng.integers(150, 360)); q = int(rng.integers(5000, 120000)); piece = contigs[1][q:q + w]
+            kb = [c for c in copies if c[0] == 1000]
+            if k % 16 >= 8 and kb:          # ... out of a planted 1-kbp repeat: several tiny lines over the same read bases, one per copy
+                w = int(rng.integers(160, 245))                                        # (two seeds' worth in the 100-bp-step mode)
+                _, ci, off = kb[int(rng.integers(0, len(kb)))]
+                o2 = int(rng.integers(0, 1000 - w)); piece = contigs[ci][off + o2:off + o2 + w]
+            if k % 8 < 4:
+                base[length - w:] = piece
+            else:
+                base[:w] = piece
+        r = simdata.mutate(rng, base, sub, ins, dele)
+        if rng.random() < 0.5:
+            r = simdata.COMP[r[::-1]]
+        reads.append(("%s_%d_w%d" % (kind, k, w), np.ascontiguousarray(r, dtype=np.uint8)))
+    return reads
 
 
 def rescue_reads(rng, contigs, n, length, sub, ins, dele):
@@ -74,7 +109,8 @@ def run(cmd, **kw):
 def make_reads(only=None):
     """only: names of the scenarios to (re)generate; default all."""
     rng = np.random.default_rng(REF["seed"])
-    contigs = simdata.make_reference(rng, REF["contigs"], REF["repeats"])
+    copies = []
+    contigs = simdata.make_reference(rng, REF["contigs"], REF["repeats"], copies=copies)
     tmp = tempfile.mkdtemp(prefix="lamsa_gold_")
     ref = os.path.join(tmp, "ref.fa")
     simdata.write_fasta(ref, [("chr%d" % (i + 1), c) for i, c in enumerate(contigs)])
@@ -88,6 +124,8 @@ def make_reads(only=None):
         sub, ins, dele = simdata.PROFILES[prof]
         if extra.get("rescue"):
             reads = rescue_reads(rng, contigs, n, length, sub, ins, dele)
+        elif extra.get("rearr"):
+            reads = rearranged_reads(rng, contigs, n, length, sub, ins, dele, copies)
         else:
             reads = simdata.simulate_reads(rng, contigs, n, length, sub, ins, dele, extra.get("sv_frac", 0.0), n_frac=extra.get("n_frac", 0.0))
         if extra.get("edge"):

@@ -18,10 +18,10 @@ ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 
 
-def make_reference(rng, contig_lens, repeats=(), div=0.05):
+def make_reference(rng, contig_lens, repeats=(), div=0.05, copies=None):
     """Return list of uint8 arrays (values 0..3), one per contig.
 
-    repeats: iterable of (unit_len, n_copies)."""
+    repeats: iterable of (unit_len, n_copies).  copies: a list that receives (unit_len, contig, offset) of every planted copy."""
     contigs = [rng.integers(0, 4, size=n, dtype=np.uint8) for n in contig_lens]
     total = sum(contig_lens)
     bounds = np.cumsum([0] + list(contig_lens))
@@ -41,6 +41,8 @@ def make_reference(rng, contig_lens, repeats=(), div=0.05):
             if rng.random() < 0.5:
                 cp = COMP[cp[::-1]]
             contigs[ci][off:off + unit_len] = cp
+            if copies is not None:
+                copies.append((unit_len, ci, int(off)))
     return contigs
 
 
