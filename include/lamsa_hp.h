@@ -32,6 +32,8 @@ extern "C" {
 /* per-read / per-job status bits (out arrays) */
 #define LAMSA_HP_ST_OVERFLOW   1  /* a device work buffer was too small; result invalid   */
 #define LAMSA_HP_ST_REFEXIT    2  /* input on which the reference itself exit(1)s         */
+#define LAMSA_HP_ST_UNSUPPORTED 4 /* the read is beyond what the device keeps (more than 32767 seeds, or a seed hit with
+                                     |len_dif| > 127): not aligned, empty result; the rest of the batch is unaffected */
 
 /* Alignment parameters after presets: the fields of the reference's lamsa_aln_para
  * (src/lamsa_aln.h:386-436) read on the hot path.  Fill with lamsa_hp_para_init() +

@@ -195,6 +195,8 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof);
     Ctx &cx = r.cx;
+    const bool skip = a.in.read_skip && a.in.read_skip[rd];        // refused by the batch check: an empty result with ST_UNSUPPORTED
+    if (skip) { cx.status |= ST_UNSUPPORTED; r.H = 0; r.seed_out = 0; }
     const int H = r.H;
     // read-lifetime allocations
     const int out_cap = 64 + 12 * r.L * a.scale;
@@ -213,7 +215,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     int n0_pos = 1, n1_pos = 2;
     const size_t sort_mark = arena_mark(cx.tmp);
     uint64_t *sort_work = (uint64_t *)arena_alloc(cx, sizeof(uint64_t) * (size_t)(H + 1));      // released once the index is built
-    if (o.w && r.rc_read && nm && sidx && sort_work && r.nd && G.beg && G.rb && G.r_beg) {
+    if (!skip && o.w && r.rc_read && nm && sidx && sort_work && r.nd && G.beg && G.rb && G.r_beg) {
         const int c = H + 1;
         { HP_T0(t_sort_);
         sort_read_hits(r.h_pos, r.h_chr, r.h_strand, H, sidx, sidx + c, sort_work, (HP_L uint64_t *)lds, HP_BOTH_LDS_WORDS / 2, a.sort_pb, a.sort_cb);
@@ -235,7 +237,7 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
             arena_release(cx.tmp, mark);
         }
         // round 2: frag_line_remain + frag_check          (lamsa_aln.c:867-871)
-        if (!(cx.status & (ST_REFEXIT | ST_OVERFLOW))) {
+        if (!(cx.status & ST_DEAD)) {
             const size_t mark = arena_mark(cx.tmp);
             regs_remain(r, G, a.P.seed_len, r.L);
             FLines F;
@@ -248,13 +250,13 @@ HP_NOINL void align_read(const AlignArgs &a, int rd, int wave_slot, HP_L int32_t
     }
     // publish: reserve the exact size in the global arena, copy with all lanes
     const int st = cx.status;
-    int n_words = (st & (ST_REFEXIT | ST_OVERFLOW)) || !o.w ? 3 : o.n;
+    int n_words = (st & ST_DEAD) || !o.w ? 3 : o.n;
     unsigned long long off = 0;
     if (wv::leader()) off = atomicAdd(a.out.cursor, (unsigned long long)n_words);
     off = (unsigned long long)wv::uni64((long long)off);
     if ((int64_t)(off + (unsigned long long)n_words) <= a.out.stream_cap) {
         int32_t *dst = a.out.stream + off;
-        if (n_words == 3 && (!o.w || (st & (ST_REFEXIT | ST_OVERFLOW)))) { dst[0] = st; dst[1] = 0; dst[2] = 0; }
+        if (n_words == 3 && (!o.w || (st & ST_DEAD))) { dst[0] = st; dst[1] = 0; dst[2] = 0; }
         else {
             o.w[0] = st;
             wv::sync();

@@ -271,6 +271,7 @@ struct OutDev {
 
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
     DevBuf bin, misc, slab, pers, prof; OutDev out1;
+    HostBuf args_host;            // page-locked copy of the launch sequence's argument block: the asynchronous copy to the device reads it after launch_phased has returned
     hipEvent_t ep[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass (ep[4]: after the lane DP of round 1)
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
@@ -278,7 +279,7 @@ struct Slot {                     // one batch on the device: its inputs, the ou
     bool phased = false;          // the launch in flight on this slot's resources is the phased main pass
     int32_t n_reads = 0; int64_t n_bases = 0, n_cig = 0, n_hits = 0;
     BatchIn in; const int32_t *d_order = nullptr;
-    std::vector<int32_t> order, h_len, h_H;
+    std::vector<int32_t> order, h_len, h_H; std::vector<uint8_t> h_skip;      // h_skip: reads the batch check found beyond the device's field widths
     int32_t max_L = 0, max_H = 0;
     int32_t sort_pb = 40, sort_cb = 24;        // key field widths for the in-kernel sort of the hits (hp_sort.h)
     hipEvent_t e0 = nullptr, e1 = nullptr;     // around the main-pass kernel, on the compute stream
@@ -316,7 +317,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3], T.ep[4]}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.prof.release(); T.args_host.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3], T.ep[4]}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
 }
@@ -346,7 +347,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     const int n = B->n_reads;
     const int64_t n_slots = n ? B->seed_off[n] : 0, n_hits = n_slots ? B->hit_off[n_slots] : 0, n_bases = n ? B->read_off[n] : 0;
     // ---- validate everything the kernels index with, on the host, before anything is launched
-    S->h_len.assign((size_t)n, 0); S->h_H.assign((size_t)n, 0); S->max_L = 0; S->max_H = 0;
+    S->h_len.assign((size_t)n, 0); S->h_H.assign((size_t)n, 0); S->h_skip.assign((size_t)n + 1, 0); S->max_L = 0; S->max_H = 0;
     if (n && (B->seed_off[0] != 0 || B->read_off[0] != 0 || (n_slots && B->hit_off[0] != 0))) { h->err = "offsets must start at 0"; return LAMSA_HP_EINVAL; }
     const bool packed_off = B->h_cig_off == nullptr, cig_bytes = B->cig8 != nullptr;
     if (B->n_cig < 0 || (!packed_off && B->n_cig > 0x7fffffffll)) { h->err = "more than 2^31-1 seed CIGAR elements with 32-bit h_cig_off: pass h_cig_off = NULL (CIGARs back to back in hit order) or split the batch"; return LAMSA_HP_EINVAL; }
@@ -359,11 +360,12 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
             long long mp = 0, sc = 0;
             for (int r = r0; r < r1 && !bad.load(std::memory_order_relaxed); ++r) {
                 const int64_t L = B->read_off[r + 1] - B->read_off[r], ns = B->seed_off[r + 1] - B->seed_off[r];
-                if (L < 0 || L > (1 << 24) || ns < 0 || ns > HP_MAX_SLOTS) { bad = 1; return; }
+                if (L < 0 || L > (1 << 24) || ns < 0) { bad = 1; return; }
+                if (ns > HP_MAX_SLOTS) S->h_skip[r] = 1;                   // more seed slots than the packed keys hold: the read is not aligned (ST_UNSUPPORTED)
                 {   // the seed geometry the kernels derive read windows from (lamsa_aln.c:251-253,281) must be the read's own
                     const int64_t sa = L < sl ? 0 : 1 + (L - sl) / ss;
                     if (B->seed_all[r] != sa || B->last_len[r] != L - sl - (sa - 1) * ss) { bad = 7; return; }
-                    if (sa > 32767) { bad = 8; return; }                   // seed ids are kept in 16 bits on the device (NodeS::sid)
+                    if (sa > 32767) S->h_skip[r] = 1;                      // seed ids are kept in 16 bits on the device (NodeS::sid): the read is not aligned (ST_UNSUPPORTED)
                 }
                 int64_t H = 0;
                 for (int64_t s = B->seed_off[r]; s < B->seed_off[r + 1]; ++s) {
@@ -376,7 +378,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                 for (int64_t i = B->read_off[r]; i < B->read_off[r + 1]; ++i) if (B->read_seq[i] > 4) { bad = 5; return; }
                 for (int64_t k = B->hit_off[B->seed_off[r]]; k < B->hit_off[B->seed_off[r + 1]]; ++k) {
                     mp = B->h_pos[k] > mp ? B->h_pos[k] : mp;
-                    if (B->h_len_dif[k] < -127 || B->h_len_dif[k] > 127) { bad = 9; return; }     // kept in 8 bits on the device (NodeS::len_dif8)
+                    if (B->h_len_dif[k] < -127 || B->h_len_dif[k] > 127) S->h_skip[r] = 1;        // kept in 8 bits on the device (NodeS::len_dif8): the read is not aligned
                     if (B->h_chr[k] < 1 || B->h_chr[k] > h->n_seqs || (B->h_strand[k] != 1 && B->h_strand[k] != -1) || B->h_pos[k] < 0 || B->h_pos[k] >= (1ll << 40) ||
                         (!packed_off && (B->h_cig_off[k] < 0 || (int64_t)B->h_cig_off[k] + B->h_cig_n[k] > B->n_cig))) { bad = 6; return; }
                     sc += B->h_cig_n[k];
@@ -387,7 +389,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
             while (mp > seen && !max_pos.compare_exchange_weak(seen, mp)) { }
             sum_cig += sc;
         });
-        static const char *why[] = {"", "read longer than 2^24 bases or more than 16383 seeds with hits", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
+        static const char *why[] = {"", "read longer than 2^24 bases", "too many hits in one seed", "seed ids must be ascending in [1, seed_all]",
                                     "too many hits in one read", "read base code > 4",
                                     "bad hit record (contig id, strand, position or seed CIGAR range)",
                                     "seed_all / last_len do not match the read length and the handle's seed length and step",
@@ -395,7 +397,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                                     "a hit's len_dif is outside [-127, 127]"};
         if (bad) { h->err = why[bad.load()]; return LAMSA_HP_EINVAL; }
         if (packed_off && sum_cig.load() != B->n_cig) { h->err = "h_cig_off is NULL but the h_cig_n do not add up to n_cig"; return LAMSA_HP_EINVAL; }
-        for (int r = 0; r < n; ++r) { S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
+        for (int r = 0; r < n; ++r) { if (S->h_skip[r]) { S->h_len[r] = 0; S->h_H[r] = 0; } S->max_L = std::max(S->max_L, S->h_len[r]); S->max_H = std::max(S->max_H, S->h_H[r]); }
         auto bits = [](unsigned long long x) { int b = 0; while (x) { ++b; x >>= 1; } return b; };
         S->sort_pb = bits((unsigned long long)max_pos.load()); S->sort_cb = bits((unsigned long long)(2 * (long long)h->n_seqs + 1));
     }
@@ -415,7 +417,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
                  o_soff = place(8 * ((size_t)n + 1)), o_sid = place(4 * (size_t)n_slots), o_hoff = place(8 * ((size_t)n_slots + 1)),
                  o_pos = place(8 * (size_t)n_hits), o_chr = place(4 * (size_t)n_hits), o_coff = place(8 * (size_t)n_hits), o_nm = place(2 * (size_t)n_hits),
                  o_ld = place(2 * (size_t)n_hits), o_st = place((size_t)n_hits), o_cn = place((size_t)n_hits), o_cig = place(4 * (size_t)B->n_cig), o_ord = place(4 * (size_t)n),
-                 o_stage = place(packed_off ? 8 * ((size_t)n_hits / HP_SCAN_BLOCK + 2) : 4 * (size_t)n_hits), o_cig8 = place(cig_bytes ? (size_t)B->n_cig : 0);
+                 o_stage = place(packed_off ? 8 * ((size_t)n_hits / HP_SCAN_BLOCK + 2) : 4 * (size_t)n_hits), o_cig8 = place(cig_bytes ? (size_t)B->n_cig : 0), o_skip = place((size_t)n);
     const double t_3 = now_s();
     if (S->bin.ensure(off)) { h->err = "hipMalloc(batch)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)S->bin.p;
@@ -431,7 +433,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     if (!packed_off) UP(o_stage, B->h_cig_off, 4 * (size_t)n_hits);
     UP(o_nm, B->h_nm, 2 * (size_t)n_hits); UP(o_ld, B->h_len_dif, 2 * (size_t)n_hits); UP(o_st, B->h_strand, (size_t)n_hits); UP(o_cn, B->h_cig_n, (size_t)n_hits);
     if (cig_bytes) UP(o_cig8, B->cig8, (size_t)B->n_cig); else UP(o_cig, B->cig, 4 * (size_t)B->n_cig);
-    UP(o_ord, S->order.data(), 4 * (size_t)n);
+    UP(o_ord, S->order.data(), 4 * (size_t)n); UP(o_skip, S->h_skip.data(), (size_t)n);
 #undef UP
     // on the device: CIGAR bytes -> words, offsets widened or summed up from the lengths (same stream, behind the copies)
     if (cig_bytes && B->n_cig > 0) hipLaunchKernelGGL(k_cig8_expand, dim3(2048), dim3(256), 0, s, (const uint8_t *)(d + o_cig8), (int32_t *)(d + o_cig), (int64_t)B->n_cig);
@@ -448,7 +450,7 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
     HIPCHK(h, hipStreamSynchronize(s), LAMSA_HP_EKERNEL);
     if (g_trace) fprintf(stderr, "[lamsa_hp] upload: validate %.1f ms, order %.1f ms, copy %.1f ms (%.2f GB on the device)\n", 1e3 * (t_1 - t_0), 1e3 * (t_3 - t_1), 1e3 * (now_s() - t_3), off / 1e9);
     BatchIn &in = S->in;
-    in.n_reads = n; in.read_off = (const int64_t *)(d + o_roff); in.read_seq = (const uint8_t *)(d + o_rseq);
+    in.n_reads = n; in.read_skip = (const uint8_t *)(d + o_skip); in.read_off = (const int64_t *)(d + o_roff); in.read_seq = (const uint8_t *)(d + o_rseq);
     in.seed_all = (const int32_t *)(d + o_sall); in.last_len = (const int32_t *)(d + o_last); in.seed_off = (const int64_t *)(d + o_soff);
     in.seed_id = (const int32_t *)(d + o_sid); in.hit_off = (const int64_t *)(d + o_hoff); in.h_pos = (const int64_t *)(d + o_pos);
     in.h_chr = (const int32_t *)(d + o_chr); in.h_cig_off = (const int64_t *)(d + o_coff); in.h_nm = (const int16_t *)(d + o_nm);
@@ -466,7 +468,9 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 // waves instead of the fill kernel's 8 192).
 static int cap_waves(int n_waves, size_t slab_per_wave, int n_cu)
 {
-    const size_t budget = (size_t)72 << 30;
+    // a quarter of the device's memory per batch in flight (72 GB of an MI355X's 288 GB), from the device itself
+    static const size_t total = []() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess && t > 0 ? t : (size_t)288 << 30; }();
+    const size_t budget = total / 4;
     if (slab_per_wave * (size_t)n_waves <= budget) return n_waves;
     size_t fit = budget / (slab_per_wave ? slab_per_wave : 1);
     if (n_cu > 0 && fit >= (size_t)n_cu) fit -= fit % (size_t)n_cu;
@@ -584,7 +588,9 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     hipStream_t s = Ln.cs;
     HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemsetAsync(d + o_ctl, 0, (o_meta - o_ctl) + sizeof(RdMeta) * ((size_t)n + 1), s), LAMSA_HP_EKERNEL);      // counters + per-read state
-    HIPCHK(h, hipMemcpyAsync(d + o_args, &a, sizeof a, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);         // pageable source: staged before the call returns
+    if (Ln.args_host.ensure(sizeof a)) { h->err = "hipHostMalloc(args)"; return LAMSA_HP_ENOMEM; }
+    memcpy(Ln.args_host.p, &a, sizeof a);                   // the slot's launch resources are not reused before this launch has been collected
+    HIPCHK(h, hipMemcpyAsync(d + o_args, Ln.args_host.p, sizeof a, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
     const PhaseArgs *da = (const PhaseArgs *)(d + o_args);
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
@@ -878,7 +884,10 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     for (Slot &T : S->slot) {
         int rc = slot_events(h, T);
         if (rc) return rc;
-        if (T.slab.ensure(slab_per_wave * (size_t)n_waves) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) { h->err = "hipMalloc(reserve)"; return LAMSA_HP_ENOMEM; }
+        if (T.slab.ensure(slab_per_wave * (size_t)n_waves) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) {
+            for (Slot &U : S->slot) { U.slab.release(); U.pers.release(); U.bin.release(); U.out1.release(); }       // nothing half reserved stays behind: the first batch sizes its own buffers
+            h->err = "hipMalloc(reserve)"; return LAMSA_HP_ENOMEM;
+        }
     }
     return LAMSA_HP_OK;
 }

@@ -19,6 +19,7 @@ struct RefView {                 // packed reference resident in HBM
 
 struct BatchIn {
     int32_t n_reads;
+    const uint8_t *read_skip;    // [n_reads] or nullptr: 1 = the batch check found the read beyond the device's field widths (ST_UNSUPPORTED)
     const int64_t *read_off;     // [n_reads+1] into read_seq
     const uint8_t *read_seq;     // 1 byte/base, codes 0..4
     const int32_t *seed_all;     // [n_reads]  1+(L-seed_len)/seed_step (src/lamsa_aln.c:252-253)

@@ -9,7 +9,8 @@ namespace hp {
 
 typedef int32_t cig_t;                       // len<<4|op, signed like the reference (src/lamsa_aln.h:210)
 enum { C_M = 0, C_I = 1, C_D = 2, C_N = 3, C_S = 4, C_H = 5 };
-enum { ST_OVERFLOW = LAMSA_HP_ST_OVERFLOW, ST_REFEXIT = LAMSA_HP_ST_REFEXIT };
+enum { ST_OVERFLOW = LAMSA_HP_ST_OVERFLOW, ST_REFEXIT = LAMSA_HP_ST_REFEXIT, ST_UNSUPPORTED = LAMSA_HP_ST_UNSUPPORTED,
+       ST_DEAD = ST_OVERFLOW | ST_REFEXIT | ST_UNSUPPORTED };     // ST_DEAD: the read has no result
 
 #define HP_NEG_INF (-0x40000000)             // MINUS_INF, src/ksw.c:504
 

@@ -150,6 +150,7 @@ HP_NOINL void phase_chain1(const PhaseArgs &a, int rd, int wave_slot, HP_L int32
 #ifdef HP_PROF
     long long ph_t_ = wv::clock();
 #endif
+    if (a.in.read_skip && a.in.read_skip[rd]) { if (wv::leader()) atomicOr(&a.meta[rd].status, ST_UNSUPPORTED); return; }       // refused by the batch check: no result
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, lds_words);
     pers_bind(r, a, rd);
@@ -187,7 +188,7 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
     UnitRec &U = a.units[(size_t)round * a.unit_cap + u];
     const int rd = U.read, line = U.line;
     RdMeta &M = a.meta[rd];
-    if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;       // the read is lost already (another line or phase failed)
+    if (*(volatile int32_t *)&M.status & ST_DEAD) return;       // the read is lost already (another line or phase failed)
     PH_T0();
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, HP_LDS_WORDS);
@@ -284,7 +285,7 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
     UnitRec &U = a.units[(size_t)round * a.unit_cap + u];
     const int rd = U.read, line = U.line;
     RdMeta &M = a.meta[rd];
-    if (*(volatile int32_t *)&M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
+    if (*(volatile int32_t *)&M.status & ST_DEAD) return;
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, 0);
     pers_bind(r, a, rd);
@@ -531,7 +532,7 @@ HP_INL void phase_filldp_strip(const PhaseArgs &a, int round, int bucket, int of
 HP_NOINL void phase_chain2(const PhaseArgs &a, int rd, int wave_slot, HP_L int32_t *lds, int lds_words = HP_CHAIN_LDS_WORDS)
 {
     RdMeta &M = a.meta[rd];
-    if (M.status & (ST_REFEXIT | ST_OVERFLOW)) return;
+    if (M.status & ST_DEAD) return;
     PH_T0();
     ReadCtx r;
     read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, lds_words);
@@ -578,7 +579,7 @@ HP_NOINL void phase_publish(const PhaseArgs &a, int rd)
 {
     const RdMeta &M = a.meta[rd];
     const int st = M.status;
-    const bool dead = (st & (ST_REFEXIT | ST_OVERFLOW)) != 0;
+    const bool dead = (st & ST_DEAD) != 0;
     int n_words = 3;
     if (!dead)
         for (int round = 0; round < 2; ++round)

@@ -32,6 +32,7 @@
 #include <immintrin.h>
 #endif
 #include <fcntl.h>
+#include <signal.h>
 #include <sstream>
 #include <sys/wait.h>
 #include <sys/mman.h>
@@ -86,8 +87,37 @@ struct Prefault {
 struct FastxReader::Impl {
     gzFile f = nullptr; std::string line; bool have = false;
     const char *m = nullptr; size_t mn = 0, mpos = 0;       // an uncompressed regular file is mapped instead of read through zlib
+    size_t limit = (size_t)-1; size_t line_at = 0;           // restrict(): records that start at or beyond `limit` are not delivered; line_at: where the current line began
     Prefault pf;
 };
+bool FastxReader::mapped() const { return p->m != nullptr; }
+size_t FastxReader::size() const { return p->mn; }
+// is there a record header at offset `at` (which is the beginning of a line)?  '>' always; '@' only when the line after next begins
+// with '+' (a FASTQ quality line may begin with '@' too)
+static bool record_starts_at(const char *m, size_t n, size_t at)
+{
+    if (at >= n) return false;
+    if (m[at] == '>') return true;
+    if (m[at] != '@') return false;
+    const char *l1 = (const char *)memchr(m + at, '\n', n - at);
+    if (!l1) return false;
+    const char *l2 = (const char *)memchr(l1 + 1, '\n', (size_t)(m + n - (l1 + 1)));
+    return l2 && l2 + 1 < m + n && l2[1] == '+';
+}
+void FastxReader::restrict(size_t lo, size_t hi)
+{
+    if (!p->m) return;
+    size_t at = lo;
+    if (at > 0) {                                             // the first beginning of a line at or after lo ...
+        const char *nl = (const char *)memchr(p->m + at - 1, '\n', p->mn - (at - 1));
+        at = nl ? (size_t)(nl - p->m) + 1 : p->mn;
+    }
+    while (at < p->mn && !record_starts_at(p->m, p->mn, at)) {    // ... that begins a record
+        const char *nl = (const char *)memchr(p->m + at, '\n', p->mn - at);
+        at = nl ? (size_t)(nl - p->m) + 1 : p->mn;
+    }
+    p->mpos = at; p->have = false; p->limit = hi;
+}
 FastxReader::FastxReader() : p(new Impl) {}
 FastxReader::~FastxReader() { p->pf.finish(); if (p->f) gzclose(p->f); if (p->m) munmap((void *)p->m, p->mn); delete p; }
 bool FastxReader::open(const std::string &path)
@@ -109,6 +139,7 @@ static bool next_line(FastxReader::Impl *p)
     if (p->have) { p->have = false; return true; }
     if (p->m) {
         if (p->mpos >= p->mn) return false;
+        p->line_at = p->mpos;
         const char *a = p->m + p->mpos, *nl = (const char *)memchr(a, '\n', p->mn - p->mpos);
         const char *e = nl ? nl : p->m + p->mn;
         p->mpos = (size_t)(e - p->m) + (nl ? 1 : 0);
@@ -133,6 +164,7 @@ bool FastxReader::next(Read &r)
 {
     r.seq.clear(); r.qual.clear(); r.has_qual = false;
     do { if (!next_line(p)) return false; } while (p->line.empty() || (p->line[0] != '>' && p->line[0] != '@'));
+    if (p->m && p->line_at >= p->limit) { p->have = true; return false; }     // the record belongs to the next shard
     const bool fastq = p->line[0] == '@';
     size_t nl = strcspn(p->line.c_str() + 1, ":,");
     r.name.assign(p->line, 1, nl);
@@ -217,7 +249,8 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
     }
     B.h_pos.push_back(pos); B.h_chr.push_back(last_id); B.h_strand.push_back(strand == '+' ? 1 : -1);
     B.h_nm.push_back((int16_t)nm); B.h_len_dif.push_back((int16_t)(bd - bi)); B.h_cig_off.push_back((int32_t)base);
-    B.h_cig_n.push_back((uint8_t)std::min<size_t>(255, B.cig.size() - base));
+    if (B.cig.size() - base > 255) B.cig.resize(base + 255);               // the boundary counts a seed's CIGAR in 8 bits: the surplus goes, so that the counts add up to the arena
+    B.h_cig_n.push_back((uint8_t)(B.cig.size() - base));
 }
 
 // all hits of one seed; more than max_n hits: the seed keeps its slot but loses all hits (src/gem_parse.c:243-246)
@@ -738,10 +771,22 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
 {
     const double t_begin = now_s();
     double parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0;
+    // Every way out of this function before the map has been read to its end -- an index that does not load, a map that does not match
+    // the reads, a failed submit -- must not leave the mapper started by run_seeding running (and writing, on -t cores): it is told to
+    // stop and waited for, and its exit status reported.
+    struct MapperGuard { long pid = 0; MapText *m = nullptr; ~MapperGuard() {
+        if (!pid || (m && m->follow_done)) return;
+        kill((pid_t)pid, SIGTERM);
+        int st = 0; const pid_t w = waitpid((pid_t)pid, &st, 0);
+        if (m) m->follow_done = true;
+        if (w > 0 && WIFEXITED(st)) fprintf(stderr, "[lamsa_aln] gem-mapper stopped (exit status %d)\n", WEXITSTATUS(st));
+        else fprintf(stderr, "[lamsa_aln] gem-mapper stopped (signal %d)\n", w > 0 && WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    } };
+    MapText mapt, hitsf;                                // GEM map text, or (--hits) the binary hit stream written by --save-hits (declared before the guard that ends the mapper: destroyed after it)
+    MapperGuard orphan; orphan.pid = opt.mapper_pid; orphan.m = &mapt;
     Index ix; std::string err;
     if (!load_index(opt.ref_prefix, ix, err)) { fprintf(stderr, "[lamsa_aln] %s\n", err.c_str()); return 1; }
     const std::string map_path = opt.seed_result.empty() ? opt.reads + ".seed.gem.map" : opt.seed_result;
-    MapText mapt, hitsf;                                // GEM map text, or (--hits) the binary hit stream written by --save-hits
     const bool from_hits = !opt.hits.empty();
     if (from_hits) {
         HitsHeader hh;
@@ -755,6 +800,56 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     } else if (!mapt.open(map_path)) { fprintf(stderr, "[lamsa_aln] Can't open seed-result file %s (seeding is not run by this build: provide the GEM map, as with the reference's -N)\n", map_path.c_str()); return 1; }
     FastxReader fx;
     if (!fx.open(opt.reads)) { fprintf(stderr, "[lamsa_aln] Can't open read file %s\n", opt.reads.c_str()); return 1; }
+    // ---- --shard i/N (the read stream shards naturally; one process -- one parser -- per GPU).  This process
+    // takes the i-th of N contiguous parts: a mapped read file is cut by bytes (no pass over the parts before it: the first read's
+    // name finds its lines in the GEM map, whose lines begin "<read name>_<seed>:"), a compressed one by record count, a hit stream
+    // by chunks.  Shards 0 .. N-1 written one after the other are the unsharded output; only shard 0 writes the header.
+    long reads_left = -1, chunks_left = -1;                 // -1: no limit
+    if (opt.shard_n > 1) {
+        const int si = opt.shard_i, sn = opt.shard_n;
+        if (opt.mapper_pid) { fprintf(stderr, "[lamsa_aln] --shard needs an existing seed result (-N or --hits): the shards would each run the seeding\n"); return 1; }
+        if (from_hits) {
+            std::vector<int64_t> n_in; std::vector<size_t> at;
+            for (size_t q = hitsf.pos; q + sizeof(HitsChunkHeader) <= hitsf.n; ) {
+                HitsChunkHeader ch; memcpy(&ch, hitsf.p + q, sizeof ch);
+                if (ch.n_reads <= 0 || ch.bytes < 0 || q + sizeof ch + (size_t)ch.bytes > hitsf.n) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); return 1; }
+                n_in.push_back(ch.n_reads); at.push_back(q); q += sizeof ch + (size_t)ch.bytes;
+            }
+            const size_t C = n_in.size(), c0 = C * (size_t)si / (size_t)sn, c1 = C * (size_t)(si + 1) / (size_t)sn;
+            int64_t skip = 0;
+            for (size_t c = 0; c < c0; ++c) skip += n_in[c];
+            Read d;
+            for (int64_t k = 0; k < skip; ++k) if (!fx.next(d)) { fprintf(stderr, "[lamsa_read_seq] the hit stream does not match the reads\n"); return 1; }
+            hitsf.pos = c0 < C ? at[c0] : hitsf.n;
+            chunks_left = (long)(c1 - c0);
+        } else if (fx.mapped()) {
+            const size_t S = fx.size(), lo = S / (size_t)sn * (size_t)si, hi = si + 1 == sn ? S : S / (size_t)sn * (size_t)(si + 1);
+            fx.restrict(lo, hi);
+            if (si > 0) {
+                FastxReader probe; Read first;
+                if (probe.open(opt.reads)) probe.restrict(lo, hi);
+                if (!probe.next(first)) mapt.pos = mapt.n;       // no record starts in this part: nothing to do
+                else {
+                    std::string nm = first.name.substr(0, first.name.find_first_of(" \t"));
+                    const std::string key = "\n" + nm + "_0:";
+                    const size_t est = (size_t)((double)mapt.n * ((double)lo / (double)(S ? S : 1)));
+                    const size_t from = est > (mapt.n >> 3) ? est - (mapt.n >> 3) : 0;
+                    const char *hit = (const char *)memmem(mapt.p + from, mapt.n - from, key.data(), key.size());
+                    if (!hit && from) hit = (const char *)memmem(mapt.p, mapt.n, key.data(), key.size());
+                    if (!hit) { fprintf(stderr, "[lamsa_aln] --shard %d/%d: no line of %s begins with %s_0: (the seeds of the shard's first read)\n", si, sn, map_path.c_str(), nm.c_str()); return 1; }
+                    mapt.pos = (size_t)(hit - mapt.p) + 1;
+                }
+            }
+        } else {                                            // compressed reads: count the records, then skip to this shard's first
+            long total = 0; { FastxReader cnt; Read d; if (cnt.open(opt.reads)) while (cnt.next(d)) ++total; }
+            const long r0 = total * si / sn, r1 = total * (si + 1) / sn;
+            Read d; const char *la, *lb;
+            for (long k = 0; k < r0; ++k) {
+                if (!fx.next(d) || !mapt.take(seeds_of(P, (int)d.seq.size()), la, lb)) { fprintf(stderr, "[lamsa_read_seq] seeds' GEM map result does not match the reads\n"); return 1; }
+            }
+            reads_left = r1 - r0;
+        }
+    }
     lamsa_hp_ref ref; ref.pac = ix.pac.data(); ref.l_pac = ix.l_pac; ref.n_seqs = (int32_t)ix.name.size(); ref.seq_offset = ix.off.data(); ref.seq_len = ix.len.data();
     // one handle per GPU: the read stream is dealt out chunk by chunk, the reference is resident on
     // every device, nothing is exchanged between devices
@@ -776,7 +871,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     const double load_s = now_s() - t_begin;
     std::string sam;
     sam_header(sam, ix, pg_line);
-    fwrite(sam.data(), 1, sam.size(), out);
+    if (opt.shard_i == 0) fwrite(sam.data(), 1, sam.size(), out);
     long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
     const int threads = opt.n_thread > 0 ? opt.n_thread : 1;
     bool eof = false; int ret = 0;
@@ -808,7 +903,9 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         Read rd;
         int64_t chunk_bases = 0;
         if (from_hits) {                                    // the chunk as it was stored: its arrays are views into the mapped stream
-            if (hitsf.pos + sizeof(HitsChunkHeader) > hitsf.n) { eof = true; if (fx.next(rd)) { fprintf(stderr, "[lamsa_read_seq] the hit stream ends before the reads\n"); c->ret = 1; } return c; }
+            if (chunks_left == 0) { eof = true; return c; }
+            if (chunks_left > 0) --chunks_left;
+            if (hitsf.pos + sizeof(HitsChunkHeader) > hitsf.n) { eof = true; if (opt.shard_n <= 1 && fx.next(rd)) { fprintf(stderr, "[lamsa_read_seq] the hit stream ends before the reads\n"); c->ret = 1; } return c; }
             HitsChunkHeader ch; memcpy(&ch, hitsf.p + hitsf.pos, sizeof ch);
             const char *a = hitsf.p + hitsf.pos + sizeof ch;
             if (ch.n_reads <= 0 || ch.bytes < 0 || hitsf.pos + sizeof ch + (size_t)ch.bytes > hitsf.n) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
@@ -833,6 +930,8 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             return c;
         }
         while ((int)B.reads.size() < opt.chunk_reads && chunk_bases < opt.chunk_bases) {
+            if (reads_left == 0) { eof = true; break; }
+            if (reads_left > 0) --reads_left;
             if (!fx.next(rd)) {
                 eof = true;
                 if (mapt.following()) {                      // the reads are through: the mapper must have ended, and ended well
@@ -876,7 +975,10 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             const int64_t r_nb = nb + nb / 4 + 4096;
             reserver = std::thread([&hs, &reserve_s, r_n, r_nb, max_len]() {
                 const double t = now_s();
-                for (lamsa_hp_handle *hh : hs) lamsa_hp_reserve(hh, r_n, r_nb, r_nb / 3, 3 * r_nb, max_len + max_len / 4 + 256, 8192);
+                for (lamsa_hp_handle *hh : hs) {
+                    const int e = lamsa_hp_reserve(hh, r_n, r_nb, r_nb / 3, 3 * r_nb, max_len + max_len / 4 + 256, 8192);
+                    if (e != LAMSA_HP_OK) fprintf(stderr, "[lamsa_aln] note: device buffers could not be reserved ahead (%d %s); the first batch allocates what it needs\n", e, lamsa_hp_last_error(hh));
+                }
                 reserve_s = now_s() - t;
             });
         }
@@ -992,7 +1094,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 if (rescue && R.status == 0 && !plans[(size_t)r].lines.empty()) rescue_finish(R, codes + roff[r], L, ix, P, plans[(size_t)r], dp);
                 if (R.status != 0) {
                     ++bad_of[(size_t)t];
-                    fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[(size_t)r].name.c_str(), (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow");
+                    fprintf(stderr, "[lamsa_aln] read %s: %s; reported unmapped\n", B.reads[(size_t)r].name.c_str(), (R.status & LAMSA_HP_ST_UNSUPPORTED) ? "more than 32767 seeds, or a seed hit with |len_dif| > 127: beyond what the device keeps" : (R.status & LAMSA_HP_ST_REFEXIT) ? "input on which the reference aligner exits" : "device work buffer overflow");
                     for (int st = 0; st < 3; ++st) R.stage[st].clear();
                 }
                 rank_results(R, L, P);

@@ -26,6 +26,10 @@ class FastxReader {
     FastxReader(); ~FastxReader();
     bool open(const std::string &path);
     bool next(Read &r);
+    // Sharding (--shard i/N).  A mapped (uncompressed, regular) file is cut by bytes: restrict(lo, hi) makes next() deliver the records
+    // that START in [lo, hi) of the file; other inputs are cut by record count (count the records with next(), re-open, skip).
+    bool mapped() const; size_t size() const;
+    void restrict(size_t lo, size_t hi);
   private:
     Impl *p;
 };
@@ -71,6 +75,8 @@ struct Options {
     int seed_first = 0;                                   // --seed-first: wait for the mapper before aligning, as the reference does; default: read its map while it is being written
     long mapper_pid = 0;                                  // set by main(): the mapper started by run_seeding and still running
     std::string save_hits, hits;                          // --save-hits FILE: also write the parsed chunks as a binary hit stream; --hits FILE: read that instead of the GEM map text
+    int shard_i = 0, shard_n = 1;                         // --shard i/N: this process aligns the i-th of N contiguous parts of the read stream (one process per GPU);
+                                                          // the outputs of shards 0 .. N-1 concatenated are the unsharded output (only shard 0 writes the header)
     int parse_only = 0;                                   // --parse-only: read and parse the inputs, no GPU work, no output (ingest timing)
     float ed_rate = -1, mis_rate = -1, mat_rate = -1;     // -e, -x; defaults per read type (src/lamsa_aln.h:26-70)
     std::string gem_dir;                                  // directory holding gem-mapper (default: <directory of this binary>/gem)

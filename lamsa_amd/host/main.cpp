@@ -24,7 +24,9 @@ static int usage()
                     "         --seed-first (wait for the GEM mapper before aligning, as the reference does; default: its map is read while it is being written),\n"
                     "         --save-hits FILE (also write the parsed seed hits as a binary stream), --hits FILE (read that stream instead of the GEM map text:\n"
                     "         a re-run with other alignment options then skips seeding and text parsing; same reads file, same -T/-l/-i/-p),\n"
-                    "         --batch INT (reads per GPU batch)\n\n");
+                    "         --batch INT (reads per GPU batch),\n"
+                    "         --shard i/N (align the i-th of N contiguous parts of the read stream: one process -- one parser -- per GPU, e.g. with --device i;\n"
+                    "         needs -N or --hits; the outputs of shards 0 .. N-1 written one after the other are the unsharded output, the header comes with shard 0)\n\n");
     return 1;
 }
 
@@ -54,7 +56,7 @@ int main(int argc, char *argv[])
         {"max-skel",1,0,'s'},{"max-reg",1,0,'R'},{"bwt-kmer",1,0,'k'},{"fastest",0,0,'f'},{"ed-rate",1,0,'e'},{"diff-rate",1,0,'d'},
         {"mis-rate",1,0,'x'},{"read-type",1,0,'T'},{"match-sc",1,0,'m'},{"mis-pen",1,0,'M'},{"open-pen",1,0,'O'},{"ext-pen",1,0,'E'},
         {"band-width",1,0,'w'},{"end-bonus",1,0,'b'},{"max-out",1,0,'r'},{"gap-split",1,0,'g'},{"soft-clip",0,0,'S'},{"comment",0,0,'C'},
-        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"gem-dir",1,0,1003},{"seed-result",1,0,1001},{"batch",1,0,1002},{"parse-only",0,0,1004},{"save-hits",1,0,1005},{"hits",1,0,1006},{"devices",1,0,1007},{"seed-first",0,0,1008},{0,0,0,0}};
+        {"output",1,0,'o'},{"help",0,0,'h'},{"HELP",0,0,'H'},{"device",1,0,1000},{"gem-dir",1,0,1003},{"seed-result",1,0,1001},{"batch",1,0,1002},{"parse-only",0,0,1004},{"save-hits",1,0,1005},{"hits",1,0,1006},{"devices",1,0,1007},{"seed-first",0,0,1008},{"shard",1,0,1009},{0,0,0,0}};
     optind = 2;
     while ((c = getopt_long(argc, argv, "t:l:i:p:V:v:s:R:k:fm:M:O:E:w:b:e:d:x:T:r:g:SCo:hHNI", lopt, NULL)) >= 0) {
         switch (c) {
@@ -101,6 +103,7 @@ int main(int argc, char *argv[])
             case 1005: opt.save_hits = optarg; break;
             case 1006: opt.hits = optarg; opt.no_seed_aln = 1; break;
             case 1008: opt.seed_first = 1; break;
+            case 1009: if (sscanf(optarg, "%d/%d", &opt.shard_i, &opt.shard_n) != 2 || opt.shard_n < 1 || opt.shard_i < 0 || opt.shard_i >= opt.shard_n) { fprintf(stderr, "[lamsa_aln] --shard takes i/N with 0 <= i < N\n"); return usage(); } break;
             case 1007: { opt.devices.clear(); for (const char *q = optarg; *q;) { opt.devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; } break; }
         case 1001: opt.seed_result = optarg; break;
         case 1002: opt.chunk_reads = atoi(optarg) > 0 ? atoi(optarg) : opt.chunk_reads; break;

@@ -101,7 +101,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     AlignArgs a;
     a.P = *P;
     a.ref.pac = ref->pac; a.ref.l_pac = ref->l_pac; a.ref.n_seqs = ref->n_seqs; a.ref.seq_off = ref->seq_offset; a.ref.seq_len = ref->seq_len;
-    a.in.n_reads = B->n_reads; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
+    a.in.n_reads = B->n_reads; a.in.read_skip = nullptr; a.in.read_off = B->read_off; a.in.read_seq = B->read_seq; a.in.seed_all = B->seed_all; a.in.last_len = B->last_len;
     a.in.seed_off = B->seed_off; a.in.seed_id = B->seed_id; a.in.hit_off = B->hit_off; a.in.h_pos = B->h_pos; a.in.h_chr = B->h_chr;
     // the boundary's two CIGAR forms -> what the kernels read (words, 64-bit offsets), as the product does on the device
     const int64_t n_hits_all = B->n_reads ? B->hit_off[B->seed_off[B->n_reads]] : 0;

@@ -144,6 +144,24 @@ def test_map_is_read_while_the_mapper_writes_it(cli, tmp_path):
     assert p.returncode != 0 and ("exit abnormally" in p.stderr or "does not match" in p.stderr)
 
 
+def test_an_error_exit_does_not_leave_the_mapper_running(cli, tmp_path):
+    """run_aln leaves through an error (here: the index does not load) while the mapper started before it is still writing: the mapper is
+    told to stop and waited for -- no orphan burning -t cores and growing <reads>.seed.gem.map -- and its end is reported."""
+    import time
+    ref, reads, args, _ = G.stage_scenario("c2_pacbio", str(tmp_path))
+    keep = str(tmp_path / "map.keep")
+    shutil.move(reads + ".seed.gem.map", keep)
+    gem = _fake_mapper(str(tmp_path / "gem"), keep, pieces=40, delay=0.5)          # would run for 20 s
+    os.remove(ref + ".pac")                                                          # load_index fails after the mapper has started
+    t0 = time.time()
+    p = subprocess.run([cli, "aln", "-R", "0", "--gem-dir", gem] + args + [ref, reads], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "gem-mapper stopped" in p.stderr, p.stderr[-1500:]
+    assert time.time() - t0 < 15
+    size = os.path.getsize(reads + ".seed.gem.map") if os.path.exists(reads + ".seed.gem.map") else 0
+    time.sleep(1.5)
+    assert (os.path.getsize(reads + ".seed.gem.map") if os.path.exists(reads + ".seed.gem.map") else 0) == size, "the mapper is still writing"
+
+
 def test_chunks_dealt_over_several_devices(cli, tmp_path):
     """--devices: one handle per listed device, chunks round-robin, output in input order (two handles on device 0 here)."""
     ref, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path))
@@ -247,3 +265,39 @@ def test_bench_shaped_reads_against_the_reference_binary(cli, workload, n_reads,
     assert want.returncode == 0, want.stderr[-2000:]
     res = bench.compare_with_product(d, args, 4, n_reads, exe=cli)
     assert res == "%d/%d reads" % (n_reads, n_reads), res
+
+
+@pytest.mark.parametrize("name,n", [("c3_ont", 2), ("c2_pacbio", 3), ("c5_sv", 5)])
+def test_shards_concatenate_to_the_unsharded_output(cli, name, n, tmp_path):
+    """--shard i/N: every process aligns one contiguous part of the read stream with its own parser (the read file cut by bytes, its
+    part of the GEM map found through the first read's name; a hit stream cut by chunks; compressed reads by record count); the
+    outputs of the shards written one after the other are the unsharded SAM, byte for byte (the reference prints in input order,
+    src/lamsa_aln.c:1102-1110)."""
+    ref, reads, args, gold = G.stage_scenario(name, str(tmp_path))
+    base = [cli, "aln", "-N", "-R", "0", "--batch", "16"] + args
+    whole = subprocess.run(base + [ref, reads], capture_output=True, text=True)
+    assert whole.returncode == 0 and G.strip_pg(whole.stdout) == G.strip_pg(gold)
+    parts = []
+    for i in range(n):
+        p = subprocess.run(base + ["--shard", "%d/%d" % (i, n), ref, reads], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert (i == 0) == p.stdout.startswith("@"), "only shard 0 writes the header"
+        parts.append(p.stdout)
+    assert all(len(x) > 0 for x in parts)
+    assert G.strip_pg("".join(parts)) == G.strip_pg(whole.stdout)
+    # the hit stream, cut by chunks
+    hits = str(tmp_path / "hits.bin")
+    one = subprocess.run(base + ["--save-hits", hits, ref, reads], capture_output=True, text=True)
+    assert one.returncode == 0
+    parts = [subprocess.run(base + ["--hits", hits, "--shard", "%d/%d" % (i, n), ref, reads], capture_output=True, text=True) for i in range(n)]
+    assert all(p.returncode == 0 for p in parts), [p.stderr[-500:] for p in parts]
+    assert G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout)
+    # compressed reads, cut by record count
+    gz = str(tmp_path / "reads.fa.gz")
+    with open(reads, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    parts = [subprocess.run(base + ["--seed-result", reads + ".seed.gem.map", "--shard", "%d/%d" % (i, n), ref, gz], capture_output=True, text=True) for i in range(n)]
+    assert all(p.returncode == 0 for p in parts), [p.stderr[-500:] for p in parts]
+    assert G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout)
+    bad = subprocess.run(base + ["--shard", "3/3", ref, reads], capture_output=True, text=True)
+    assert bad.returncode != 0
