@@ -160,9 +160,50 @@ static bool next_line(FastxReader::Impl *p)
     while (!p->line.empty() && (p->line.back() == '\n' || p->line.back() == '\r')) p->line.pop_back();
     return true;
 }
+// A record of a mapped file, read straight out of the mapping: one copy of the sequence (into r.seq), none of the lines -- the sequential
+// pass over the read file is what bounds the host side once the hits come from a binary stream (tools/cli_bench.py).
+static bool next_mapped(FastxReader::Impl *p, Read &r)
+{
+    const char *m = p->m; const size_t n = p->mn;
+    size_t at = p->mpos;
+    auto line_end = [&](size_t from, size_t &next) { const char *nl = (const char *)memchr(m + from, '\n', n - from); size_t e = nl ? (size_t)(nl - m) : n; next = nl ? e + 1 : n; while (e > from && m[e - 1] == '\r') --e; return e; };
+    // the next header line
+    for (;;) {
+        if (at >= n) { p->mpos = n; return false; }
+        if (m[at] == '>' || m[at] == '@') break;
+        size_t nx; line_end(at, nx); at = nx;
+    }
+    if (at >= p->limit) { p->mpos = at; return false; }                        // the record belongs to the next shard
+    const bool fastq = m[at] == '@';
+    size_t nx; size_t e = line_end(at, nx);
+    { const char *h = m + at + 1; size_t k = 0, hl = e - (at + 1); while (k < hl && h[k] != ':' && h[k] != ',') ++k; r.name.assign(h, k); }
+    at = nx;
+    bool plus = false;
+    while (at < n) {                                                            // sequence lines, up to the next header or the '+' of a FASTQ record
+        const char c0 = m[at];
+        if (c0 == '>' || c0 == '@') break;
+        if (c0 == '+') { plus = true; line_end(at, nx); at = nx; break; }
+        e = line_end(at, nx);
+        const size_t k0 = r.seq.size();
+        r.seq.append(m + at, e - at);
+        unsigned dirty = 0;                                                     // kseq keeps the isgraph() characters of a sequence line (33..126 in the C locale)
+        { const char *d = r.seq.data(); const size_t k1 = r.seq.size(); for (size_t k = k0; k < k1; ++k) dirty |= (unsigned)((unsigned char)(d[k] - 33) >= 94); }
+        if (dirty) r.seq.erase(std::remove_if(r.seq.begin() + (long)k0, r.seq.end(), [](char c) { return (unsigned char)(c - 33) >= 94; }), r.seq.end());
+        at = nx;
+    }
+    if (fastq && plus) {
+        while (r.qual.size() < r.seq.size() && at < n) { e = line_end(at, nx); r.qual.append(m + at, e - at); at = nx; }
+        if (r.qual.size() > r.seq.size()) r.qual.resize(r.seq.size());
+        r.has_qual = true;
+    }
+    p->mpos = at;
+    return true;
+}
+
 bool FastxReader::next(Read &r)
 {
     r.seq.clear(); r.qual.clear(); r.has_qual = false;
+    if (p->m && !p->have) return next_mapped(p, r);
     do { if (!next_line(p)) return false; } while (p->line.empty() || (p->line[0] != '>' && p->line[0] != '@'));
     if (p->m && p->line_at >= p->limit) { p->have = true; return false; }     // the record belongs to the next shard
     const bool fastq = p->line[0] == '@';
@@ -831,13 +872,23 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 if (!probe.next(first)) mapt.pos = mapt.n;       // no record starts in this part: nothing to do
                 else {
                     std::string nm = first.name.substr(0, first.name.find_first_of(" \t"));
-                    const std::string key = "\n" + nm + "_0:";
+                    // the lines of a read's seeds are consecutive and begin "<read name>_<seed>" (split_seed, src/lamsa_aln.c:287): the first
+                    // of them at or after a guess of where this part begins, then back over the lines of the same read before it
+                    const std::string key = "\n" + nm + "_";
                     const size_t est = (size_t)((double)mapt.n * ((double)lo / (double)(S ? S : 1)));
                     const size_t from = est > (mapt.n >> 3) ? est - (mapt.n >> 3) : 0;
                     const char *hit = (const char *)memmem(mapt.p + from, mapt.n - from, key.data(), key.size());
                     if (!hit && from) hit = (const char *)memmem(mapt.p, mapt.n, key.data(), key.size());
-                    if (!hit) { fprintf(stderr, "[lamsa_aln] --shard %d/%d: no line of %s begins with %s_0: (the seeds of the shard's first read)\n", si, sn, map_path.c_str(), nm.c_str()); return 1; }
-                    mapt.pos = (size_t)(hit - mapt.p) + 1;
+                    if (!hit && mapt.n >= key.size() - 1 && memcmp(mapt.p, key.data() + 1, key.size() - 1) == 0) hit = mapt.p - 1;      // the very first line
+                    if (!hit) { fprintf(stderr, "[lamsa_aln] --shard %d/%d: no line of %s begins with %s_ (the seeds of the shard's first read)\n", si, sn, map_path.c_str(), nm.c_str()); return 1; }
+                    size_t at = (size_t)(hit + 1 - mapt.p);
+                    while (at > 1) {                            // the line before `at`: does it belong to the same read?
+                        const char *pe = mapt.p + at - 1;       // its newline
+                        const char *ps = (const char *)memrchr(mapt.p, '\n', (size_t)(pe - mapt.p));
+                        const size_t b = ps ? (size_t)(ps - mapt.p) + 1 : 0;
+                        if (at - 1 - b >= key.size() - 1 && memcmp(mapt.p + b, key.data() + 1, key.size() - 1) == 0) at = b; else break;
+                    }
+                    mapt.pos = at;
                 }
             }
         } else {                                            // compressed reads: count the records, then skip to this shard's first
