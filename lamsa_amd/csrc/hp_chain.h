@@ -715,11 +715,16 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
     g_in_de[n] = -1;
     const int n_sons = g_son_n[n], n_score = g_nd[n].score, n_NM = g_nd[n].NM;
     int fa = g_from[n];
-    if (n_sons == 0) { max_node = n; g_mx[n] = n; max_score = n_score; g_ms[n] = n_score; max_NM = n_NM; g_mn[n] = n_NM; }
+    if (n_sons == 0) { max_node = n; max_score = n_score; max_NM = n_NM; }      // (stored below, when and where they are read again)
     else { max_node = g_mx[n]; max_score = g_ms[n]; max_NM = g_mn[n]; }
     wv::Lane<int> path;                               // the ancestors of max_node walked so far, while path_ok
     WAVE_FOR(l) { path[l] = 0; }
     int n_path = 0; bool path_ok = n_sons == 0;       // a leaf: max_node is n itself, its ancestors are exactly the nodes walked below
+    // What the reference stores in every node it walks over (max_score, max_NM, max_node, in_de = -1; :885-910) is read again only for
+    // the node right below a node with several sons (get_max_son / cut_branch look at their sons) or below a negative edge: the walk
+    // keeps the three values in registers and stores them for that node alone -- four stores less per step.  in_de is only ever
+    // compared with 0 (is the node a leaf?), and a walked node with one son keeps its 1.
+    int prev = n;                                     // the node below fa
     while (fa >= 0) {
         const int fa_sons = g_son_n[fa], fa_score = g_nd[fa].score, fa_from = g_from[fa];
 #ifdef HP_PROF_TRACK
@@ -728,6 +733,8 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
         if (fa_sons == 1) {
             if (fa_score > max_score) {               // negative edge
                 const int s = r.n_first[fa];
+                g_ms[prev] = max_score; g_mn[prev] = max_NM; g_mx[prev] = max_node;       // s == prev: detach reads them
+                wv::sync();
                 r.n_in_de[s] = -1;
                 detach(r, s, max_node, ns);
                 r.n_son_n[fa] = 0; r.n_first[fa] = r.n_last[fa] = -1;
@@ -736,16 +743,17 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
             } else if (path_ok) {
                 if (n_path < 64) { WAVE_FOR(l) { if (l == n_path) path[l] = fa; } ++n_path; } else path_ok = false;
             }
-            g_ms[fa] = max_score; g_mn[fa] = max_NM; g_mx[fa] = max_node; g_in_de[fa] = -1;
+            prev = fa;
             fa = fa_from;                             // detach() above changes n_from of the son only, never of fa
         } else {
+            g_ms[prev] = max_score; g_mn[prev] = max_NM; g_mx[prev] = max_node;           // prev is a son of fa: what get_max_son / cut_branch read
             const int left_ = g_in_de[fa] - 1;
             g_in_de[fa] = left_;
 #ifdef HP_PROF_TRACK
             if (r.prof) r.prof[21] += 1;
             const long long tcb_ = wv::clock();
 #endif
-            if (left_ == 0) cut_branch(r, fa, ns);
+            if (left_ == 0) { wv::sync(); cut_branch(r, fa, ns); }
 #ifdef HP_PROF_TRACK
             if (r.prof) r.prof[22] += wv::clock() - tcb_;
 #endif

@@ -276,7 +276,7 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
 struct GapCache { int n, used, cap; int lo[4], off[4], cnt[4]; int32_t *ids; };
 HP_INL void gapcache_init(ReadCtx &r, GapCache &gc) { gc.n = 0; gc.used = 0; gc.cap = r.H; gc.ids = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)(r.H + 64)); if (!gc.ids) gc.cap = 0; }
 
-HP_HOT GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int G, int32_t *gp, int GA, int32_t *pool, int32_t *pool_mf, int32_t *_line, GapCache *gc = nullptr)
+HP_HOT GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int G, int32_t *gp, int GA, int32_t *pool, int32_t *pool_mf, int32_t *_line, GapCache *gc = nullptr, int cl_lo = -1, int cl_n = 0)
 {
     Ctx &cx = r.cx;
     const int H = r.H, seed_out = r.seed_out;
@@ -289,7 +289,7 @@ HP_HOT GapRest gaps_by_cluster(ReadCtx &r, const Clusters &C, int max_node, int 
     const HP_G int16_t *g_hnm = (const HP_G int16_t *)r.h_nm;
     const HP_G int32_t *g_csrt = (const HP_G int32_t *)C.csrt;
     HP_G int32_t *g_from = (HP_G int32_t *)r.n_from, *g_node_n = (HP_G int32_t *)r.n_node_n;
-    const int lo = C.cl_lo_r[r.rnk[max_node]], hi = C.ce[lo], n_c = hi - lo;
+    const int lo = cl_lo >= 0 ? cl_lo : C.cl_lo_r[r.rnk[max_node]], n_c = cl_lo >= 0 ? cl_n : C.ce[lo] - lo;       // the line's cluster (line_build has looked it up already)
     if ((long long)(n_c - 1) * C.reach > 0x3fffffffll) return R;      // neighbours of a cluster are at most `reach` apart: its span fits 30 bits
     const int sp = r.h_strand[max_node];
     const HP_G int32_t *g_left = (const HP_G int32_t *)gp, *g_right = (const HP_G int32_t *)(gp + GA), *g_lx = (const HP_G int32_t *)(gp + 2 * GA),
@@ -534,11 +534,13 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
 #endif
     HP_G int32_t *g_anc = (HP_G int32_t *)anc, *g_ancx = (HP_G int32_t *)anc_x;
     bool walked = false;
+    int cl_lo = -1, cl_n = 0;                                  // the line's cluster, when the read's hits have been clustered
     if (C) {
         // A line of a large cluster (the read's true locus: a few hundred anchors) is a pointer chase of that many dependent loads.  Its
         // cluster's predecessors are fetched into LDS first -- as places in the cluster's rank range, 64 hits per step -- and chased there.
         const HP_G int32_t *g_srt = (const HP_G int32_t *)r.srt, *g_rnk = (const HP_G int32_t *)r.rnk;
         const int rk = r.rnk[max_node], lo = C->cl_lo_r[rk], n_c = C->ce[lo] - lo;
+        cl_lo = lo; cl_n = n_c;
         // (worth it for a long line only: the number of nodes the main pass counted up to the end node says how long)
         if (n_c <= 6) HP_STAT(6); else if (n_c <= 16) HP_STAT(7); else HP_STAT(8);
         if (n_c >= HP_WALK_MIN && n_c <= cx.lds_words && r.n_node_n[max_node] >= HP_WALK_MIN) {
@@ -629,7 +631,7 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
     int pool_n = 0, d_score = 0, d_NM = 0;
     bool by_cluster = false;
     if (C) {
-        const GapRest gr = gaps_by_cluster(r, *C, max_node, G, gp, GA, pool, pool_mf, _line, gc);
+        const GapRest gr = gaps_by_cluster(r, *C, max_node, G, gp, GA, pool, pool_mf, _line, gc, cl_lo, cl_n);
         if (gr.pool_n == -1) { arena_release(cx.tmp, mark); return -1; }
         if (gr.pool_n >= 0) { by_cluster = true; pool_n = gr.pool_n; d_score = gr.d_score; d_NM = gr.d_NM; HP_STAT(0); }
         HP_LSTAMP(18);
@@ -694,7 +696,28 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
     HP_LSTAMP(19);
     // ---- the line, end node first: [nodes beyond the end node], anchor 0, [nodes of the gap after it], anchor 1, ...
     int node_i = 0;
-    {
+    if (pool_n == 0) {
+        // No gap has put a node on the line (the usual case): the line is its anchors, and an inter-line trigger (:1384-1386, :1404-1414)
+        // is a pair of consecutive anchors more than two slots apart -- the gap between them exists then, and START never takes part.
+        HP_G int32_t *g_ln = (HP_G int32_t *)ln;
+        for (int q0 = 0; q0 < A; q0 += 64) {
+            wv::Lane<int> push, a0, a1;
+            WAVE_FOR(l) {
+                const int q = q0 + l;
+                int p = 0, x0 = 0, x1 = 0;
+                if (q < A) { x0 = g_anc[q]; g_ln[q] = x0; if (q > 0) { x1 = g_anc[q - 1]; p = g_ancx[q - 1] - g_ancx[q] > 2; } }
+                push[l] = p; a0[l] = x0; a1[l] = x1;
+            }
+            const unsigned long long m = wv::ballot(push);
+            const int cnt = __builtin_popcountll(m);
+            if (!cnt) continue;
+            if (T.used + cnt > T.cap) { cx.status |= ST_OVERFLOW; break; }
+            WAVE_FOR(l) { if (push[l]) { const int at = T.used + __builtin_popcountll(m & ((1ull << l) - 1)); T.n1[at] = a0[l]; T.n2[at] = a1[l]; } }
+            T.used += cnt; T.cnt[l_i] += cnt;
+        }
+        node_i = A;
+        wv::sync();
+    } else {
         HP_G int32_t *g_ln = (HP_G int32_t *)ln; HP_G int32_t *g_seg = (HP_G int32_t *)(posx + (H + A + 8));
         // Positions by prefix sums instead of one anchor after the other: an anchor sits at its index plus the nodes of all gaps before it.
         HP_G int32_t *g_na = g_ancx;                       // per anchor: nodes of the gap that follows it << 1 | 1, or 0 (the slots are not needed any more)
