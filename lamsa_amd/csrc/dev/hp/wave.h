@@ -69,6 +69,10 @@ HP_INL long long uni64(long long v) {
 }
 
 HP_INL int bcast(const Lane<int> &x, int src) { return __builtin_amdgcn_readlane(x.v, src); }
+// every lane reads x of the lane it names (ds_bpermute_b32: the LDS crossbar, no memory)
+HP_INL Lane<int> gather(const Lane<int> &x, const Lane<int> &from) { Lane<int> o; o.v = __builtin_amdgcn_ds_bpermute(from.v << 2, x.v); return o; }
+// lane `dst` of x takes the wave-uniform value v
+HP_INL void setlane(Lane<int> &x, int dst, int v) { x.v = lane() == dst ? v : x.v; }
 
 HP_INL unsigned long long ballot(const Lane<int> &p) { return __ballot(p.v != 0); }
 
@@ -123,6 +127,19 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
     x.v = dpp<0x138>(ident, v);                        // shift the inclusive scan right by one lane
 }
 
+// the same, and the maximum of all 64 inputs is returned (lane 63 of the inclusive scan)
+HP_INL int scan_max_excl_top(Lane<int> &x, int ident) {
+    int v = x.v;
+    HP_MAX_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    HP_MAX_DPP(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    HP_MAX_DPP(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    x.v = dpp<0x138>(ident, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // every lane receives the value of the lane below it; lane 0 receives `fill`
 HP_INL void shr1(Lane<int> &x, int fill) { x.v = dpp<0x138>(fill, x.v); }
 
@@ -161,3 +178,28 @@ HP_INL void scan_add_excl(Lane<int> &x) {
 }
 
 }  // namespace wv
+
+// ---- two int16 values per 32-bit register (VOP3P packed math: v_pk_add_i16, v_pk_max_i16, ...): the banded DP of hp_ksw.h keeps two
+// columns per lane where its scores fit.  Arithmetic wraps like the hardware's; the callers stay far from the ends of the range.
+namespace pk {
+typedef short v2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+HP_INL v2 V(int x) { return __builtin_bit_cast(v2, x); }
+HP_INL u2 U(int x) { return __builtin_bit_cast(u2, x); }
+HP_INL int I(v2 x) { return __builtin_bit_cast(int, x); }
+HP_INL int I(u2 x) { return __builtin_bit_cast(int, x); }
+HP_INL int add(int a, int b) { return I(V(a) + V(b)); }
+HP_INL int sub(int a, int b) { return I(V(a) - V(b)); }
+HP_INL int max(int a, int b) { return I(__builtin_elementwise_max(V(a), V(b))); }
+HP_INL int min_u(int a, int b) { return I(__builtin_elementwise_min(U(a), U(b))); }
+HP_INL int mul(int a, int b) { return I(V(a) * V(b)); }                                  // low 16 bits of each product
+HP_INL int neg_mask(int a) { return I(V(a) >> (v2){15, 15}); }                           // per half: 0xFFFF where negative, else 0
+HP_INL int rep(int x) { return (x & 0xffff) | (int)((unsigned)x << 16); }                // both halves = (short)x
+HP_INL int lo(int a) { return (int)(short)(a & 0xffff); }                                // sign-extended halves
+HP_INL int hi(int a) { return a >> 16; }
+HP_INL int pack(int l, int h) { return (l & 0xffff) | (int)((unsigned)h << 16); }
+HP_INL int sel(int mask, int a, int b) { return (a & mask) | (b & ~mask); }              // bitwise: a where the mask is set
+// columns shifted up by one: half 1 <- half 0, half 0 <- half 1 of the lane below (`below`: the register of lane l - 1)
+HP_INL int shift_up(int x, int below) { return (int)(((unsigned)x << 16) | ((unsigned)below >> 16)); }
+}  // namespace pk
+

@@ -506,6 +506,9 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
         fprintf(stderr, "[HP_PROF] gaps: %lld in lines with fewer than HP_GAP_MIN gaps (%lld lines with gaps); lane gaps: %lld hits scanned, %lld refused (range too long or too many active hits)\n", sum[54], sum[55], sum[11], sum[13]);
         { const char *nm[] = {"ksw_global", "ksw_extend", "backtrack", "ref_fetch", "head_fix", "frag_extend", "split_mapping", "tail_fix", "res_split", "res_aux", "mini_line_regs", "sort index"};
           for (int k = 0; k < 12; ++k) fprintf(stderr, "[HP_PROF] %-16s %8lld Mcyc %10lld calls\n", nm[k], sum[24 + 2 * k] / 1000000, sum[25 + 2 * k]);
+#ifdef HP_PROF_FILL
+          fprintf(stderr, "[HP_PROF] in frags_merge: boundary repair (merge_cigar_full) %lld Mcyc %lld calls; junctions through split_mapping %lld Mcyc %lld calls; fragments of several seeds %lld Mcyc %lld calls; 64-step gathers %lld Mcyc %lld\n", sum[16] / 1000000, sum[17], sum[18] / 1000000, sum[19], sum[20] / 1000000, sum[21], sum[22] / 1000000, sum[23]);
+#endif
           fprintf(stderr, "[HP_PROF] direction-matrix bytes in HBM %lld (%lld jobs); hits passed through nodes_per_init %lld (%lld calls)\n", sum[52], sum[53], sum[54], sum[55]);
           fprintf(stderr, "[HP_PROF] chain_first start: seed loop %lld, node_set loop %lld, min_extend %lld Mcyc (%lld reads with a MIN pass)\n", sum[56] / 1000000, sum[57] / 1000000, sum[58] / 1000000, sum[59]);
           fprintf(stderr, "[HP_PROF] query <= 62: ksw_extend %lld Mcyc %lld calls, ksw_global %lld Mcyc %lld calls\n", sum[60] / 1000000, sum[61], sum[62] / 1000000, sum[63]);

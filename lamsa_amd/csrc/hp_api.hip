@@ -164,6 +164,7 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         // worst-case scratch of one job: H,E rows + row bounds + direction matrix + 3 temporary CIGARs (bi-extend)
         size_t wmax = (size_t)(abs(ql - tl) + 3 > (J->kind[i] == 2 ? h->para.band_w : J->w[i]) ? abs(ql - tl) + 3 : (J->kind[i] == 2 ? h->para.band_w : J->w[i]));
         size_t ncol = (size_t)ql < 2 * wmax + 1 ? (size_t)ql : 2 * wmax + 1;
+        if (ql <= HP_PK_QMAX(2) && ncol < 128) ncol = 128;          // the two-columns-per-lane extension keeps whole rows of its direction matrix (hp_ksw.h)
         size_t need = 2 * 4 * ((size_t)ql + 18) + 8 * ((size_t)tl + 17) + ncol * tl + 64 + 3 * 4 * ((size_t)ql + tl + 24) + 1024;
         if (need > z_need) z_need = need;
     }

@@ -728,7 +728,7 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
     while (fa >= 0) {
         const int fa_sons = g_son_n[fa], fa_score = g_nd[fa].score, fa_from = g_from[fa];
 #ifdef HP_PROF_TRACK
-        if (r.prof) r.prof[20] += 1;
+        if (HP_PROF_CHAIN_ON && r.prof) r.prof[20] += 1;
 #endif
         if (fa_sons == 1) {
             if (fa_score > max_score) {               // negative edge
@@ -750,12 +750,12 @@ HP_HOT void branch_track(ReadCtx &r, int n, NScore &ns)
             const int left_ = g_in_de[fa] - 1;
             g_in_de[fa] = left_;
 #ifdef HP_PROF_TRACK
-            if (r.prof) r.prof[21] += 1;
+            if (HP_PROF_CHAIN_ON && r.prof) r.prof[21] += 1;
             const long long tcb_ = wv::clock();
 #endif
             if (left_ == 0) { wv::sync(); cut_branch(r, fa, ns); }
 #ifdef HP_PROF_TRACK
-            if (r.prof) r.prof[22] += wv::clock() - tcb_;
+            if (HP_PROF_CHAIN_ON && r.prof) r.prof[22] += wv::clock() - tcb_;
 #endif
             return;
         }
@@ -834,7 +834,7 @@ HP_INL void track_slot(ReadCtx &r, int h0, int h1, int dp_flag, bool skip_lone, 
 #endif
             branch_track(r, b + __builtin_ctzll(m), ns);
 #ifdef HP_PROF_TRACK
-            if (r.prof) { r.prof[17] += wv::clock() - tb_; r.prof[18] += 1; }
+            if (HP_PROF_CHAIN_ON && r.prof) { r.prof[17] += wv::clock() - tb_; r.prof[18] += 1; }
 #endif
         }
     }
@@ -875,7 +875,7 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
     }
     wv::sync();
 #ifdef HP_PROF_TRACK
-    if (r.prof) r.prof[16] += wv::clock() - tt0_;
+    if (HP_PROF_CHAIN_ON && r.prof) r.prof[16] += wv::clock() - tt0_;
 #endif
     r.leaf_bits = bits; r.leaf_on = true;
     for (int w = nw - 1; w >= w_lo; --w) {
@@ -891,7 +891,7 @@ HP_NOINL void track_leaves(ReadCtx &r, int first_slot, int last_slot, int dp_fla
             wv::sync();
             const int i = w * 32 + bit;
 #ifdef HP_PROF_TRACK
-            if (r.prof) r.prof[19] += 1;
+            if (HP_PROF_CHAIN_ON && r.prof) r.prof[19] += 1;
 #endif
             track_slot(r, (int)(g_hoff[i] - hb), (int)(g_hoff[i + 1] - hb), dp_flag, skip_lone, ns);
         }

@@ -52,6 +52,14 @@ struct Ctx {
     long long n_cells;        // DP cells updated (accounting: GCUPS)
     long long *prof;          // per-read cycle counters of diagnostic builds (-DHP_PROF), else nullptr
 };
+// -DHP_PROF_FILL: slots 16 .. 23 time parts of frags_merge (hp_fill.h) instead of parts of the chaining (hp_chain.h, hp_gaps.h)
+#ifdef HP_PROF_FILL
+#define HP_PROF_CHAIN_ON 0
+#define HP_TADD_FILL(cx, slot, v) HP_TADD(cx, slot, v)
+#else
+#define HP_PROF_CHAIN_ON 1
+#define HP_TADD_FILL(cx, slot, v) do { } while (0)
+#endif
 #ifdef HP_PROF
 #define HP_T0(v) const long long v = wv::clock()
 #define HP_TADD(cx, slot, v) do { if ((cx).prof) { (cx).prof[slot] += wv::clock() - (v); (cx).prof[(slot) + 1] += 1; } } while (0)
@@ -61,6 +69,9 @@ struct Ctx {
 #endif
 
 // path counters of the tests' CPU build (tests/emu/emu_api.cpp defines HP_STAT): which variant of a routine a test has really run
+#ifndef HP_DPLOG
+#define HP_DPLOG(kind, qlen, tlen, w, cells) do { } while (0)      // tests' CPU build: one record per DP call (tools/dp_shapes.py)
+#endif
 #ifndef HP_STAT
 #define HP_STAT(i) do { } while (0)
 #endif

@@ -50,39 +50,82 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
 }
 
 // ---------------------------------------------------------------- merge_cigar, frag_check.c:251-328
+// _push_cigar (frag_check.h:158-184) with what the caller already holds in registers: `last` = the vector's last element (used when it
+// is not empty), `c0` = the first source element (which may differ from c[0] in memory: the repair below shortens it).  Returns the
+// vector's new last element.  Nothing is loaded but the body of the copy.
+HP_FN int cig_pushv_known(Ctx &cx, CigV &v, int last, const cig_t *c, int n, int c0)
+{
+    if (n == 0) return last;
+    const HP_G cig_t *src = (const HP_G cig_t *)c;
+    HP_G cig_t *dst = (HP_G cig_t *)v.c;
+    const int vn = v.n;
+    int j = 0;
+    if (vn > 0) {
+        if ((last & 0xf) == (c0 & 0xf)) { last = last + ((c0 >> 4) << 4); dst[vn - 1] = last; j = 1; }
+        else if (((last & 0xf) == C_I && (c0 & 0xf) == C_S) || ((last & 0xf) == C_S && (c0 & 0xf) == C_I)) { last = (((last >> 4) + (c0 >> 4)) << 4) | C_S; dst[vn - 1] = last; j = 1; }
+    }
+    const int m = n - j;
+    if (vn + m > v.cap) { cx.status |= ST_OVERFLOW; return last; }
+    if (m > 0) {
+        wv::Lane<int> w;
+        WAVE_FOR(l) { w[l] = 0; }
+        for (int b0 = 0; b0 < m; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < m) { w[l] = j + i == 0 ? c0 : (int)src[j + i]; dst[vn + i] = w[l]; } } }
+        last = wv::bcast(w, (m - 1) & 63);
+    }
+    v.n = vn + m;
+    wv::sync();
+    return last;
+}
+
+// The boundary repair (:264-322): both CIGARs are shortened from the junction by whole elements, up to five matched bases into the
+// first long match on either side, the stretch between is aligned again, and if that alignment still begins or ends with a gap the
+// flanks grow once more.  The elements it walks over -- the tail of c1, the head of c2 -- are loaded once, 64 of each, one per lane,
+// and the walk reads lanes; the element a side stops in is shortened in a register and stored when the walk is over.  (Walked one at
+// a time out of HBM this routine was a quarter of the fill kernel: ~16 calls per line, each a chain of ~40 dependent round trips.)
 HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1_readend, int chr,
                                const cig_t *_c2, int c2_n, int c2_reflen, int c2_readlen)
 {
     if (c2_n == 0) return true;
     Ctx &cx = r.cx;
+    HP_T0(tmf_);
     const lamsa_hp_para *P = cx.P;
+    const HP_G cig_t *g1 = (const HP_G cig_t *)c1.c, *g2 = (const HP_G cig_t *)_c2;
+    const int n1_0 = c1.n;
+    wv::Lane<int> T1, T2;                                     // T1[l] = c1[n1_0 - 1 - l] (the top first), T2[l] = c2[l]
+    WAVE_FOR(l) { T1[l] = l < n1_0 ? (int)g1[n1_0 - 1 - l] : 0; T2[l] = l < c2_n ? (int)g2[l] : 0; }
     bool repair = false;
-    if (c1.n > 1) {
-        const cig_t t = c1.c[c1.n - 1], h = _c2[0];
+    if (n1_0 > 1) {
+        const int t = wv::bcast(T1, 0), h = wv::bcast(T2, 0);
         const int top = t & 0xf, hop = h & 0xf;
         if ((((top == C_I || top == C_D) && (t >> 4) <= 3) && hop != C_S && hop != C_H) ||
             (((hop == C_I || hop == C_D) && (h >> 4) <= 3) && top != C_S && top != C_H)) repair = true;
     }
-    if (!repair) cig_pushv(cx, c1, _c2, c2_n);
+#ifdef HP_EXP_NO_MERGEFULL
+    repair = false;
+#endif
+    if (!repair) cig_pushv_known(cx, c1, wv::bcast(T1, 0), _c2, c2_n, wv::bcast(T2, 0));
     else {
         const size_t mark = arena_mark(cx.tmp);
         int len1, len11 = 0, len2, len21 = 0, len22 = 0, len_dif1 = 0, len_dif2 = 0;
         int b = 0, min_b, ci = 0, left = 1, right = 1;
         const int md = 5;
         int64_t ref_start = 0; int read_start = 0;
-        cig_t *c2 = (cig_t *)arena_alloc(cx, sizeof(cig_t) * (size_t)(c2_n + 1));
         CigV bd; bd.c = nullptr; bd.n = 0; bd.cap = 0;
-        if (!c2) { arena_release(cx.tmp, mark); return false; }
-        for (int i = 0; i < c2_n; ++i) c2[i] = _c2[i];
+        int n1 = n1_0;                                        // c1.n while the walk goes on
+        // the element on top of c1 / at ci of c2 as the walk has left it (a long match is shortened where the walk stops)
+#define HP_MF_E1(k) ((k) <= 0 ? 0 : (n1_0 - (k) < 64 ? wv::bcast(T1, n1_0 - (k)) : (int)g1[(k) - 1]))          /* element k-1 of c1, untouched */
+#define HP_MF_E2(k) ((k) >= c2_n ? 0 : ((k) < 64 ? wv::bcast(T2, (k)) : (int)g2[(k)]))                       /* element k of c2, untouched */
+        int e1 = HP_MF_E1(n1), e2 = HP_MF_E2(0);
+        int bd_first = 0, bd_last = 0;
         bool ok = true;
         for (;;) {
             if (left) {
-                while (c1.n >= 1) {
-                    const cig_t w = c1.c[c1.n - 1]; const int op = w & 0xf, l = w >> 4;
-                    if (op == C_M && l > md) { c1.c[c1.n - 1] -= md << 4; len21 += md; break; }
-                    else if (op == C_M) { len21 += l; --c1.n; }
-                    else if (op == C_I) { len21 += l; len_dif1 -= l; b += l; --c1.n; }
-                    else if (op == C_D) { len_dif1 += l; b += l; --c1.n; }
+                while (n1 >= 1) {
+                    const int op = e1 & 0xf, l = e1 >> 4;
+                    if (op == C_M && l > md) { e1 -= md << 4; len21 += md; break; }
+                    else if (op == C_M) { len21 += l; --n1; e1 = HP_MF_E1(n1); }
+                    else if (op == C_I) { len21 += l; len_dif1 -= l; b += l; --n1; e1 = HP_MF_E1(n1); }
+                    else if (op == C_D) { len_dif1 += l; b += l; --n1; e1 = HP_MF_E1(n1); }
                     else { left = -1; break; }
                 }
                 len11 = len21 + len_dif1;
@@ -91,11 +134,11 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
             }
             if (right) {
                 while (ci < c2_n) {
-                    const int op = c2[ci] & 0xf, l = c2[ci] >> 4;
-                    if (op == C_M && l > md) { c2[ci] -= md << 4; len22 += md; break; }
-                    else if (op == C_M) { len22 += l; ci++; }
-                    else if (op == C_I) { len22 += l; len_dif2 -= l; b += l; ++ci; }
-                    else if (op == C_D) { len_dif2 += l; b += l; ++ci; }
+                    const int op = e2 & 0xf, l = e2 >> 4;
+                    if (op == C_M && l > md) { e2 -= md << 4; len22 += md; break; }
+                    else if (op == C_M) { len22 += l; ci++; e2 = HP_MF_E2(ci); }
+                    else if (op == C_I) { len22 += l; len_dif2 -= l; b += l; ++ci; e2 = HP_MF_E2(ci); }
+                    else if (op == C_D) { len_dif2 += l; b += l; ++ci; e2 = HP_MF_E2(ci); }
                     else { right = -1; break; }
                 }
             }
@@ -109,22 +152,35 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
             if (!cig_alloc(cx, bd, len1 + len2 + 8)) { ok = false; break; }
             ksw_global(cx, len2, seq_fwd(r.cur_read + read_start - 1), len1, seq_fwd(seq1), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, b, &bd);
             if (bd.n == 0) { cx.status |= ST_REFEXIT; ok = false; break; }    // the reference dereferences an empty CIGAR here
+            {   // its first and last element, in one trip
+                wv::Lane<int> fl;
+                WAVE_FOR(l) { fl[l] = l < 2 ? (int)((const HP_G cig_t *)bd.c)[l ? bd.n - 1 : 0] : 0; }
+                bd_first = wv::bcast(fl, 0); bd_last = wv::bcast(fl, 1);
+            }
             bool stop = false;
-            if ((bd.c[0] & 0xf) == C_M) left = 0;
-            else if (c1.n == 0 || left < 0) stop = true;
+            if ((bd_first & 0xf) == C_M) left = 0;
+            else if (n1 == 0 || left < 0) stop = true;
             if (!stop) {
-                if ((bd.c[bd.n - 1] & 0xf) == C_M) right = 0;
+                if ((bd_last & 0xf) == C_M) right = 0;
                 else if (ci == c2_n || right < 0) stop = true;
             }
             if (stop || left + right == 0) break;
             arena_release(cx.tmp, m2);           // drop this round's window + CIGAR, try a longer flank
         }
-        if (ok) { cig_pushv(cx, c1, bd.c, bd.n); cig_pushv(cx, c1, c2 + ci, c2_n - ci); }
+#undef HP_MF_E1
+#undef HP_MF_E2
+        if (ok) {
+            c1.n = n1;
+            if (n1 > 0) ((HP_G cig_t *)c1.c)[n1 - 1] = e1;                      // the top of c1 as the walk left it (the push may merge into it and store it again)
+            const int last = cig_pushv_known(cx, c1, e1, bd.c, bd.n, bd_first);
+            cig_pushv_known(cx, c1, last, _c2 + ci, c2_n - ci, e2);
+        }
         arena_release(cx.tmp, mark);
         if (!ok) return false;
     }
     *c1_refend += c2_reflen;
     *c1_readend += c2_readlen;
+    HP_TADD_FILL(cx, 16, tmf_);
     return true;
 }
 
@@ -447,7 +503,11 @@ HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &o
     const int mm = S.n - j;
     if (n1 + mm > res.cig.cap) ovf = true;
     else if (mm > 0) {
+#ifdef HP_EXP_NO_COPYLOAD      // experiment only (wrong results): the appended words are not loaded
+        if (S.p) { for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = i == mm - 1 ? S.last : S.first; } } }
+#else
         if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
+#endif
         else dst[n1] = S.first;
         m.n = n1 + mm; tail = S.last;
     }
@@ -470,6 +530,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
     long long cs_ = 0;                               // seed-CIGAR words appended (accounting, flushed once)
     MergeLoc ml; mloc_in(ml, res);                   // the record's running state, in registers
     for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
+        HP_T0(tg64_);
         // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
         WAVE_FOR(l) {
             const int t = t0 + l;
@@ -502,6 +563,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
         wv::Lane<int> V[16];
         WAVE_FOR(l) { for (int k = 0; k < 16; ++k) V[k][l] = g_pl[k * 64 + l]; }
         const int cnt = nfr - t0 < 64 ? nfr - t0 : 64;
+        HP_TADD_FILL(cx, 22, tg64_);
         for (int q = 0; q < cnt && ok; ++q) {
             const int t = t0 + q, f = strand == 1 ? f0 + nfr - 1 - t : f0 + t;
             // frag_extend, :332-410
@@ -514,7 +576,9 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
             } else {
                 mloc_out(ml, res);
                 wv::sync();
+                HP_T0(tfm_);
                 ok = frag_extend_multi(r, F, f, res);
+                HP_TADD_FILL(cx, 20, tfm_);
                 wv::sync();
                 mloc_in(ml, res);
                 tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
@@ -525,7 +589,9 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
             if (kind == 3) {
                 mloc_out(ml, res);
                 wv::sync();
+                HP_T0(tsm_);
                 ok = split_mapping(r, F, f, strand == 1 ? f - 1 : f + 1, res);
+                HP_TADD_FILL(cx, 18, tsm_);
                 wv::sync();
                 mloc_in(ml, res);
                 tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
@@ -769,9 +835,25 @@ HP_NOINL bool res_aux(ReadCtx &r, LineRes &la)
                 il[l] = op == C_I ? len : 0; dl[l] = op == C_D ? len : 0; io[l] = op == C_I; dq[l] = op == C_D;
             }
             if (wv::ballot(isbad) != 0) { bad = true; break; }
-            const int maxlen = wv::reduce_max(mlen);
-            for (int b0 = 0; b0 < maxlen; ++b0) {
-                WAVE_FOR(l) { if (b0 < mlen[l]) mm[l] += gread[read_i + rs[l] + b0] != gref[ref_i + fs[l] + b0]; }
+            // The mismatches of the M runs, 64 read bases at a time, one per lane: a lane finds the element its base lies in by a binary
+            // search over the elements' read ends (lane gathers, no memory), and with it the reference base that faces it.  (One lane
+            // per M run, a base per trip, was as many dependent loads as the longest run of the 64 has bases.)
+            {
+                wv::Lane<int> rend, delta, ism;
+                WAVE_FOR(l) { rend[l] = rs[l] + rinc[l]; delta[l] = fs[l] - rs[l]; ism[l] = mlen[l] > 0; }
+                for (int q0 = 0; q0 < r_tot; q0 += 64) {
+                    wv::Lane<int> e;
+                    WAVE_FOR(l) { e[l] = 0; }
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        wv::Lane<int> probe;
+                        WAVE_FOR(l) { probe[l] = e[l] + step - 1; }
+                        const wv::Lane<int> v = wv::gather(rend, probe);
+                        WAVE_FOR(l) { if (v[l] <= q0 + l) e[l] += step; }        // e = elements that end at or before this base
+                    }
+                    const wv::Lane<int> dv = wv::gather(delta, e), mv = wv::gather(ism, e);
+                    WAVE_FOR(l) { const int q = q0 + l; if (q < r_tot && mv[l]) mm[l] += gread[read_i + q] != gref[ref_i + q + dv[l]]; }
+                }
             }
             const int mms = wv::reduce_sum(mm);
             n_mm += mms; n_m += wv::reduce_sum(mlen) - mms;

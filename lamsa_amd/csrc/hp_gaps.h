@@ -570,7 +570,7 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
     wv::sync();
     HP_LSTAMP(16);
 #if defined(HP_PROF) && !defined(HP_PROF_TRACK)
-    if (r.prof) { r.prof[21] += 1; r.prof[12] += A; }
+    if (HP_PROF_CHAIN_ON && r.prof) { r.prof[21] += 1; r.prof[12] += A; }
 #endif
     // Most lines of a read against a repeat-rich genome are a few hits of neighbouring seed slots at some repeat copy: no gap at all.
     {
@@ -587,7 +587,7 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
             arena_release(cx.tmp, mark);
             HP_LSTAMP(17);
 #if defined(HP_PROF) && !defined(HP_PROF_TRACK)
-            if (r.prof) r.prof[22] += 1;
+            if (HP_PROF_CHAIN_ON && r.prof) r.prof[22] += 1;
 #endif
             return A;
         }
@@ -625,7 +625,7 @@ HP_HOT int line_build(ReadCtx &r, int max_node, int32_t *ln, int32_t *_line, int
     wv::sync();
     HP_LSTAMP(17);
 #if defined(HP_PROF) && !defined(HP_PROF_TRACK)
-    if (r.prof) { r.prof[23] += G; if (G < HP_GAP_MIN) r.prof[54] += G; r.prof[55] += 1; }
+    if (HP_PROF_CHAIN_ON && r.prof) { r.prof[23] += G; if (G < HP_GAP_MIN) r.prof[54] += G; r.prof[55] += 1; }
 #endif
     // ---- the mini DPs.  By cluster when the read's hits have been clustered (gaps_by_cluster above); else every gap scans its own seed range:
     int pool_n = 0, d_score = 0, d_NM = 0;

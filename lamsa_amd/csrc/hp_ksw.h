@@ -38,24 +38,32 @@ HP_INL void z_put(HP_L uint8_t *LZ, int row, int n_col, int c, int dir) {       
 // wave's HBM slab (gz).  Cells the forward pass never wrote read as 255 (src/ksw.c:707): outside the row's window
 // always; inside it the LDS matrix holds 255 where the band did not reach, and for the HBM matrix of the extension
 // routine the per-row band limits (rowb) say which cells were written.
-HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out)
+HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out, int pk_stride = 0)
 {
+    pk_stride = wv::uni(pk_stride);                                        // > 0: the HBM matrix of the two-columns-per-lane routine, a nibble per cell, rows of pk_stride bytes indexed by the column itself
     const HP_G uint8_t *gz = (const HP_G uint8_t *)wv::uni64((long long)z);
     const HP_G hp_v2i *grb = (const HP_G hp_v2i *)wv::uni64((long long)rowb);     // HBM matrix of the extension routine: [beg, end) of every row
     HP_G cig_t *oc = (HP_G cig_t *)wv::uni64((long long)out.c);
     const int cap = wv::uni(out.cap);
     n_col = wv::uni(n_col); w = wv::uni(w); i = wv::uni(i); k = wv::uni(k);
     // the run being built stays in registers; finished runs are stored and never read back (_push_cigar0 semantics)
+    // The first 64 finished runs stay in a lane register (run k in lane k): a CIGAR of at most 64 elements -- nearly every one -- is stored
+    // once, already inverted, and never read back.
     int n = 0, pend = 0, which = 0;
     bool have = false;
+    wv::Lane<int> runs;
+    WAVE_FOR(l) { runs[l] = 0; }
+#define HP_BT_OUT(v_) do { if (n < cap) { if (n < 64) wv::setlane(runs, n, (v_)); else { if (n == 64) { WAVE_FOR(l) { oc[l] = runs[l]; } } oc[n] = (v_); } ++n; } else cx.status |= ST_OVERFLOW; } while (0)
 #define HP_BT_PUSH(w_) do { const int v_ = (w_); if (have && (pend & 0xf) == (v_ & 0xf)) pend += (v_ >> 4) << 4; \
-        else { if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; } pend = v_; have = true; } } while (0)
+        else { if (have) HP_BT_OUT(pend); pend = v_; have = true; } } while (0)
     const int zstride = HP_ZSTRIDE(n_col);
     // one cell of the matrix as the reference's byte; 255 = never written (outside the window or the band)
 #define HP_BT_CELL(ii, kk, cell_) do { const int off_ = (ii) > w ? (ii) - w : 0; cell_ = 255; \
         if ((kk) >= off_ && (kk) - off_ < n_col) { \
             if (lz) { const int c_ = (kk) - off_, nib_ = (lz[(ii) * zstride + (c_ >> 1)] >> ((c_ & 1) << 2)) & 0xf; \
                       cell_ = nib_ == 0xf ? 255 : ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)); } \
+            else if (pk_stride) { const int nib_ = (gz[(long)(ii) * pk_stride + ((kk) >> 1)] >> (((kk) & 1) << 2)) & 0xf; const hp_v2i be_ = grb[(ii)]; \
+                   cell_ = ((kk) >= be_.x && (kk) < be_.y) ? ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)) : 255; } \
             else { const int zc_ = gz[(long)(ii) * n_col + ((kk) - off_)]; \
                    if (grb) { const hp_v2i be_ = grb[(ii)]; cell_ = ((kk) >= be_.x && (kk) < be_.y) ? zc_ : 255; } else cell_ = zc_; } } } while (0)
     while (i >= 0 && k >= 0) {
@@ -84,12 +92,16 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
     }
     if (i >= 0) HP_BT_PUSH((i + 1) << 4 | C_D);
     if (k >= 0) HP_BT_PUSH((k + 1) << 4 | C_I);
-    if (have) { if (n < cap) oc[n++] = pend; else cx.status |= ST_OVERFLOW; }
+    if (have) HP_BT_OUT(pend);
 #undef HP_BT_PUSH
+#undef HP_BT_OUT
 #undef HP_BT_CELL
-    wv::sync();
-    for (int b0 = 0; b0 < n / 2; b0 += 64) {                               // _invert_cigar, lane-parallel
-        WAVE_FOR(l) { const int a = b0 + l; if (a < n / 2) { const cig_t x = oc[a], y = oc[n - 1 - a]; oc[a] = y; oc[n - 1 - a] = x; } }
+    if (n <= 64) { WAVE_FOR(l) { if (l < n) oc[n - 1 - l] = runs[l]; } }   // _invert_cigar on the way out
+    else {
+        wv::sync();
+        for (int b0 = 0; b0 < n / 2; b0 += 64) {                           // _invert_cigar, lane-parallel
+            WAVE_FOR(l) { const int a = b0 + l; if (a < n / 2) { const cig_t x = oc[a], y = oc[n - 1 - a]; oc[a] = y; oc[n - 1 - a] = x; } }
+        }
     }
     wv::sync();
     out.n = n;
@@ -687,13 +699,17 @@ HP_NOINL ExtRes ksw_extend_reg(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w,
     return er;
 }
 
-// ksw_extend_core for queries of 63 .. HP_REG2_QMAX bases: the row in TWO registers per lane -- column j of the reference's eh[] array is
-// lane (j & 63) of register set (j >> 6) -- so that a row is one pass over both sets instead of two trips through the LDS row with the
-// scalar bookkeeping of a tile each (~1 050 instructions per row there, ~450 here; the junction extensions of a noisy read, 65-125
-// query bases, are 38 % of the fill kernel's DP time).  Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg.
-#define HP_REG2_QMAX 126
+// ksw_extend_core for queries of 63 .. 64 * NS - 2 bases: the row in NS registers per lane -- column j of the reference's eh[] array is
+// lane (j & 63) of register set (j >> 6) -- so that a row is one pass over the sets instead of NS trips through the LDS row with the
+// scalar bookkeeping of a tile each (~1 050 instructions per row there for two tiles, ~450 here; the junction extensions of a noisy
+// read, 75 .. 250 query bases, are most of the fill kernel's DP time).  The sets are walked in order: the F scan of a set is topped up
+// with the maximum of the sets before it, and only H of the row survives a set's pass, so the live registers are three per set.
+// Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg.
+#define HP_REGN_SETS 4
+#define HP_REGN_QMAX(ns) (64 * (ns) - 2)
 HP_INL unsigned long long lt_mask64(int x) { return x <= 0 ? 0ull : (x >= 64 ? ~0ull : ((1ull << x) - 1)); }      // bits below x
-HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
+template <int NS>
+HP_NOINL ExtRes ksw_extend_regn(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
     long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
@@ -719,17 +735,17 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
     const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
     const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
-    wv::Lane<int> Hs[2], Es[2], qb[2], tl;
+    wv::Lane<int> Hs[NS], Es[NS], hcur[NS], qbp, je0, tl;
+    WAVE_FOR(l) { qbp[l] = 0; je0[l] = l * e_ins; tl[l] = 4; }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NS; ++c) {
         WAVE_FOR(l) {                                                      // first row, :692-694
             const int j = 64 * c + l;
             Hs[c][l] = j == 0 ? h0 : (j == 1 ? h1v : ((j <= qlen && h1v - (j - 2) * e_ins > e_ins) ? h1v - (j - 1) * e_ins : 0));
             Es[c][l] = 0;
-            qb[c][l] = j < qlen ? (int)gq[(long)j * qs] : 4;
+            qbp[l] |= (j < qlen ? (int)gq[(long)j * qs] : 4) << (3 * c);   // the query codes of a lane's columns, three bits per set
         }
     }
-    WAVE_FOR(l) { tl[l] = 4; }
     int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
     int beg = 0, end = qlen;
     bool stop_rows = false;
@@ -749,33 +765,31 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
             int h1_init;
             if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
             else h1_init = 0;
-            wv::Lane<int> m[2], key[2], hcur[2];
+            const int fbase = beg * e_ins;                                 // F(i,beg) = 0 carried along the row: (beg - j) * e_ins at column j
+            int carry = HP_SCAN_IDENT;                                     // maximum of the scan keys of the sets below
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NS; ++c) {
+                const int jc = 64 * c * e_ins;
+                wv::Lane<int> m, key;
                 WAVE_FOR(l) {
                     const int j = 64 * c + l;
-                    const int hm = Hs[c][l];
-                    const int M = hm ? hm + HP_SUB(ti, qb[c][l]) : 0;      // :737
+                    const int hm = Hs[c][l], qb = (qbp[l] >> (3 * c)) & 7;
+                    const int M = hm ? hm + HP_SUB(ti, qb) : 0;            // :737
                     int tt = M - oe_ins; tt = tt > 0 ? tt : 0;
-                    m[c][l] = M;
-                    key[c][l] = (j >= beg && j < end) ? tt + j * e_ins : HP_SCAN_IDENT;
+                    m[l] = M;
+                    key[l] = (j >= beg && j < end) ? tt + je0[l] + jc : HP_SCAN_IDENT;
                 }
-            }
-            // F along the row: an exclusive prefix maximum over the 128 columns = the scan of each set, the second one topped up with
-            // the maximum of the whole first set
-            const int top0 = wv::reduce_max(key[0]);
-            wv::scan_max_excl(key[0], HP_SCAN_IDENT);
-            wv::scan_max_excl(key[1], HP_SCAN_IDENT);
-            WAVE_FOR(l) { key[1][l] = key[1][l] > top0 ? key[1][l] : top0; }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
+                // F along the row: an exclusive prefix maximum over all the columns = the scan of each set, topped up with the maximum
+                // of the sets before it
+                const int top = wv::scan_max_excl_top(key, HP_SCAN_IDENT);
                 WAVE_FOR(l) {
                     const int j = 64 * c + l;
                     hcur[c][l] = -1;
                     if (j >= beg && j < end) {
-                        int f = 0 - (j - beg) * e_ins;                     // F(i,beg) = 0 carried along the row
-                        if (j > beg) { const int g = key[c][l] - (j - 1) * e_ins; f = g > f ? g : f; }
-                        int M = m[c][l], ee = Es[c][l], h, tt;
+                        const int je = je0[l] + jc;
+                        int f = fbase - je;
+                        if (j > beg) { const int kk = key[l] > carry ? key[l] : carry; const int g = kk - je + e_ins; f = g > f ? g : f; }
+                        int M = m[l], ee = Es[c][l], h, tt;
                         int dir = M > ee ? 0 : 1; h = M > ee ? M : ee;      // ties: E over M   :738-739
                         dir = h > f ? dir : 2;    h = h > f ? h : f;        //       F over both :740-741
                         tt = M - oe_del; tt = tt > 0 ? tt : 0; ee -= e_del;
@@ -787,36 +801,56 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
                         if (zl) z_put(LZ, i, n_col, j - d_beg, dir); else gz[(long)i * n_col + (j - d_beg)] = (uint8_t)dir;
                     }
                 }
+                carry = top > carry ? top : carry;
             }
             // row maximum, last j among equals (:743-744)
             int mrow = 0, mj = -1;
             {
-                const int hm0 = wv::reduce_max(hcur[0]), hm1 = wv::reduce_max(hcur[1]);
-                const int hmax = hm1 > hm0 ? hm1 : hm0;
+                wv::Lane<int> hm;
+                WAVE_FOR(l) {
+                    int v = hcur[0][l];
+#pragma unroll
+                    for (int c = 1; c < NS; ++c) v = hcur[c][l] > v ? hcur[c][l] : v;
+                    hm[l] = v;
+                }
+                const int hmax = wv::reduce_max(hm);
                 if (hmax >= 0) {
-                    wv::Lane<int> eq;
                     mrow = hmax;
-                    if (hm1 >= hm0) { WAVE_FOR(l) eq[l] = hcur[1][l] == hmax; mj = 64 + 63 - __builtin_clzll(wv::ballot(eq)); }
-                    else { WAVE_FOR(l) eq[l] = hcur[0][l] == hmax; mj = 63 - __builtin_clzll(wv::ballot(eq)); }
+                    bool got = false;
+#pragma unroll
+                    for (int c = NS - 1; c >= 0; --c) {
+                        if (got) continue;
+                        wv::Lane<int> eq;
+                        WAVE_FOR(l) eq[l] = hcur[c][l] == hmax;
+                        const unsigned long long b = wv::ballot(eq);
+                        if (b) { mj = 64 * c + 63 - __builtin_clzll(b); got = true; }
+                    }
                 }
             }
             int h_last = h1_init;                                          // H(i,end-1), or the first-column value when the row is empty
-            if (beg < end) h_last = end - 1 < 64 ? wv::bcast(hcur[0], end - 1) : wv::bcast(hcur[1], end - 1 - 64);
+            if (beg < end) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { WAVE_FOR(l) { if (hcur[c][l] < 0) hcur[c][l] = 0; } }
-            const int carry = wv::bcast(hcur[0], 63);
-            wv::shr1(hcur[1], carry);                                      // eh[j+1].h = H(i,j), across the two sets
-            wv::shr1(hcur[0], 0);
-            wv::Lane<int> nz[2];
+                for (int c = 0; c < NS; ++c) if (((end - 1) >> 6) == c) h_last = wv::bcast(hcur[c], (end - 1) & 63);
+            }
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NS; ++c) { WAVE_FOR(l) { if (hcur[c][l] < 0) hcur[c][l] = 0; } }
+#pragma unroll
+            for (int c = NS - 1; c >= 0; --c) {                            // eh[j+1].h = H(i,j), across the sets
+                const int below = c > 0 ? wv::bcast(hcur[c > 0 ? c - 1 : 0], 63) : 0;
+                wv::shr1(hcur[c], below);
+            }
+            unsigned long long nzm[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                wv::Lane<int> nz;
                 WAVE_FOR(l) {
                     const int j = 64 * c + l;
                     if (beg < end) { if (j == beg) Hs[c][l] = h1_init; else if (j > beg && j <= end) Hs[c][l] = hcur[c][l]; }
                     else if (j == end) Hs[c][l] = h1_init;                 // eh[end].h = h1 when the row is empty (:758)
                     if (j == end) Es[c][l] = 0;                            // :758
-                    nz[c][l] = j >= beg && j <= end && (Hs[c][l] != 0 || Es[c][l] != 0);
+                    nz[l] = j >= beg && j <= end && (Hs[c][l] != 0 || Es[c][l] != 0);
                 }
+                nzm[c] = wv::ballot(nz);
             }
             const int jj = beg < end ? end : beg;                          // loop variable j after the row
             if (jj == qlen) {                                              // :759-762
@@ -831,11 +865,19 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
             }
             // shrink the band for the next row, :775-778
             {
-                const unsigned long long nz0 = wv::ballot(nz[0]), nz1 = wv::ballot(nz[1]);
-                const unsigned long long lo0 = nz0 & lt_mask64(end), lo1 = nz1 & lt_mask64(end - 64);          // non-zero indices in [beg, end)
-                const int nb = lo0 ? __builtin_ctzll(lo0) : (lo1 ? 64 + __builtin_ctzll(lo1) : end);
-                const unsigned long long up0 = nz0 & ~lt_mask64(nb), up1 = nz1 & ~lt_mask64(nb - 64);          // non-zero indices in [nb, end]
-                const int jl = up1 ? 64 + 63 - __builtin_clzll(up1) : (up0 ? 63 - __builtin_clzll(up0) : nb - 1);
+                int nb = end, jl;                                          // first non-zero index in [beg, end), else end
+                bool got = false;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const unsigned long long lo = nzm[c] & lt_mask64(end - 64 * c);
+                    if (!got && lo) { nb = 64 * c + __builtin_ctzll(lo); got = true; }
+                }
+                jl = nb - 1; got = false;                                  // last non-zero index in [nb, end], else nb - 1
+#pragma unroll
+                for (int c = NS - 1; c >= 0; --c) {
+                    const unsigned long long up = nzm[c] & ~lt_mask64(nb - 64 * c);
+                    if (!got && up) { jl = 64 * c + 63 - __builtin_clzll(up); got = true; }
+                }
                 beg = nb;
                 end = jl + 2 < qlen ? jl + 2 : qlen;
             }
@@ -852,6 +894,252 @@ HP_NOINL ExtRes ksw_extend_reg2(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     return er;
 }
 
+// ksw_extend_core with TWO columns per lane, scores as int16 pairs (packed math, wave.h pk::): column j of the reference's eh[] array is
+// half (j & 1) of lane ((j >> 1) & 63) of register set (j >> 7).  Everything a row does per register set -- the F scan, the reductions,
+// the ballots of the band logic, the store of the direction cells -- serves 128 columns instead of 64, and a cell costs half a packed
+// instruction where it cost a whole one: a row of a 100-base junction is ~200 instructions instead of ~400 (ksw_extend_regn<2>).  The
+// fill kernel is bound by instruction issue (VALU 68 %, scalar 60 % busy: profiles/r03_fill_issue.txt), so that is time.
+// Comparisons become sign bits of differences; every quantity is a sum of a few scores and penalties, and ksw_extend() only sends a job
+// here when none of them can leave +-16 000 (pk_extend_ok).  Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg.
+// The direction matrix is a nibble per cell in the wave's HBM slab, two cells per byte, a row = 64 * NS bytes indexed by the column.
+#define HP_PK_QMAX(ns) (128 * (ns) - 2)
+#ifndef HP_PK_RT
+#define HP_PK_RT 1                          // the tests' CPU build switches the routine off to reach the int32 register sets behind it
+#endif
+#define HP_PK_IDENT (-16000)
+HP_INL bool pk_extend_ok(const lamsa_hp_para *P, int qlen, int h0)
+{
+    const int mx = P->match > P->mis ? P->match : P->mis;
+    const int pen = (P->ins_ext_o > P->del_ext_o ? P->ins_ext_o : P->del_ext_o) + (P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e);
+    const int ext = P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e;
+    return mx > 0 && mx < 256 && pen >= 0 && pen < 4000 && P->ins_ext_e >= 0 && P->del_ext_e >= 0 && P->ins_ext_o >= 0 && P->del_ext_o >= 0 &&
+           (long long)h0 + (long long)qlen * mx < 15000 && (long long)(qlen + 2) * ext < 8000;
+}
+template <int NS>
+HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
+{
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
+    HP_T0(te0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
+    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
+    const size_t mark = arena_mark(cx.tmp);
+    uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1);
+    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!z || !rowb) { arena_release(cx.tmp, mark); return er; }
+#ifdef HP_PROF
+    if (cx.prof) { cx.prof[52] += (long long)zs * tlen; cx.prof[53] += 1; }
+#endif
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
+    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+    // packed constants (both halves the same value)
+    const int OEI = pk::rep(oe_ins), OED = pk::rep(oe_del), EI = pk::rep(e_ins), ED = pk::rep(e_del);
+    const int DSC = pk::rep(sc_match - sc_mis), MIS = pk::rep(sc_mis), IDENT = pk::rep(HP_PK_IDENT);
+    wv::Lane<int> Hs[NS], Es[NS], qoh[NS], qN[NS], hcur[NS], jp0, jep0, tl;
+    WAVE_FOR(l) { jp0[l] = pk::pack(2 * l, 2 * l + 1); jep0[l] = pk::pack(2 * l * e_ins, (2 * l + 1) * e_ins); tl[l] = 4; }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        WAVE_FOR(l) {                                                      // first row, :692-694
+            int hv[2], oh = 0, nn = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int j = 128 * c + 2 * l + b;
+                hv[b] = j == 0 ? h0 : (j == 1 ? h1v : ((j <= qlen && h1v - (j - 2) * e_ins > e_ins) ? h1v - (j - 1) * e_ins : 0));
+                const int code = j < qlen ? (int)gq[(long)j * qs] : 4;
+                if (code < 4) oh |= 1 << (code + 16 * b); else nn |= 0xffff << (16 * b);
+            }
+            Hs[c][l] = pk::pack(hv[0], hv[1]); Es[c][l] = 0;
+            qoh[c][l] = oh; qN[c][l] = nn;                                 // the query base of a column as one bit of four; N (and beyond the query): score -1
+        }
+    }
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            if (beg < i - w) beg = i - w;                                  // :718-720
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            cells_ += end > beg ? end - beg : 0;
+            { WAVE_FOR(l) { if (l < 2) growb[2 * i + l] = l ? end : beg; } }
+            int h1_init;
+            if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+            else h1_init = 0;
+            const int tsh = ti & 3, tN = ti > 3 ? -1 : 0;                   // a target N scores -1 against everything
+            const int BEG = pk::rep(beg), END = pk::rep(end), FB = pk::rep(beg * e_ins), H1 = pk::rep(h1_init);
+            int carry = HP_PK_IDENT;                                       // maximum of the scan keys of the sets below
+            wv::Lane<int> inb[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                wv::Lane<int> key, klo, tI, M;
+                WAVE_FOR(l) {
+                    const int jp = pk::add(jp0[l], pk::rep(128 * c));
+                    inb[c][l] = pk::neg_mask(pk::sub(jp, END)) & ~pk::neg_mask(pk::sub(jp, BEG));      // beg <= j < end, per half
+                    const int eq = (qoh[c][l] >> tsh) & 0x00010001;
+                    const int S = pk::add(pk::mul(eq, DSC), MIS) | qN[c][l] | tN;                       // HP_SUB(ti, qb)
+                    const int hm = Hs[c][l];
+                    const int m = pk::mul(pk::add(hm, S), pk::min_u(hm, 0x00010001));                   // hm ? hm + S : 0   (:737; hm is never negative)
+                    const int t1 = pk::max(pk::sub(m, OEI), 0);
+                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
+                    const int k = pk::sel(inb[c][l], pk::add(t1, jep), IDENT);
+                    M[l] = m; tI[l] = t1;
+                    klo[l] = pk::lo(k);
+                    const int kh = pk::hi(k);
+                    key[l] = klo[l] > kh ? klo[l] : kh;
+                }
+                // F along the row: an exclusive prefix maximum over the columns = the scan over the lanes' maxima, the second column of a
+                // lane topped up with the first, every set with the maximum of the sets before it
+                const int top = wv::scan_max_excl_top(key, HP_PK_IDENT);
+                WAVE_FOR(l) {
+                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
+                    const int s0 = key[l] > carry ? key[l] : carry, s1 = s0 > klo[l] ? s0 : klo[l];
+                    const int pre = pk::pack(s0, s1);
+                    int f = pk::max(pk::add(pk::sub(pre, jep), EI), pk::sub(FB, jep));                   // F(i,beg) = 0 carried along the row
+                    const int m = M[l];
+                    int ee = Es[c][l];
+                    const int m1 = pk::neg_mask(pk::sub(ee, m));                                        // M > E
+                    int h = pk::max(m, ee);                                                             // ties: E over M   :738-739
+                    const int m2 = pk::neg_mask(pk::sub(f, h));                                         // h > F
+                    int d = pk::sel(m2, ~m1 & 0x00010001, 0x00020002);                                  //       F over both :740-741
+                    h = pk::max(h, f);
+                    const int tD = pk::max(pk::sub(m, OED), 0);
+                    ee = pk::sub(ee, ED);
+                    d |= pk::neg_mask(pk::sub(tD, ee)) & 0x00040004;                                    // E extends, :745-750
+                    ee = pk::max(ee, tD);
+                    f = pk::sub(f, EI);
+                    d |= pk::neg_mask(pk::sub(tI[l], f)) & 0x00080008;                                  // F extends, :751-755
+                    const int in = inb[c][l];
+                    Es[c][l] = pk::sel(in, ee, Es[c][l]);
+                    hcur[c][l] = pk::sel(in, h, -1);
+                    if (in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
+                }
+                carry = top > carry ? top : carry;
+            }
+            // row maximum, last j among equals (:743-744)
+            int mrow = 0, mj = -1;
+            {
+                wv::Lane<int> hm;
+                WAVE_FOR(l) {
+                    int v = -1;
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) { const int a = pk::lo(hcur[c][l]), b = pk::hi(hcur[c][l]); v = a > v ? a : v; v = b > v ? b : v; }
+                    hm[l] = v;
+                }
+                const int hmax = wv::reduce_max(hm);
+                if (hmax >= 0) {
+                    mrow = hmax;
+                    bool got = false;
+#pragma unroll
+                    for (int c = NS - 1; c >= 0; --c) {
+                        if (got) continue;
+                        wv::Lane<int> e0, e1;
+                        WAVE_FOR(l) { e0[l] = pk::lo(hcur[c][l]) == hmax; e1[l] = pk::hi(hcur[c][l]) == hmax; }
+                        const unsigned long long b0 = wv::ballot(e0), b1 = wv::ballot(e1);
+                        if (b0 | b1) {
+                            const int j0 = b0 ? 2 * (63 - __builtin_clzll(b0)) : -1, j1 = b1 ? 2 * (63 - __builtin_clzll(b1)) + 1 : -1;
+                            mj = 128 * c + (j0 > j1 ? j0 : j1); got = true;
+                        }
+                    }
+                }
+            }
+            int h_last = h1_init;                                          // H(i,end-1), or the first-column value when the row is empty
+            if (beg < end) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) if (((end - 1) >> 7) == c) { const int v = wv::bcast(hcur[c], ((end - 1) >> 1) & 63); h_last = ((end - 1) & 1) ? pk::hi(v) : pk::lo(v); }
+            }
+            // eh[j+1].h = H(i,j): the row one column up, across halves, lanes and sets; columns the row did not compute arrive as -1
+            unsigned long long nz0[NS], nz1[NS];
+#pragma unroll
+            for (int c = NS - 1; c >= 0; --c) {
+                const int below = c > 0 ? wv::bcast(hcur[c > 0 ? c - 1 : 0], 63) : -1;
+                wv::Lane<int> dn = hcur[c];
+                wv::shr1(dn, below);
+                wv::Lane<int> z0, z1;
+                WAVE_FOR(l) {
+                    const int hsh = pk::shift_up(hcur[c][l], dn[l]);
+                    const int in = inb[c][l];
+                    int hs = Hs[c][l], es = Es[c][l];
+                    if (beg < end) {
+                        const int upd = ~pk::neg_mask(hsh);                // beg < j <= end
+                        hs = pk::sel(upd, hsh, hs);
+                        hs = pk::sel(in & ~upd, H1, hs);                   // j == beg
+                        es &= ~(upd & ~in);                                // eh[end].e = 0, :758
+                        const int live = (hs | es) & (in | upd);
+                        z0[l] = (live & 0xffff) != 0; z1[l] = ((unsigned)live >> 16) != 0;
+                    } else {                                               // the row is empty: eh[end].h = h1, eh[end].e = 0 (:758)
+                        const int jp = pk::add(jp0[l], pk::rep(128 * c));
+                        const int at = ~(pk::neg_mask(pk::sub(jp, END)) | pk::neg_mask(pk::sub(END, jp)));      // j == end
+                        hs = pk::sel(at, H1, hs); es &= ~at;
+                        const int live = (hs | es) & at;
+                        z0[l] = (live & 0xffff) != 0; z1[l] = ((unsigned)live >> 16) != 0;
+                    }
+                    Hs[c][l] = hs; Es[c][l] = es;
+                }
+                nz0[c] = wv::ballot(z0); nz1[c] = wv::ballot(z1);          // eh[j] not zero, for j in [beg, end]: even columns, odd columns
+            }
+            const int jj = beg < end ? end : beg;                          // loop variable j after the row
+            if (jj == qlen) {                                              // :759-762
+                max_ie = gscore > h_last ? max_ie : i;
+                gscore = gscore > h_last ? gscore : h_last;
+            }
+            if (mrow == 0) { stop_rows = true; break; }                    // :763
+            if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+            else if (zdrop > 0) {                                          // :767-773
+                if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
+                else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
+            }
+            // shrink the band for the next row, :775-778
+            {
+                int nb = end, jl;                                          // first non-zero index in [beg, end), else end
+                bool got = false;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    const int e_c = end - 128 * c;                          // columns of this set below `end`: even ones 2l < e_c, odd ones 2l + 1 < e_c
+                    const unsigned long long l0 = nz0[c] & lt_mask64((e_c + 1) >> 1), l1 = nz1[c] & lt_mask64(e_c >> 1);
+                    if (!got && (l0 | l1)) {
+                        const int a = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
+                        nb = 128 * c + (a < b ? a : b); got = true;
+                    }
+                }
+                jl = nb - 1; got = false;                                  // last non-zero index in [nb, end], else nb - 1
+#pragma unroll
+                for (int c = NS - 1; c >= 0; --c) {
+                    const int n_c = nb - 128 * c;                           // columns of this set from `nb` on: even ones 2l >= n_c, odd ones 2l + 1 >= n_c
+                    const unsigned long long u0 = nz0[c] & ~lt_mask64((n_c + 1) >> 1), u1 = nz1[c] & ~lt_mask64(n_c >> 1);
+                    if (!got && (u0 | u1)) {
+                        const int a = u0 ? 2 * (63 - __builtin_clzll(u0)) : -1, b = u1 ? 2 * (63 - __builtin_clzll(u1)) + 1 : -1;
+                        jl = 128 * c + (a > b ? a : b); got = true;
+                    }
+                }
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+            }
+        }
+    }
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out, zs); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
+    return er;
+}
+
 // ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
 HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                       int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
@@ -859,6 +1147,15 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     if (out) out->n = 0;
     if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
     { const int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }             // :549
+    HP_DPLOG(1, qlen, tlen, w, 0);
+#ifdef HP_EXP_NO_GLOBAL   // experiment only (wrong results)
+#ifdef HP_EXP_NO_SMALLGLOBAL
+    if (qlen >= 0)
+#else
+    if (qlen > HP_REG_QMAX)
+#endif
+    { if (out) { const int m = qlen < tlen ? qlen : tlen; if (m) cig_push0(cx, *out, (cig_t)(m << 4) | C_M); if (qlen > m) cig_push0(cx, *out, (cig_t)((qlen - m) << 4) | C_I); if (tlen > m) cig_push0(cx, *out, (cig_t)((tlen - m) << 4) | C_D); } return qlen; }
+#endif
     if (qlen <= HP_REG_QMAX) return ksw_global_reg(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
     if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_global_lds(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
     return ksw_global_wide(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
@@ -1051,9 +1348,20 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
         max_del = max_del > 1 ? max_del : 1;
         w = w < max_del ? w : max_del;
     }
-    const ExtRes er = qlen <= HP_REG_QMAX ? ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out)
-                    : (qlen <= HP_REG2_QMAX ? ksw_extend_reg2(cx, qlen, q, tlen, t, w, h0, out)
-                    : (2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out)));
+    const long long cells0_ = cx.n_cells; (void)cells0_;
+    ExtRes er;
+#ifdef HP_EXP_NO_EXT      // experiment only (wrong results): what the fill costs without the wave-wide extensions
+    if (qlen > HP_REG_QMAX) { er.score = h0 + qlen; er.qle = qlen; er.tle = qlen < tlen ? qlen : tlen; if (out) { out->n = 0; cig_push0(cx, *out, (cig_t)(er.tle << 4) | C_M); if (qlen > er.tle) cig_push0(cx, *out, (cig_t)((qlen - er.tle) << 4) | C_I); } }
+    else
+#endif
+    if (qlen <= HP_REG_QMAX) er = ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out);
+    else if (HP_PK_RT && qlen <= HP_PK_QMAX(2) && pk_extend_ok(cx.P, qlen, h0))
+        { HP_STAT(16); er = qlen <= HP_PK_QMAX(1) ? ksw_extend_pk<1>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_pk<2>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (qlen <= HP_REGN_QMAX(2)) { HP_STAT(17); er = ksw_extend_regn<2>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (qlen <= HP_REGN_QMAX(3) && HP_REGN_SETS >= 3) { HP_STAT(17); er = ksw_extend_regn<3>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (qlen <= HP_REGN_QMAX(4) && HP_REGN_SETS >= 4) { HP_STAT(17); er = ksw_extend_regn<4>(cx, qlen, q, tlen, t, w, h0, out); }
+    else er = 2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out);
+    HP_DPLOG(0, qlen, tlen, w, cx.n_cells - cells0_);
     if (qle) *qle = er.qle;
     if (tle) *tle = er.tle;
     return er.score;

@@ -12,7 +12,13 @@ int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than t
 #define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
 int g_emu_strip = 0;                   // tests: 1 = junction jobs of 65 .. 127 query bases go to the four-jobs-per-wave routine (hp_stripdp.h; off in the product)
 #define HP_STRIP_RT g_emu_strip
-long long g_emu_stat[16];              // path counters (HP_STAT slots of the device sources)
+int g_emu_pk = 1;                      // tests: 0 = extensions of 63 .. 254 query bases take the int32 register sets instead of the packed int16 routine (hp_ksw.h)
+#define HP_PK_RT g_emu_pk
+#include <vector>
+std::vector<long long> g_emu_dplog;    // one record per DP call of the fill: kind (0 extension, 1 global), query, target, band, cells
+int g_emu_dplog_on = 0;
+#define HP_DPLOG(kind, qlen, tlen, w, cells) do { if (g_emu_dplog_on) { g_emu_dplog.push_back(kind); g_emu_dplog.push_back(qlen); g_emu_dplog.push_back(tlen); g_emu_dplog.push_back(w); g_emu_dplog.push_back(cells); } } while (0)
+long long g_emu_stat[32];              // path counters (HP_STAT slots of the device sources)
 #define HP_STAT(i) (++g_emu_stat[i])
 #include "hp_dp_batch.h"
 
@@ -91,7 +97,10 @@ extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab_cap > 0 ? tab_cap : (tab_cap < 0 ? 0 : 1 << 30); g_emu_gap_mcap = mcap > 0 ? mcap : (mcap < 0 ? 0 : 1 << 30); }
 extern "C" void emu_set_strip(int on) { g_emu_strip = on; }
-extern "C" long long emu_stat(int i) { return g_emu_stat[i & 15]; }
+extern "C" void emu_set_pk(int on) { g_emu_pk = on; }
+extern "C" long long emu_stat(int i) { return g_emu_stat[i & 31]; }
+extern "C" void emu_dplog_on(int on) { g_emu_dplog_on = on; g_emu_dplog.clear(); }
+extern "C" long long emu_dplog(long long *buf, long long cap) { long long n = (long long)g_emu_dplog.size(); for (long long i = 0; i < n && i < cap; ++i) buf[i] = g_emu_dplog[i]; return n; }
 extern "C" void emu_stat_reset() { memset(g_emu_stat, 0, sizeof g_emu_stat); }
 extern "C" void emu_set_unit_cap(int cap) { g_emu_unit_cap = cap; }      // tests: force the "too many lines" overflow
 

@@ -43,6 +43,8 @@ HP_INL unsigned long long wall() { return 0; }
 HP_INL int uni(int v) { return v; }
 HP_INL long long uni64(long long v) { return v; }
 HP_INL int bcast(const Lane<int> &x, int src) { return x.v[src]; }
+HP_INL void setlane(Lane<int> &x, int dst, int v) { x.v[dst] = v; }
+HP_INL Lane<int> gather(const Lane<int> &x, const Lane<int> &from) { Lane<int> o; for (int l = 0; l < 64; ++l) o.v[l] = x.v[from.v[l] & 63]; return o; }
 HP_INL unsigned long long ballot(const Lane<int> &p) {
     unsigned long long m = 0;
     for (int l = 0; l < 64; ++l) if (p.v[l]) m |= 1ull << l;
@@ -60,6 +62,15 @@ HP_INL void scan_max_excl(Lane<int> &x, int ident) {
         run = l == 0 ? cur : (cur > run ? cur : run);
     }
 }
+HP_INL int scan_max_excl_top(Lane<int> &x, int ident) {
+    int run = 0;
+    for (int l = 0; l < 64; ++l) {
+        int cur = x.v[l];
+        x.v[l] = l == 0 ? ident : run;
+        run = l == 0 ? cur : (cur > run ? cur : run);
+    }
+    return run;
+}
 
 HP_INL void shr1(Lane<int> &x, int fill) { for (int l = 63; l > 0; --l) x.v[l] = x.v[l - 1]; x.v[0] = fill; }
 // the same inside every 16-lane row
@@ -74,6 +85,23 @@ HP_INL void scan_add_excl(Lane<int> &x) {
 }
 
 }  // namespace wv
+
+// two int16 values per 32-bit word, as the packed math of the device build (VOP3P) computes them
+namespace pk {
+HP_INL int pack(int l, int h) { return (l & 0xffff) | (int)((unsigned)h << 16); }
+HP_INL int lo(int a) { return (int)(short)(a & 0xffff); }
+HP_INL int hi(int a) { return a >> 16; }
+HP_INL int add(int a, int b) { return pack((short)(lo(a) + lo(b)), (short)(hi(a) + hi(b))); }
+HP_INL int sub(int a, int b) { return pack((short)(lo(a) - lo(b)), (short)(hi(a) - hi(b))); }
+HP_INL int max(int a, int b) { return pack(lo(a) > lo(b) ? lo(a) : lo(b), hi(a) > hi(b) ? hi(a) : hi(b)); }
+HP_INL int min_u(int a, int b) { const unsigned al = a & 0xffff, bl = b & 0xffff, ah = (unsigned)a >> 16, bh = (unsigned)b >> 16; return (int)((al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16)); }
+HP_INL int mul(int a, int b) { return pack((short)(lo(a) * lo(b)), (short)(hi(a) * hi(b))); }
+HP_INL int neg_mask(int a) { return pack(lo(a) < 0 ? -1 : 0, hi(a) < 0 ? -1 : 0); }
+HP_INL int rep(int x) { return (x & 0xffff) | (int)((unsigned)x << 16); }
+HP_INL int sel(int mask, int a, int b) { return (a & mask) | (b & ~mask); }
+HP_INL int shift_up(int x, int below) { return (int)(((unsigned)x << 16) | ((unsigned)below >> 16)); }
+}  // namespace pk
+
 
 // single-threaded stand-ins for the two device atomics the kernels use
 static inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }

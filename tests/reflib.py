@@ -223,8 +223,9 @@ def emu_capi_lib():
     return out
 
 
-def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
-    """Run DP jobs through the emulated device code (same kernel sources, CPU lanes)."""
+def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20, pk=True, stats=None):
+    """Run DP jobs through the emulated device code (same kernel sources, CPU lanes).  pk=False: extensions of 63 .. 254 query bases take the
+    int32 register sets instead of the packed int16 routine; stats: a list that receives [calls of the packed routine, of the int32 sets]."""
     import sys
     sys.path.insert(0, ROOT)
     from lamsa_amd.hp import pack_jobs
@@ -240,8 +241,12 @@ def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20):
     st = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(int(cap[n]) + 4, np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     E.emu_dp_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 15 + [C.c_size_t]
+    E.emu_set_pk(1 if pk else 0); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
     E.emu_dp_batch(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), p(kind), p(w), p(h0),
                    p(score), p(qle), p(tle), p(st), p(cn), p(cap), p(cig), slab_bytes)
+    E.emu_set_pk(1)
+    if stats is not None:
+        stats[:] = [int(E.emu_stat(16)), int(E.emu_stat(17))]
     cigars = [cig[cap[i]:cap[i] + cn[i]].tolist() for i in range(n)]
     return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)
 

@@ -63,11 +63,12 @@ def test_emulated_kernels_match_oracle(rt):
 
 
 def _mid_jobs(seed, err):
-    """Queries of 58 .. 132 bases around every length near the limits of the register routines (62 | 63 .. 126 | 127), targets
-    from half to twice as long."""
+    """Queries of 58 .. 260 bases around every length near the limits of the register routines (62 | 63 .. 126 | 127 .. 190 | 191 .. 254
+    | 255), targets from half to twice as long."""
     rng = np.random.default_rng(seed)
     jobs = []
-    for ql in list(range(58, 70)) + list(range(120, 133)) + [int(x) for x in rng.integers(63, 127, 60)]:
+    for ql in (list(range(58, 70)) + list(range(120, 133)) + list(range(186, 196)) + list(range(250, 260)) + [int(x) for x in rng.integers(63, 127, 40)]
+               + [int(x) for x in rng.integers(127, 255, 50)]):
         t = rng.integers(0, 4, size=int(ql * rng.uniform(0.5, 2.0)), dtype=np.uint8)
         q = dpjobs.mutate(rng, t, *err)
         q = np.concatenate([q, rng.integers(0, 4, size=max(0, ql - len(q)), dtype=np.uint8)])[:ql]
@@ -76,13 +77,28 @@ def _mid_jobs(seed, err):
 
 
 @pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
-def test_emulated_extension_with_the_row_in_two_register_sets(rt):
-    """ksw_extend_core for queries of 63 .. 126 bases (ksw_extend_reg2: column j in lane j & 63 of register set j >> 6): extension and
-    two-sided extension, full and narrow bands (the band edge crosses from one set to the other), small and large h0."""
+def test_emulated_extension_with_the_row_in_register_sets(rt):
+    """ksw_extend_core for queries of 63 .. 254 bases (ksw_extend_regn<2 | 3 | 4>: column j in lane j & 63 of register set j >> 6):
+    extension and two-sided extension, full and narrow bands (the band edge crosses from one set to the next), small and large h0."""
     lp, P = reflib.lo_para(rt), hp_para_like(rt)
     jobs = _mid_jobs(77 + len(rt), ERR[rt])
-    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (2, 0, 100), (2, 0, 12)):
-        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), reflib.emu_dp(jobs, P, kind, w, h0), kind) == [], (kind, w, h0)
+    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (1, 130, 90), (2, 0, 100), (2, 0, 12)):
+        want = reflib.oracle_dp(jobs, lp, kind, w, h0)
+        for pk in (True, False):              # two columns per lane as int16 pairs (ksw_extend_pk<1 | 2>), then the int32 sets behind it
+            st = []
+            assert goldenlib.same_dp(want, reflib.emu_dp(jobs, P, kind, w, h0, pk=pk, stats=st), kind) == [], (kind, w, h0, pk)
+            assert (st[0] > 0 and st[1] == 0) if pk else (st[0] == 0 and st[1] > 0), st
+
+
+def test_emulated_packed_extension_refuses_scores_beyond_int16():
+    """A start score that would take a cell past the int16 range sends the job to the int32 register sets (pk_extend_ok, hp_ksw.h)."""
+    lp, P = reflib.lo_para("ont2d"), hp_para_like("ont2d")
+    jobs = _mid_jobs(5, ERR["ont2d"])[:40]
+    for h0, packed in ((14000, True), (14950, False), (30000, False), (1 << 20, False)):
+        st = []
+        got = reflib.emu_dp(jobs, P, 1, lp.band_w, h0, stats=st)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 1, lp.band_w, h0), got, 1) == [], h0
+        assert (st[0] > 0 and st[1] == 0) if packed else (st[0] == 0 and st[1] > 0), (h0, st)
 
 
 def test_emulated_kernels_edge_cases():

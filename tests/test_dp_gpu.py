@@ -41,12 +41,12 @@ def test_hip_matches_oracle_fuzz(handles, rt):
 
 
 @pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
-def test_hip_extension_with_the_row_in_two_register_sets(handles, rt):
-    """Queries of 58 .. 132 bases (the limits of ksw_extend_reg and ksw_extend_reg2 and everything between), full and narrow bands."""
+def test_hip_extension_with_the_row_in_register_sets(handles, rt):
+    """Queries of 58 .. 260 bases (the limits of ksw_extend_reg and ksw_extend_regn<2 | 3 | 4> and everything between), full and narrow bands."""
     import test_dp_cpu
     lp = reflib.lo_para(rt)
     jobs = test_dp_cpu._mid_jobs(77 + len(rt), ERR[rt])
-    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (2, 0, 100), (2, 0, 12)):
+    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (1, 130, 90), (2, 0, 100), (2, 0, 12)):
         got = handles[rt].dp_batch(jobs, kind, w, h0)
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (rt, kind, w, h0)
 
