@@ -200,6 +200,29 @@ static bool next_mapped(FastxReader::Impl *p, Read &r)
     return true;
 }
 
+bool FastxReader::spans() const { return p->m != nullptr && p->mn > 0 && p->m[0] == '>'; }
+bool FastxReader::next_span(size_t &beg, size_t &end)
+{
+    if (!spans() || p->have) return false;
+    const char *m = p->m; const size_t n = p->mn;
+    size_t at = p->mpos;
+    while (at < n && m[at] != '>') { const char *nl = (const char *)memchr(m + at, '\n', n - at); at = nl ? (size_t)(nl - m) + 1 : n; }      // the next header line
+    if (at >= n) { p->mpos = n; return false; }
+    if (at >= p->limit) { p->mpos = at; return false; }                        // the record belongs to the next shard
+    beg = at;
+    do { const char *nl = (const char *)memchr(m + at, '\n', n - at); at = nl ? (size_t)(nl - m) + 1 : n; } while (at < n && m[at] != '>');
+    end = at; p->mpos = at;
+    return true;
+}
+bool FastxReader::parse_span(size_t beg, size_t end, Read &r) const
+{
+    Impl q; q.m = p->m; q.mn = end; q.mpos = beg;                              // a view of the mapping that ends with the record (it owns nothing)
+    r.seq.clear(); r.qual.clear(); r.has_qual = false;
+    const bool ok = next_mapped(&q, r);
+    q.m = nullptr;
+    return ok;
+}
+
 bool FastxReader::next(Read &r)
 {
     r.seq.clear(); r.qual.clear(); r.has_qual = false;
@@ -930,7 +953,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // input files that cuts the next chunk (reads + the line span of every read in the mapped GEM file), the parse of
     // the chunk before it on all host threads, the GPU on the one before that, and the SAM text of the oldest.
     // The chunk buffers are recycled.
-    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; std::vector<std::string> text; bool mapped = false; lamsa_hp_batch hb; int dev = 0;
+    struct Chunk { Batch B; int ret = 0; std::vector<std::pair<const char *, const char *>> span; std::vector<std::pair<size_t, size_t>> rspan; std::vector<std::string> text; bool mapped = false; lamsa_hp_batch hb; int dev = 0;
                    int sub_rc = 0, col_rc = 0; lamsa_hp_result res; std::promise<void> collected; };
     // One worker thread per device runs that device's submit / collect calls in the order they are queued (a handle is not
     // thread-safe, and the copies of a submit block their caller): the uploads of different devices then run side by side.
@@ -948,7 +971,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     auto scan = [&]() -> Chunk * {                          // sequential: FASTA/FASTQ records and their seed_all map lines
         Chunk *c = &pool[(size_t)(n_scanned++ % (2 * G + 6))];
         Batch &B = c->B;
-        B.clear(); c->ret = 0; c->span.clear(); c->text.clear(); c->mapped = false;
+        B.clear(); c->ret = 0; c->span.clear(); c->rspan.clear(); c->text.clear(); c->mapped = false;
         if (eof) return c;
         const double t0 = now_s();
         Read rd;
@@ -972,7 +995,12 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             else { hb.h_cig_off = nullptr; hb.cig = nullptr; hb.cig8 = (const uint8_t *)take(nc); }
             if ((size_t)(a - (hitsf.p + hitsf.pos + sizeof ch)) != (size_t)ch.bytes) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
             hitsf.pos += sizeof ch + (size_t)ch.bytes;
-            for (size_t r = 0; r < n; ++r) {
+            if (fx.spans()) {                               // only where the records lie: they are parsed by all threads (prepare)
+                c->rspan.resize(n);
+                for (size_t r = 0; r < n; ++r)
+                    if (!fx.next_span(c->rspan[r].first, c->rspan[r].second)) { fprintf(stderr, "[lamsa_read_seq] the hit stream does not match the reads\n"); c->ret = 1; eof = true; return c; }
+                B.reads.resize(n);
+            } else for (size_t r = 0; r < n; ++r) {
                 if (!fx.next(rd) || (int64_t)rd.seq.size() != hb.read_off[r + 1] - hb.read_off[r]) { fprintf(stderr, "[lamsa_read_seq] the hit stream does not match the reads\n"); c->ret = 1; eof = true; return c; }
                 B.reads.emplace_back(); std::swap(B.reads.back(), rd);
             }
@@ -1033,7 +1061,17 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 reserve_s = now_s() - t;
             });
         }
-        if (c->mapped) { parse_s += now_s() - t0; return c; }
+        if (c->mapped) {
+            if (!c->rspan.empty()) {                        // the records of a chunk of the hit stream, parsed side by side
+                std::vector<int> bad((size_t)threads, 0);
+                parallel_blocks(n, threads, [&](int t, int r0, int r1) {
+                    for (int r = r0; r < r1; ++r)
+                        if (!fx.parse_span(c->rspan[(size_t)r].first, c->rspan[(size_t)r].second, B.reads[(size_t)r]) || (int64_t)B.reads[(size_t)r].seq.size() != c->hb.read_off[r + 1] - c->hb.read_off[r]) bad[(size_t)t] = 1;
+                });
+                for (int b : bad) if (b) { fprintf(stderr, "[lamsa_read_seq] the hit stream does not match the reads\n"); c->ret = 1; break; }
+            }
+            parse_s += now_s() - t0; return c;
+        }
         const double t1 = now_s();
         // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
         for (Batch &p : parts) p.clear();

@@ -30,6 +30,12 @@ class FastxReader {
     // that START in [lo, hi) of the file; other inputs are cut by record count (count the records with next(), re-open, skip).
     bool mapped() const; size_t size() const;
     void restrict(size_t lo, size_t hi);
+    // A mapped FASTA file (first byte '>') can hand out its records as byte spans -- two line searches per single-line record -- and
+    // have them parsed later, on any thread: next_span() delivers the next record's [beg, end) (false at the end, or when the file
+    // is not a mapped FASTA file), parse_span() is next() on that span.
+    bool spans() const;
+    bool next_span(size_t &beg, size_t &end);
+    bool parse_span(size_t beg, size_t end, Read &r) const;
   private:
     Impl *p;
 };

@@ -68,6 +68,22 @@ def test_binary_hit_stream_round_trip(cli, tmp_path):
     q = subprocess.run([cli, "aln", "-R", "0", "--hits", hits] + args + [ref, reads], capture_output=True, text=True)
     assert q.returncode == 0, q.stderr[-2000:]
     assert G.strip_pg(q.stdout) == G.strip_pg(want)
+    # the same reads as FASTA lines of 60 columns with DOS line ends (records handed out as spans of the mapped file, parsed by all
+    # threads), and as FASTQ (the sequential reader): the replay does not care
+    recs = [(l.split("\n", 1)[0], "".join(l.split("\n")[1:])) for l in open(reads).read().split(">")[1:]]
+    folded, fq = str(tmp_path / "folded.fa"), str(tmp_path / "reads.fq")
+    with open(folded, "w", newline="") as f:
+        for name, seq in recs:
+            f.write(">" + name + "\r\n" + "".join(seq[i:i + 60] + "\r\n" for i in range(0, len(seq), 60)))
+    with open(fq, "w") as f:
+        for name, seq in recs:
+            f.write("@" + name + "\n" + seq + "\n+\n" + "@" * len(seq) + "\n")
+    for other in (folded, fq):
+        q = subprocess.run([cli, "aln", "-R", "0", "-t", "3", "--hits", hits] + args + [ref, other], capture_output=True, text=True)
+        assert q.returncode == 0, q.stderr[-2000:]
+        got = [l.split("\t") for l in G.strip_pg(q.stdout).splitlines() if not l.startswith("@")]
+        exp = [l.split("\t") for l in G.strip_pg(want).splitlines() if not l.startswith("@")]
+        assert [g[:10] for g in got] == [e[:10] for e in exp] and [g[11:] for g in got] == [e[11:] for e in exp], other      # (the FASTQ run prints qualities)
     bad = subprocess.run([cli, "aln", "-R", "0", "--hits", hits, "-T", "pacbio", ref, reads], capture_output=True, text=True)
     assert bad.returncode != 0 and "hit stream" in bad.stderr
     os.makedirs(str(tmp_path / "other"))
