@@ -325,6 +325,7 @@ def main():
             r_stream_pinned = round(streamed(Bp, a.stream_chunks), 2)
             Bp.release()
         cpu = None
+        h.close()                                          # every GPU measurement is taken: the device buffers go back before the product binary (a process of its own) is run beside the reference's
         if a.cpu_seconds > 0 and world == 1 and not a.bare:               # the CPU baseline is measured on rank 0 of the single-GPU run only
             lp = reflib.lo_para(wl["read_type"], **wl["over"])
             probe = min(256, a.reads)                      # estimate the rate on a probe, then size the sample for ~cpu_seconds
@@ -446,7 +447,7 @@ def compare_with_product(d, args, threads, n, exe=None):
     q = subprocess.run([exe, "aln"] + args + ["-t", str(min(threads, 32)), "-N", "-I", "-R", "0", "-o", d + "/out_gpu.sam", d + "/ref.fa", d + "/reads.fa"],
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
     if q.returncode != 0:
-        return "product binary exited with %d: %s" % (q.returncode, q.stderr[-200:])
+        return "product binary exited with %d: %s" % (q.returncode, " | ".join(l for l in q.stderr.splitlines() if "read " not in l)[-600:])
 
     def by_read(path):
         recs, hdr = {}, []

@@ -100,9 +100,6 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
         if ((((top == C_I || top == C_D) && (t >> 4) <= 3) && hop != C_S && hop != C_H) ||
             (((hop == C_I || hop == C_D) && (h >> 4) <= 3) && top != C_S && top != C_H)) repair = true;
     }
-#ifdef HP_EXP_NO_MERGEFULL
-    repair = false;
-#endif
     if (!repair) cig_pushv_known(cx, c1, wv::bcast(T1, 0), _c2, c2_n, wv::bcast(T2, 0));
     else {
         const size_t mark = arena_mark(cx.tmp);
@@ -503,11 +500,7 @@ HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &o
     const int mm = S.n - j;
     if (n1 + mm > res.cig.cap) ovf = true;
     else if (mm > 0) {
-#ifdef HP_EXP_NO_COPYLOAD      // experiment only (wrong results): the appended words are not loaded
-        if (S.p) { for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = i == mm - 1 ? S.last : S.first; } } }
-#else
         if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
-#endif
         else dst[n1] = S.first;
         m.n = n1 + mm; tail = S.last;
     }

@@ -62,8 +62,9 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
         if ((kk) >= off_ && (kk) - off_ < n_col) { \
             if (lz) { const int c_ = (kk) - off_, nib_ = (lz[(ii) * zstride + (c_ >> 1)] >> ((c_ & 1) << 2)) & 0xf; \
                       cell_ = nib_ == 0xf ? 255 : ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)); } \
-            else if (pk_stride) { const int nib_ = (gz[(long)(ii) * pk_stride + ((kk) >> 1)] >> (((kk) & 1) << 2)) & 0xf; const hp_v2i be_ = grb[(ii)]; \
-                   cell_ = ((kk) >= be_.x && (kk) < be_.y) ? ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)) : 255; } \
+            else if (pk_stride) { const int nib_ = (gz[(long)(ii) * pk_stride + ((kk) >> 1)] >> (((kk) & 1) << 2)) & 0xf; \
+                   cell_ = (nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0); \
+                   if (grb) { const hp_v2i be_ = grb[(ii)]; if (!((kk) >= be_.x && (kk) < be_.y)) cell_ = 255; } } \
             else { const int zc_ = gz[(long)(ii) * n_col + ((kk) - off_)]; \
                    if (grb) { const hp_v2i be_ = grb[(ii)]; cell_ = ((kk) >= be_.x && (kk) < be_.y) ? zc_ : 255; } else cell_ = zc_; } } } while (0)
     while (i >= 0 && k >= 0) {
@@ -955,7 +956,7 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
                 const int j = 128 * c + 2 * l + b;
                 hv[b] = j == 0 ? h0 : (j == 1 ? h1v : ((j <= qlen && h1v - (j - 2) * e_ins > e_ins) ? h1v - (j - 1) * e_ins : 0));
                 const int code = j < qlen ? (int)gq[(long)j * qs] : 4;
-                if (code < 4) oh |= 1 << (code + 16 * b); else nn |= 0xffff << (16 * b);
+                if (code < 4) oh |= 1 << (code + 16 * b); else nn |= (int)(0xffffu << (16 * b));
             }
             Hs[c][l] = pk::pack(hv[0], hv[1]); Es[c][l] = 0;
             qoh[c][l] = oh; qN[c][l] = nn;                                 // the query base of a column as one bit of four; N (and beyond the query): score -1
@@ -1140,6 +1141,144 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
     return er;
 }
 
+// ksw_global2 with two columns per lane, scores as int16 pairs: the layout and the row of ksw_extend_pk without the row maximum and the
+// band logic.  MINUS_INF becomes -12 000 and the scan's identity -24 000: every cell is MINUS_INF or zero plus a sum of scores and
+// penalties that pk_global_ok keeps below 4 000 in size, so the three classes never meet and every comparison of the reference -- all
+// between sums of the same terms -- comes out as it does in 32 bits.
+#define HP_PKG_NEG (-12000)
+#define HP_PKG_IDENT (-24000)
+HP_INL bool pk_global_ok(const lamsa_hp_para *P, int qlen, int tlen, int o_del, int e_del, int o_ins, int e_ins)
+{
+    const int mx = P->match > P->mis ? P->match : P->mis;
+    const long long o = o_del > o_ins ? o_del : o_ins, e = e_del > e_ins ? e_del : e_ins;
+    return mx > 0 && mx < 256 && o_del >= 0 && e_del >= 0 && o_ins >= 0 && e_ins >= 0 && o + e * ((long long)qlen + tlen + 4) + (long long)mx * (qlen + 2) < 4000;
+}
+template <int NS>
+HP_NOINL int ksw_global_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
+{
+    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
+    HP_T0(tg0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);
+    o_del = wv::uni(o_del); e_del = wv::uni(e_del); o_ins = wv::uni(o_ins); e_ins = wv::uni(e_ins);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
+    const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
+    const size_t mark = arena_mark(cx.tmp);
+    uint8_t *z = out ? (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1) : nullptr;
+    if (out && !z) { arena_release(cx.tmp, mark); return 0; }
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    const int sc_match = wv::uni(cx.P->match), sc_mis = -wv::uni(cx.P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    const int OEI = pk::rep(oe_ins), OED = pk::rep(oe_del), EI = pk::rep(e_ins), ED = pk::rep(e_del);
+    const int DSC = pk::rep(sc_match - sc_mis), MIS = pk::rep(sc_mis), IDENT = pk::rep(HP_PKG_IDENT), NEG = pk::rep(HP_PKG_NEG);
+    wv::Lane<int> Hs[NS], Es[NS], qoh[NS], qN[NS], hcur[NS], jp0, jep0, tl;
+    WAVE_FOR(l) { jp0[l] = pk::pack(2 * l, 2 * l + 1); jep0[l] = pk::pack(2 * l * e_ins, (2 * l + 1) * e_ins); tl[l] = 4; }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) {
+        WAVE_FOR(l) {                                                      // first row, :569-572
+            int hv[2], oh = 0, nn = 0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int j = 128 * c + 2 * l + b;
+                hv[b] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : HP_PKG_NEG);
+                const int code = j < qlen ? (int)gq[(long)j * qs] : 4;
+                if (code < 4) oh |= 1 << (code + 16 * b); else nn |= (int)(0xffffu << (16 * b));
+            }
+            Hs[c][l] = pk::pack(hv[0], hv[1]); Es[c][l] = NEG;
+            qoh[c][l] = oh; qN[c][l] = nn;
+        }
+    }
+    for (int ib = 0; ib < tlen; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            const int beg = i > w ? i - w : 0;
+            const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+            cells_ += end > beg ? end - beg : 0;
+            const int h1_init = beg == 0 ? -(o_del + e_del * (i + 1)) : HP_PKG_NEG;   // :579
+            const int tsh = ti & 3, tN = ti > 3 ? -1 : 0;
+            const int BEG = pk::rep(beg), END = pk::rep(end), FB = pk::rep(HP_PKG_NEG + beg * e_ins), H1 = pk::rep(h1_init);
+            int carry = HP_PKG_IDENT;
+            wv::Lane<int> inb[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                wv::Lane<int> key, klo, M;
+                WAVE_FOR(l) {
+                    const int jp = pk::add(jp0[l], pk::rep(128 * c));
+                    inb[c][l] = pk::neg_mask(pk::sub(jp, END)) & ~pk::neg_mask(pk::sub(jp, BEG));      // beg <= j < end, per half
+                    const int eq = (qoh[c][l] >> tsh) & 0x00010001;
+                    const int S = pk::add(pk::mul(eq, DSC), MIS) | qN[c][l] | tN;                       // HP_SUB(ti, qb)
+                    const int m = pk::add(Hs[c][l], S);
+                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
+                    const int k = pk::sel(inb[c][l], pk::add(pk::sub(m, OEI), jep), IDENT);
+                    M[l] = m;
+                    klo[l] = pk::lo(k);
+                    const int kh = pk::hi(k);
+                    key[l] = klo[l] > kh ? klo[l] : kh;
+                }
+                const int top = wv::scan_max_excl_top(key, HP_PKG_IDENT);
+                WAVE_FOR(l) {
+                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
+                    const int s0 = key[l] > carry ? key[l] : carry, s1 = s0 > klo[l] ? s0 : klo[l];
+                    const int pre = pk::pack(s0, s1);
+                    int f = pk::max(pk::add(pk::sub(pre, jep), EI), pk::sub(FB, jep));                   // F(i,beg) = MINUS_INF carried along the row
+                    const int m = M[l];
+                    int ee = Es[c][l];
+                    int d = pk::neg_mask(pk::sub(m, ee)) & 0x00010001;                                  // ties: M over E   :598-599
+                    int h = pk::max(m, ee);
+                    d = pk::sel(pk::neg_mask(pk::sub(h, f)), 0x00020002, d);                            //       then over F :600-601
+                    h = pk::max(h, f);
+                    const int tD = pk::sub(m, OED);
+                    ee = pk::sub(ee, ED);
+                    d |= pk::neg_mask(pk::sub(tD, ee)) & 0x00040004;                                    // :603-607
+                    ee = pk::max(ee, tD);
+                    f = pk::sub(f, EI);
+                    d |= pk::neg_mask(pk::sub(pk::sub(m, OEI), f)) & 0x00080008;                        // :608-611
+                    const int in = inb[c][l];
+                    Es[c][l] = pk::sel(in, ee, Es[c][l]);
+                    hcur[c][l] = h;
+                    if (out && in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
+                }
+                carry = top > carry ? top : carry;
+            }
+            // eh[j+1].h = H(i,j) for the row's columns (the band mask moves up with the values), eh[beg].h = H(i,-1), eh[end].e = MINUS_INF
+#pragma unroll
+            for (int c = NS - 1; c >= 0; --c) {
+                const int below = c > 0 ? wv::bcast(hcur[c > 0 ? c - 1 : 0], 63) : 0, below_in = c > 0 ? wv::bcast(inb[c > 0 ? c - 1 : 0], 63) : 0;
+                wv::Lane<int> dn = hcur[c], dm = inb[c];
+                wv::shr1(dn, below); wv::shr1(dm, below_in);
+                WAVE_FOR(l) {
+                    const int hsh = pk::shift_up(hcur[c][l], dn[l]), upd = pk::shift_up(inb[c][l], dm[l]);      // beg < j <= end
+                    const int in = inb[c][l];
+                    int hs = pk::sel(upd, hsh, Hs[c][l]);
+                    hs = pk::sel(in & ~upd, H1, hs);                       // j == beg
+                    Hs[c][l] = hs;
+                    Es[c][l] = pk::sel(upd & ~in, NEG, Es[c][l]);          // j == end, :632
+                }
+            }
+        }
+    }
+    int score = 0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) if ((qlen >> 7) == c) { const int v = wv::bcast(Hs[c], (qlen >> 1) & 63); score = (qlen & 1) ? pk::hi(v) : pk::lo(v); }
+    if (score <= HP_PKG_NEG / 2) score = HP_NEG_INF + (score - HP_PKG_NEG);           // (a cell the band never reached, as the reference would return it)
+    if (out) {
+        const int i = tlen - 1;
+        const int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;           // :638
+        wv::sync();
+        HP_T0(tb0_);
+        dp_backtrack(cx, nullptr, z, nullptr, n_col, w, i, k, *out, zs);
+        HP_TADD(cx, 28, tb0_);
+    }
+    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 24, tg0_);
+    return score;
+}
+
 // ---- ksw_global2 (src/ksw.c:543-653).  out may be nullptr (score only). ----
 HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                       int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
@@ -1148,15 +1287,12 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
     if (qlen < 0 || tlen < 0) { cx.status |= ST_REFEXIT; return 0; }      // reference: exit(-1), :547
     { const int d = iabs(qlen - tlen) + 3; if (w < d) w = d; }             // :549
     HP_DPLOG(1, qlen, tlen, w, 0);
-#ifdef HP_EXP_NO_GLOBAL   // experiment only (wrong results)
-#ifdef HP_EXP_NO_SMALLGLOBAL
-    if (qlen >= 0)
-#else
-    if (qlen > HP_REG_QMAX)
-#endif
-    { if (out) { const int m = qlen < tlen ? qlen : tlen; if (m) cig_push0(cx, *out, (cig_t)(m << 4) | C_M); if (qlen > m) cig_push0(cx, *out, (cig_t)((qlen - m) << 4) | C_I); if (tlen > m) cig_push0(cx, *out, (cig_t)((tlen - m) << 4) | C_D); } return qlen; }
-#endif
     if (qlen <= HP_REG_QMAX) return ksw_global_reg(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
+    if (HP_PK_RT && qlen <= HP_PK_QMAX(2) && pk_global_ok(cx.P, qlen, tlen, o_del, e_del, o_ins, e_ins)) {
+        HP_STAT(18);
+        return qlen <= HP_PK_QMAX(1) ? ksw_global_pk<1>(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out) : ksw_global_pk<2>(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
+    }
+    HP_STAT(19);
     if (2 * w + 4 + 64 <= HP_LDS_CELLS) return ksw_global_lds(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
     return ksw_global_wide(cx, qlen, q, tlen, t, o_del, e_del, o_ins, e_ins, w, out);
 }
@@ -1350,10 +1486,6 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
     }
     const long long cells0_ = cx.n_cells; (void)cells0_;
     ExtRes er;
-#ifdef HP_EXP_NO_EXT      // experiment only (wrong results): what the fill costs without the wave-wide extensions
-    if (qlen > HP_REG_QMAX) { er.score = h0 + qlen; er.qle = qlen; er.tle = qlen < tlen ? qlen : tlen; if (out) { out->n = 0; cig_push0(cx, *out, (cig_t)(er.tle << 4) | C_M); if (qlen > er.tle) cig_push0(cx, *out, (cig_t)((qlen - er.tle) << 4) | C_I); } }
-    else
-#endif
     if (qlen <= HP_REG_QMAX) er = ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out);
     else if (HP_PK_RT && qlen <= HP_PK_QMAX(2) && pk_extend_ok(cx.P, qlen, h0))
         { HP_STAT(16); er = qlen <= HP_PK_QMAX(1) ? ksw_extend_pk<1>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_pk<2>(cx, qlen, q, tlen, t, w, h0, out); }

@@ -225,7 +225,8 @@ def emu_capi_lib():
 
 def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20, pk=True, stats=None):
     """Run DP jobs through the emulated device code (same kernel sources, CPU lanes).  pk=False: extensions of 63 .. 254 query bases take the
-    int32 register sets instead of the packed int16 routine; stats: a list that receives [calls of the packed routine, of the int32 sets]."""
+    int32 register sets instead of the packed int16 routine; stats: a list that receives [extensions through the packed routine, through the int32 sets, global alignments of more than 62
+    query bases through the packed routine, through the LDS rows]."""
     import sys
     sys.path.insert(0, ROOT)
     from lamsa_amd.hp import pack_jobs
@@ -246,7 +247,7 @@ def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20, pk=True, stats=None)
                    p(score), p(qle), p(tle), p(st), p(cn), p(cap), p(cig), slab_bytes)
     E.emu_set_pk(1)
     if stats is not None:
-        stats[:] = [int(E.emu_stat(16)), int(E.emu_stat(17))]
+        stats[:] = [int(E.emu_stat(16)), int(E.emu_stat(17)), int(E.emu_stat(18)), int(E.emu_stat(19))]
     cigars = [cig[cap[i]:cap[i] + cn[i]].tolist() for i in range(n)]
     return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)
 

@@ -88,6 +88,12 @@ def test_emulated_extension_with_the_row_in_register_sets(rt):
             st = []
             assert goldenlib.same_dp(want, reflib.emu_dp(jobs, P, kind, w, h0, pk=pk, stats=st), kind) == [], (kind, w, h0, pk)
             assert (st[0] > 0 and st[1] == 0) if pk else (st[0] == 0 and st[1] > 0), st
+    for w in (lp.band_w, 3, 40):              # ksw_global2 on the same jobs: ksw_global_pk<1 | 2>, then the LDS rows behind it
+        want = reflib.oracle_dp(jobs, lp, 0, w, 0)
+        for pk in (True, False):
+            st = []
+            assert goldenlib.same_dp(want, reflib.emu_dp(jobs, P, 0, w, 0, pk=pk, stats=st), 0) == [], (w, pk)
+            assert (st[2] > 0 and st[3] > 0) if pk else (st[2] == 0 and st[3] > 0), st          # (queries beyond 254 bases keep the LDS rows)
 
 
 def test_emulated_packed_extension_refuses_scores_beyond_int16():

@@ -46,7 +46,7 @@ def test_hip_extension_with_the_row_in_register_sets(handles, rt):
     import test_dp_cpu
     lp = reflib.lo_para(rt)
     jobs = test_dp_cpu._mid_jobs(77 + len(rt), ERR[rt])
-    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (1, 130, 90), (2, 0, 100), (2, 0, 12)):
+    for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (1, 130, 90), (2, 0, 100), (2, 0, 12), (0, lp.band_w, 0), (0, 3, 0), (0, 40, 0)):
         got = handles[rt].dp_batch(jobs, kind, w, h0)
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, kind, w, h0), got, kind) == [], (rt, kind, w, h0)
 
