@@ -282,7 +282,8 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6),
                 "traffic": prof.get(dom_kernel, {}).get("hbm_bytes_per_step_upper"), "traffic_source": prof.get("_source"),
                 "kernel": dom_kernel, "kernel_ms": round(dom_ms, 3), "kernel_ms_timed_region_overlapped": round(dom_ms_timed, 3),
-                "kernel_ms_rocprof_avg_committed": prof.get(dom_kernel, {}).get("ms_per_step_rocprof"),
+                "kernel_ms_rocprof_avg_committed": (prof.get(dom_kernel, {}).get("round1") or {}).get("avg_ms_rocprof") or prof.get(dom_kernel, {}).get("ms_per_step_rocprof"),
+                "issue_busy_committed": {k: {"valu": (v.get("round1") or v).get("valu_busy_frac"), "scalar": (v.get("round1") or v).get("salu_busy_frac")} for k, v in prof.items() if isinstance(v, dict) and (v.get("round1") or v).get("valu_busy_frac") is not None} or None,
                 "algorithmic_bytes_per_launch": int(dom_bytes),
                 "note": "dominant launch of the step; duration = HIP events on the launches' own stream, %s; its algorithmic bytes = the terms of B_read that launch group touches "
                         "(seed-CIGAR words only of the hits on lines, counted by the kernel)" % ("steps one at a time after the timed region (the timed region queues steps two deep, so its event intervals overlap)" if lm_seq else "timed region"),

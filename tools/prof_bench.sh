@@ -8,12 +8,14 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --bare > $out/bench_stats.log 2>&1
+# one launch at a time (--sequential): the timed region of a plain run queues steps two deep, and the trace would show every kernel stretched by the one it shares the GPU with
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --sequential --bare > $out/bench_stats.log 2>&1
 # PMC_SETS="FETCH_SIZE;WRITE_SIZE" limits the counter passes (default: all five)
 if [ -n "${PMC_SETS:-}" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; else
 SETS=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"
       "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"
-      "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"); fi
+      "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+      "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES"); fi
 for set in "${SETS[@]}"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40)
   # counter passes serialise the dispatches anyway: one launch at a time (--sequential)

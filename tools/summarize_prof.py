@@ -35,6 +35,21 @@ def main():
         k = kname(row["Name"])
         if k:
             kern[k] = {"calls": int(row["Calls"]), "avg_ms_rocprof": round(float(row["AverageNs"]) / 1e6, 3), "total_ms_rocprof": round(float(row["TotalDurationNs"]) / 1e6, 3)}
+    # The fill launches run twice per step (round 1, round 2) and round 2 is nearly empty on the bench data: an average over both says
+    # little about either.  The dispatches of such a kernel are told apart by their order (round 1 first): `round1` holds the same figures
+    # for the first of every pair.
+    TWICE = ("k_fill", "k_filllist", "k_filldp_small", "k_filldp_big")
+    for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_trace.csv"), recursive=True):
+        by = {}
+        for row in csv.DictReader(open(f)):
+            k = kname(row["Kernel_Name"])
+            if k in TWICE:
+                by.setdefault(k, []).append((int(row["Dispatch_Id"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
+        for k, v in by.items():
+            v.sort()
+            first = [ms for i, (_, ms) in enumerate(v) if i % 2 == 0]
+            if k in kern and first and len(v) % 2 == 0:
+                kern[k].setdefault("round1", {})["avg_ms_rocprof"] = round(sum(first) / len(first), 3)
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
         acc = {}
         for row in csv.DictReader(open(f)):
@@ -46,21 +61,34 @@ def main():
         for (k, name), by_disp in acc.items():
             kern.setdefault(k, {}).setdefault("per_dispatch", {})[name] = sum(by_disp.values()) / len(by_disp)
             kern[k].setdefault("pmc_dispatches", {})[name] = len(by_disp)
-    for k, d in kern.items():
-        per = d.get("per_dispatch", {})
-        if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
-            d["hbm_bytes_per_dispatch_lower"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
-            d["hbm_bytes_per_dispatch_upper"] = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
-        wc = per.get("SQ_WAVE_CYCLES")
-        if wc:
-            for c, key in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_ACTIVE_INST_ANY", "issuing_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac")):
-                if c in per:
-                    d[key] = round(per[c] / wc, 4)
-        if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per:
-            d["l2_hit_rate"] = round(per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4)
-        if "SQ_INSTS_VALU" in per and d.get("avg_ms_rocprof"):
-            # vector instructions issued per second against what 1024 SIMDs can issue (one wave64 VALU instruction per 2 cycles at 2.4 GHz)
-            d["valu_issue_frac"] = round(per["SQ_INSTS_VALU"] / (d["avg_ms_rocprof"] * 1e-3) / (1024 * 2.4e9 / 2), 4)
+            if k in TWICE and len(by_disp) % 2 == 0:
+                ids = sorted(by_disp, key=int)
+                first = [by_disp[i] for n_, i in enumerate(ids) if n_ % 2 == 0]
+                kern[k].setdefault("round1", {}).setdefault("per_dispatch", {})[name] = sum(first) / len(first)
+    for k, d0 in list(kern.items()):
+      for d in ([d0, d0["round1"]] if "round1" in d0 else [d0]):
+          per = d.get("per_dispatch", {})
+          if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+              d["hbm_bytes_per_dispatch_lower"] = (per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+              d["hbm_bytes_per_dispatch_upper"] = (2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024
+          wc = per.get("SQ_WAVE_CYCLES")
+          if wc:
+              for c, key in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_ACTIVE_INST_ANY", "issuing_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac")):
+                  if c in per:
+                      d[key] = round(per[c] / wc, 4)
+          if "TCC_HIT_sum" in per and "TCC_MISS_sum" in per:
+              d["l2_hit_rate"] = round(per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"]), 4)
+          if per.get("GRBM_GUI_ACTIVE"):
+              # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md): cycles of the dispatch = / 8; 1024 SIMDs, a VALU or scalar instruction
+              # holds its issue port of a SIMD for 4 cycles
+              cyc = per["GRBM_GUI_ACTIVE"] / 8.0
+              if "SQ_ACTIVE_INST_VALU" in per:
+                  d["valu_busy_frac"] = round(per["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 4)
+              if "SQ_INST_CYCLES_SALU" in per:
+                  d["salu_busy_frac"] = round(per["SQ_INST_CYCLES_SALU"] * 4 / 1024 / cyc, 4)
+          if "SQ_INSTS_VALU" in per and d.get("avg_ms_rocprof"):
+              # vector instructions issued per second against what 1024 SIMDs can issue (one wave64 VALU instruction per 2 cycles at 2.4 GHz)
+              d["valu_issue_frac"] = round(per["SQ_INSTS_VALU"] / (d["avg_ms_rocprof"] * 1e-3) / (1024 * 2.4e9 / 2), 4)
     doc = {"command": cmd, "kernels": kern,
            "hbm_traffic_note": "FETCH_SIZE/WRITE_SIZE are in KiB.  Per MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; these kernels mix "
                                "narrow gathers and coalesced loads, so a lower (as reported) and an upper (reads x2) bound are given; bench.py's roofline.traffic uses the upper one."}
