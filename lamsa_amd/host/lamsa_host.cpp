@@ -1049,7 +1049,8 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         if (!reserve_started && !opt.parse_only && !hs.empty()) {
             reserve_started = true;
             int64_t nb = 0; int max_len = 0;
-            for (const Read &rd : B.reads) { nb += (int64_t)rd.seq.size(); max_len = std::max(max_len, (int)rd.seq.size()); }
+            if (c->mapped) { for (int r = 0; r < n; ++r) { const int len = (int)(c->hb.read_off[r + 1] - c->hb.read_off[r]); nb += len; max_len = std::max(max_len, len); } }     // (the records of a chunk of the hit stream may not be parsed yet)
+            else for (const Read &rd : B.reads) { nb += (int64_t)rd.seq.size(); max_len = std::max(max_len, (int)rd.seq.size()); }
             const int32_t r_n = (int32_t)std::max(n, opt.chunk_reads > n ? std::min(opt.chunk_reads, 2 * n) : n);
             const int64_t r_nb = nb + nb / 4 + 4096;
             reserver = std::thread([&hs, &reserve_s, r_n, r_nb, max_len]() {
