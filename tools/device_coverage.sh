@@ -10,7 +10,7 @@ out=${1:-profiles/r03_device_coverage.txt}
 rm -rf tests/_build_cov
 LAMSA_EMU_COVERAGE=1 python -m pytest tests -q -m "not gpu" -x -k "emu or kernel or cli or lane or sort or compact or chaining or split or four or edge" > /tmp/cov_pytest.log 2>&1 || { tail -20 /tmp/cov_pytest.log; exit 1; }
 cd tests/_build_cov
-for g in *.gcda; do gcov -b -o . "$g" > /dev/null 2>&1 || true; done
+gcov -o . *.gcda > /dev/null 2>&1 || true        # one invocation: the counts of a header compiled into several objects are summed
 cd ../..
 python3 - "$out" <<'PY'
 import glob, os, re, sys
@@ -19,7 +19,8 @@ rows = []
 for f in sorted(glob.glob("tests/_build_cov/hp_*.h.gcov")):
     name = os.path.basename(f)[:-5]
     src = open(os.path.join("lamsa_amd/csrc", name)).read().split("\n") if os.path.exists(os.path.join("lamsa_amd/csrc", name)) else []
-    execd = miss = 0; missing = []
+    # a line of a template is listed once per instantiation as well: a line counts once, and as run when any listing of it ran
+    seen = {}
     for line in open(f, errors="replace"):
         m = re.match(r"\s*([^:]+):\s*(\d+):(.*)", line)
         if not m:
@@ -27,10 +28,9 @@ for f in sorted(glob.glob("tests/_build_cov/hp_*.h.gcov")):
         cnt, ln = m.group(1).strip(), int(m.group(2))
         if ln == 0 or cnt == "-":
             continue
-        if cnt.startswith("#") or cnt.startswith("="):
-            miss += 1; missing.append(ln)
-        else:
-            execd += 1
+        ran = not (cnt.startswith("#") or cnt.startswith("="))
+        seen[ln] = seen.get(ln, False) or ran
+    execd = sum(1 for v in seen.values() if v); miss = sum(1 for v in seen.values() if not v); missing = sorted(l for l, v in seen.items() if not v)
     # merge gcov files of the same header coming from several objects: keep the best (gcov writes one per object; take union)
     rows.append((name, execd, miss, missing, src))
 # union over duplicates
