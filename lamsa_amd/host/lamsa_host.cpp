@@ -257,6 +257,16 @@ template <class V> static inline void cig_push1(V &c, size_t base, int32_t w)
     c.push_back(w);
 }
 
+// the same on the compact form (op << 6 | len, len <= 63, ops M / I / D); false: the element does not fit
+static inline bool cig8_push1(RawVec<uint8_t> &c, size_t base, int32_t w)
+{
+    const int len = w >> 4, op = w & 0xf;
+    if (len == 0) return true;
+    if (c.size() > base && (c.back() >> 6) == op) { const int nl = (c.back() & 63) + len; c.back() = (uint8_t)((op << 6) | (nl & 63)); return nl <= 63 && op <= 2; }
+    c.push_back((uint8_t)((op << 6) | (len & 63)));
+    return len <= 63 && op <= 2;
+}
+
 // one hit "chr:strand:pos:gigar" appended to the batch; md2cigar, src/gem_parse.c:74-112.  The text is a view into the
 // mapped file: every scan is bounded by the token's end.
 static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
@@ -274,7 +284,10 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
     while (c3 < e && *c3 != ':') ++c3;
     const char *md = c3 < e ? c3 + 1 : e, *mdend = md;
     while (mdend < e && *mdend != ':') ++mdend;
-    const size_t base = B.cig.size();
+    const bool compact = B.parse_compact;
+    const size_t base = compact ? B.cig8.size() : B.cig.size();
+    bool fits = true;
+#define HP_HIT_PUSH(w_) do { if (compact) fits &= cig8_push1(B.cig8, base, (w_)); else cig_push1(B.cig, base, (w_)); } while (0)
     int nm = 0, bd = 0, bi = 0;
     for (const char *q = md; q < mdend;) {
         if (*q == '>') {
@@ -285,7 +298,7 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
             for (; s < mdend && *s >= '0' && *s <= '9'; ++s) n = n * 10 + (*s - '0');
             if (neg) { n = -n; s = d0 - 1; }                               // ">-3": atoi takes the sign, the scan below stops at it
             while (s < mdend && *s != '+' && *s != '-') ++s;
-            if (s < mdend && *s == '+') { bd += n; cig_push1(B.cig, base, (n << 4) | 2); } else { bi += n; cig_push1(B.cig, base, (n << 4) | 1); }
+            if (s < mdend && *s == '+') { bd += n; HP_HIT_PUSH((n << 4) | 2); } else { bi += n; HP_HIT_PUSH((n << 4) | 1); }
             nm += n;
             int d = 1; for (int t = n; t >= 10; t /= 10) ++d;
             q += d + 2;
@@ -298,36 +311,51 @@ static void add_hit(Batch &B, const Index &ix, const char *tok, size_t len)
                 else if (in_run) { m += run; run = 0; in_run = false; }
             }
             if (in_run) m += run;
-            cig_push1(B.cig, base, ((m + mm) << 4) | 0);
+            HP_HIT_PUSH(((m + mm) << 4) | 0);
             nm += mm;
         }
     }
-    if (strand == '-') std::reverse(B.cig.begin() + (long)base, B.cig.end());      // _invert_cigar, src/gem_parse.c:267
+#undef HP_HIT_PUSH
+    if (!fits) B.saw_wide = true;
+    if (strand == '-') { if (compact) std::reverse(B.cig8.begin() + (long)base, B.cig8.end()); else std::reverse(B.cig.begin() + (long)base, B.cig.end()); }      // _invert_cigar, src/gem_parse.c:267
     // contig name -> id (map_cal_msg's strcmp scan, src/lamsa_aln.c:767); consecutive hits mostly share the contig
-    static thread_local std::string last_name; static thread_local int last_id = 0; static thread_local const Index *last_ix = nullptr;
+    // (the hits of a repeat seed go from contig to contig: a small cache per thread, keyed by a hash of the name, in front of the map)
+    struct NameSlot { std::string name; int id = 0; const Index *ix = nullptr; };
+    static thread_local NameSlot cache[256];
     const size_t nl = (size_t)(c1 - tok);
-    if (last_ix != &ix || last_name.size() != nl || memcmp(last_name.data(), tok, nl) != 0) {
-        last_name.assign(tok, nl); last_ix = &ix;
-        auto it = ix.name_to_id.find(last_name);
-        last_id = it == ix.name_to_id.end() ? -1 : it->second;
+    unsigned hsh = 2166136261u;
+    for (size_t k = 0; k < nl; ++k) hsh = (hsh ^ (unsigned char)tok[k]) * 16777619u;
+    NameSlot &slot = cache[(hsh ^ (hsh >> 8) ^ (hsh >> 16)) & 255];
+    if (slot.ix != &ix || slot.name.size() != nl || memcmp(slot.name.data(), tok, nl) != 0) {
+        slot.name.assign(tok, nl); slot.ix = &ix;
+        auto it = ix.name_to_id.find(slot.name);
+        slot.id = it == ix.name_to_id.end() ? -1 : it->second;
     }
+    const int last_id = slot.id;
     B.h_pos.push_back(pos); B.h_chr.push_back(last_id); B.h_strand.push_back(strand == '+' ? 1 : -1);
-    B.h_nm.push_back((int16_t)nm); B.h_len_dif.push_back((int16_t)(bd - bi)); B.h_cig_off.push_back((int32_t)base);
-    if (B.cig.size() - base > 255) B.cig.resize(base + 255);               // the boundary counts a seed's CIGAR in 8 bits: the surplus goes, so that the counts add up to the arena
-    B.h_cig_n.push_back((uint8_t)(B.cig.size() - base));
+    B.h_nm.push_back((int16_t)nm); B.h_len_dif.push_back((int16_t)(bd - bi));
+    if (compact) {
+        if (B.cig8.size() - base > 255) B.cig8.resize(base + 255);         // the boundary counts a seed's CIGAR in 8 bits: the surplus goes, so that the counts add up to the arena
+        B.h_cig_n.push_back((uint8_t)(B.cig8.size() - base));
+    } else {
+        B.h_cig_off.push_back((int32_t)base);
+        if (B.cig.size() - base > 255) B.cig.resize(base + 255);
+        B.h_cig_n.push_back((uint8_t)(B.cig.size() - base));
+    }
 }
 
 // all hits of one seed; more than max_n hits: the seed keeps its slot but loses all hits (src/gem_parse.c:243-246)
 static void parse_gem_hits(Batch &B, const Index &ix, const char *s, const char *end, int max_n)
 {
-    const size_t h0 = B.h_pos.size(), c0 = B.cig.size();
+    const size_t h0 = B.h_pos.size(), c0 = B.parse_compact ? B.cig8.size() : B.cig.size();
     int n = 0;
     for (const char *p = s; p < end;) {
         while (p < end && *p == ',') ++p;
         if (p >= end) break;
         const char *e = (const char *)memchr(p, ',', (size_t)(end - p)); if (!e) e = end;
         if (n >= max_n) {
-            B.h_pos.resize(h0); B.h_chr.resize(h0); B.h_strand.resize(h0); B.h_nm.resize(h0); B.h_len_dif.resize(h0); B.h_cig_off.resize(h0); B.h_cig_n.resize(h0); B.cig.resize(c0);
+            B.h_pos.resize(h0); B.h_chr.resize(h0); B.h_strand.resize(h0); B.h_nm.resize(h0); B.h_len_dif.resize(h0); B.h_cig_n.resize(h0);
+            if (B.parse_compact) B.cig8.resize(c0); else { B.h_cig_off.resize(h0); B.cig.resize(c0); }
             return;
         }
         add_hit(B, ix, p, (size_t)(e - p));
@@ -338,7 +366,7 @@ static void parse_gem_hits(Batch &B, const Index &ix, const char *s, const char 
 void Batch::clear()
 {
     reads.clear(); read_off.assign(1, 0); read_seq.clear(); seed_all.clear(); last_len.clear(); seed_off.assign(1, 0); seed_id.clear(); hit_off.assign(1, 0);
-    h_pos.clear(); h_chr.clear(); h_strand.clear(); h_nm.clear(); h_len_dif.clear(); h_cig_off.clear(); h_cig_n.clear(); cig.clear(); cig8.clear(); cig_wide = false;
+    h_pos.clear(); h_chr.clear(); h_strand.clear(); h_nm.clear(); h_len_dif.clear(); h_cig_off.clear(); h_cig_n.clear(); cig.clear(); cig8.clear(); cig_wide = false; saw_wide = false;
 }
 
 static const uint8_t *nt4_table()
@@ -496,12 +524,13 @@ static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
     for (size_t i = 0; i < np; ++i) {
         const Batch &p = parts[i];
         r0[i + 1] = r0[i] + p.seed_all.size(); b0[i + 1] = b0[i] + p.read_seq.size(); s0[i + 1] = s0[i] + p.seed_id.size();
-        h0[i + 1] = h0[i] + p.h_pos.size(); c0[i + 1] = c0[i] + p.cig.size();
+        h0[i + 1] = h0[i] + p.h_pos.size(); c0[i + 1] = c0[i] + (p.parse_compact ? p.cig8.size() : p.cig.size());
     }
+    const bool compact_parts = np > 0 && parts[0].parse_compact;      // the parts hold the seed CIGARs as bytes already (none of them met an element that does not fit)
     B.read_off.resize(r0[np] + 1); B.seed_off.resize(r0[np] + 1); B.seed_all.resize(r0[np]); B.last_len.resize(r0[np]); B.read_seq.resize(b0[np]);
     B.seed_id.resize(s0[np]); B.hit_off.resize(s0[np] + 1);
-    B.h_pos.resize(h0[np]); B.h_chr.resize(h0[np]); B.h_strand.resize(h0[np]); B.h_nm.resize(h0[np]); B.h_len_dif.resize(h0[np]); B.h_cig_n.resize(h0[np]); B.h_cig_off.resize(h0[np]);
-    B.cig.resize(c0[np]); B.cig8.resize(c0[np]);
+    B.h_pos.resize(h0[np]); B.h_chr.resize(h0[np]); B.h_strand.resize(h0[np]); B.h_nm.resize(h0[np]); B.h_len_dif.resize(h0[np]); B.h_cig_n.resize(h0[np]);
+    B.cig8.resize(c0[np]); B.cig.clear(); B.h_cig_off.clear();      // the word form of the CIGARs (4 B per element + 4 B per hit) is only made when an element does not fit a byte
     std::atomic<int> wide(0);
     B.read_off[0] = 0; B.seed_off[0] = 0; B.hit_off[0] = 0;
     auto copy_parts = [&](int i0, int i1) {
@@ -520,22 +549,32 @@ static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
             std::copy(p.h_nm.begin(), p.h_nm.end(), B.h_nm.begin() + (long)h0[i]);
             std::copy(p.h_len_dif.begin(), p.h_len_dif.end(), B.h_len_dif.begin() + (long)h0[i]);
             std::copy(p.h_cig_n.begin(), p.h_cig_n.end(), B.h_cig_n.begin() + (long)h0[i]);
-            for (size_t k = 0; k < p.h_cig_off.size(); ++k) B.h_cig_off[h0[i] + k] = (int32_t)(p.h_cig_off[k] + (int64_t)c0[i]);
-            std::copy(p.cig.begin(), p.cig.end(), B.cig.begin() + (long)c0[i]);
             {   // the same CIGARs one byte per element (they lie back to back in hit order: no offsets needed on the way to the GPU)
                 int w = 0;
                 uint8_t *o8 = B.cig8.data() + c0[i];
-                for (size_t k = 0; k < p.cig.size(); ++k) { const int32_t x = p.cig[k]; w |= (x >> 4) > 63 || (x & 0xf) > 2; o8[k] = (uint8_t)(((x & 3) << 6) | ((x >> 4) & 63)); }
+                if (compact_parts) std::copy(p.cig8.begin(), p.cig8.end(), o8);
+                else for (size_t k = 0; k < p.cig.size(); ++k) { const int32_t x = p.cig[k]; w |= (x >> 4) > 63 || (x & 0xf) > 2; o8[k] = (uint8_t)(((x & 3) << 6) | ((x >> 4) & 63)); }
                 if (w) wide = 1;
             }
-            p.clear();
         }
     };
-    if (threads < 2 || h0[np] < 4096) { copy_parts(0, (int)np); B.cig_wide = wide.load() != 0; return; }
-    std::vector<std::thread> th;                             // one thread per part
-    for (size_t i = 0; i < np; ++i) if (!parts[i].seed_all.empty()) th.emplace_back(copy_parts, (int)i, (int)i + 1);
-    for (auto &x : th) x.join();
-    B.cig_wide = wide.load() != 0;
+    auto copy_words = [&](int i0, int i1) {                   // second pass, rare: some element is longer than 63
+        for (int i = i0; i < i1; ++i) {
+            const Batch &p = parts[(size_t)i];
+            for (size_t k = 0; k < p.h_cig_off.size(); ++k) B.h_cig_off[h0[i] + k] = (int32_t)(p.h_cig_off[k] + (int64_t)c0[i]);
+            std::copy(p.cig.begin(), p.cig.end(), B.cig.begin() + (long)c0[i]);
+        }
+    };
+    auto on_parts = [&](const std::function<void(int, int)> &fn) {
+        if (threads < 2 || h0[np] < 4096) { fn(0, (int)np); return; }
+        std::vector<std::thread> th;                         // one thread per part
+        for (size_t i = 0; i < np; ++i) if (!parts[i].seed_all.empty()) th.emplace_back(fn, (int)i, (int)i + 1);
+        for (auto &x : th) x.join();
+    };
+    on_parts(copy_parts);
+    B.cig_wide = wide.load() != 0 || !compact_parts;          // (parts in words: the parse has met an element that does not fit a byte)
+    if (B.cig_wide) { B.cig.resize(c0[np]); B.h_cig_off.resize(h0[np]); on_parts(copy_words); }
+    for (Batch &p : parts) p.clear();
 }
 
 // ------------------------------------------------------------------ result stream -> records
@@ -815,7 +854,7 @@ struct HitsWriter {
         return padn == 0 || fwrite(zeros, 1, padn, fp) == padn;
     }
     bool write(const lamsa::Batch &B) {
-        const size_t n = B.reads.size(), nb = B.read_seq.size(), ns = B.seed_id.size(), nh = B.h_pos.size(), nc = B.cig.size();
+        const size_t n = B.reads.size(), nb = B.read_seq.size(), ns = B.seed_id.size(), nh = B.h_pos.size(), nc = B.cig8.size();
         HitsChunkHeader c; c.n_reads = (int64_t)n; c.n_bases = (int64_t)nb; c.n_slots = (int64_t)ns; c.n_hits = (int64_t)nh; c.n_cig = (int64_t)nc; c.cig_elem = B.cig_wide ? 4 : 1;
         c.bytes = (int64_t)(pad64(8 * (n + 1)) * 2 + pad64(nb) + pad64(4 * n) * 2 + pad64(4 * ns) + pad64(8 * (ns + 1)) + pad64(8 * nh) + pad64(4 * nh) + pad64(nh) * 2 + pad64(2 * nh) * 2 +
                             (B.cig_wide ? pad64(4 * nh) + pad64(4 * nc) : pad64(nc)));
@@ -1075,10 +1114,18 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         }
         const double t1 = now_s();
         // text -> hit records (gem_map_msg / map_cal_msg run inside the worker threads in the reference too)
-        for (Batch &p : parts) p.clear();
-        parallel_blocks(n, threads, [&](int t, int r0, int r1) {
-            for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], c->span[(size_t)r].first, c->span[(size_t)r].second, seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
-        });
+        // The seed CIGARs are written in the boundary's compact form (a byte per element) as they are parsed; a chunk in which an element
+        // does not fit a byte (longer than 63 -- no 50-base seed has one) is parsed once more into words.
+        static const bool words_only = getenv("LAMSA_WIDE_CIGARS") != nullptr;      // tests: every chunk through the word form
+        for (int pass = words_only ? 1 : 0; pass < 2; ++pass) {
+            for (Batch &p : parts) { p.clear(); p.parse_compact = pass == 0; }
+            parallel_blocks(n, threads, [&](int t, int r0, int r1) {
+                for (int r = r0; r < r1; ++r) append_read_lines(parts[(size_t)t], ix, P, B.reads[(size_t)r], c->span[(size_t)r].first, c->span[(size_t)r].second, seeds_of(P, (int)B.reads[(size_t)r].seq.size()));
+            });
+            bool wide = false;
+            for (const Batch &p : parts) wide |= p.saw_wide;
+            if (!wide) break;
+        }
         const double t2 = now_s();
         merge_batches(B, parts, threads);
         if (trace) fprintf(stderr, "[prepare] waited %.3f s for the scan, parse %.3f, merge %.3f\n", t1 - t0, t2 - t1, now_s() - t2);
@@ -1109,7 +1156,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         else {
         hb.n_reads = (int32_t)B.reads.size(); hb.read_off = B.read_off.data(); hb.read_seq = B.read_seq.data(); hb.seed_all = B.seed_all.data(); hb.last_len = B.last_len.data();
         hb.seed_off = B.seed_off.data(); hb.seed_id = B.seed_id.data(); hb.hit_off = B.hit_off.data(); hb.h_pos = B.h_pos.data(); hb.h_chr = B.h_chr.data(); hb.h_strand = B.h_strand.data();
-        hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_n = B.h_cig_n.data(); hb.n_cig = (int64_t)B.cig.size();
+        hb.h_nm = B.h_nm.data(); hb.h_len_dif = B.h_len_dif.data(); hb.h_cig_n = B.h_cig_n.data(); hb.n_cig = (int64_t)B.cig8.size();
         if (B.cig_wide) { hb.h_cig_off = B.h_cig_off.data(); hb.cig = B.cig.data(); hb.cig8 = nullptr; }
         else { hb.h_cig_off = nullptr; hb.cig = nullptr; hb.cig8 = B.cig8.data(); }                 // compact form: a quarter of the CIGAR bytes, no offsets
         static const int32_t zero32 = 0; static const uint8_t zero8 = 0; static const int64_t zero64 = 0; static const int16_t zero16 = 0; static const int8_t zeroi8 = 0;

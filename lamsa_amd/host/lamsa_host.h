@@ -54,6 +54,7 @@ struct Batch {                       // the arrays of lamsa_hp_batch, host side
     RawVec<int64_t> read_off, seed_off, hit_off, h_pos;
     RawVec<uint8_t> read_seq, h_cig_n, cig8;      // cig8: the seed CIGARs as the GPU boundary's compact form takes them (op << 6 | len)
     bool cig_wide = false;                        // some element is longer than 63: the chunk goes in the word form (cig + h_cig_off)
+    bool parse_compact = false, saw_wide = false; // a per-thread part of the parse: the seed CIGARs written as bytes (cig8) straight away; an element that does not fit was met
     RawVec<int32_t> seed_all, last_len, seed_id, h_chr, h_cig_off, cig;
     RawVec<int16_t> h_nm, h_len_dif;
     RawVec<int8_t> h_strand;

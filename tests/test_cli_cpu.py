@@ -56,6 +56,20 @@ def test_error_paths(cli, tmp_path):
     assert seeds[0].endswith("_0:0") and len(seeds[1]) == 50 and seeds[2].endswith("_1:100")
 
 
+def test_seed_cigars_in_words_when_an_element_does_not_fit_a_byte(cli, tmp_path):
+    """The parser writes the seed CIGARs in the boundary's compact form (a byte per element) and parses a chunk again into 32-bit words
+    when an element is longer than 63 (seeds longer than that); LAMSA_WIDE_CIGARS=1 sends every chunk that way: same SAM, and a hit
+    stream saved from it replays to the same SAM."""
+    ref, reads, args, want = G.stage_scenario("c3_ont", str(tmp_path))
+    env = dict(os.environ, LAMSA_WIDE_CIGARS="1")
+    hits = str(tmp_path / "hits_w.bin")
+    p = subprocess.run([cli, "aln", "-N", "-R", "0", "--batch", "7", "--save-hits", hits] + args + [ref, reads], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(p.stdout) == G.strip_pg(want)
+    q = subprocess.run([cli, "aln", "-R", "0", "--hits", hits] + args + [ref, reads], capture_output=True, text=True)
+    assert q.returncode == 0 and G.strip_pg(q.stdout) == G.strip_pg(want), q.stderr[-2000:]
+
+
 def test_binary_hit_stream_round_trip(cli, tmp_path):
     """--save-hits writes the parsed seed hits chunk by chunk; --hits replays them (no GEM text, no parse) -- same SAM;
     a stream written with other seeding options, or for other reads, is refused."""
