@@ -1238,7 +1238,35 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 write_sam(o, R, B.reads[(size_t)r], ix, opt);
             }
         });
-        for (int t = 0; t < threads; ++t) { fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
+        // The chunk's text (15 KB per 10-kbp read) goes out in input order.  Into a regular file the threads copy their parts side by side through
+        // a mapping of the file's new end (one thread's write() of 250 MB per chunk was the slowest stage of the loop once the hits came from a
+        // binary stream); a pipe or a terminal takes them one after the other.
+        bool mapped_out = false;
+        {
+            size_t total = 0; for (const std::string &x : sams) total += x.size();
+            struct stat st; const int fd = fileno(out);
+            static const size_t map_min = getenv("LAMSA_MAP_OUT_MIN") ? (size_t)atol(getenv("LAMSA_MAP_OUT_MIN")) : ((size_t)8 << 20);      // (tests lower it)
+            if (threads > 1 && total >= map_min && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fflush(out) == 0) {
+                const off_t base = lseek(fd, 0, SEEK_CUR);
+                const long pg = sysconf(_SC_PAGESIZE);
+                if (base >= 0 && pg > 0 && ftruncate(fd, base + (off_t)total) == 0) {
+                    const off_t m0 = base / pg * pg;
+                    void *m = mmap(nullptr, (size_t)(base - m0) + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
+                    if (m != MAP_FAILED) {
+                        char *dst = (char *)m + (base - m0);
+                        std::vector<size_t> at((size_t)threads + 1, 0);
+                        for (int t = 0; t < threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + sams[(size_t)t].size();
+                        std::vector<std::thread> th;
+                        for (int t = 0; t < threads; ++t) if (!sams[(size_t)t].empty()) th.emplace_back([&, t]() { memcpy(dst + at[(size_t)t], sams[(size_t)t].data(), sams[(size_t)t].size()); });
+                        for (auto &x : th) x.join();
+                        munmap(m, (size_t)(base - m0) + total);
+                        mapped_out = lseek(fd, base + (off_t)total, SEEK_SET) == base + (off_t)total;
+                        if (!mapped_out) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
+                    } else if (ftruncate(fd, base) != 0) { fprintf(stderr, "[lamsa_aln] cannot restore the output file's length\n"); return 2; }
+                }
+            }
+        }
+        for (int t = 0; t < threads; ++t) { if (!mapped_out) fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
         sam_s += now_s() - t1;

@@ -56,6 +56,17 @@ def test_error_paths(cli, tmp_path):
     assert seeds[0].endswith("_0:0") and len(seeds[1]) == 50 and seeds[2].endswith("_1:100")
 
 
+def test_output_file_written_through_a_mapping_by_all_threads(cli, tmp_path):
+    """-o FILE: the SAM text of a chunk is copied into a mapping of the file's new end by the threads side by side (chunks of 8 MB and
+    more; LAMSA_MAP_OUT_MIN lowers the limit); the file is the same as the text written to a pipe, header and chunk order included."""
+    ref, reads, args, want = G.stage_scenario("c2_pacbio", str(tmp_path))
+    out = str(tmp_path / "out.sam")
+    for limit, t in (("1", "3"), ("1", "5"), ("100000000", "3")):
+        p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", t, "--batch", "7", "-o", out] + args + [ref, reads], capture_output=True, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN=limit))
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert G.strip_pg(open(out).read()) == G.strip_pg(want), (limit, t)
+
+
 def test_seed_cigars_in_words_when_an_element_does_not_fit_a_byte(cli, tmp_path):
     """The parser writes the seed CIGARs in the boundary's compact form (a byte per element) and parses a chunk again into 32-bit words
     when an element is longer than 63 (seeds longer than that); LAMSA_WIDE_CIGARS=1 sends every chunk that way: same SAM, and a hit
