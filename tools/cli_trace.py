@@ -21,9 +21,16 @@ B = simbatch.SimBatch(ref, n, 10000, "ont2d", seed=31, threads=min(threads, 16))
 simfiles.write_index(d + "/ref.fa", ref); simfiles.write_reads(d + "/reads.fa", B, workers=min(threads, 32))
 print("files written in %.1f s; %d threads; %d cpus visible, affinity %d" % (time.time() - t, threads, os.cpu_count(), len(os.sched_getaffinity(0))), flush=True)
 exe = os.path.join(ROOT, "lamsa_amd", "bin", "lamsa")
-for rep in range(2):
-    for th in (threads, threads * 2):
+for rep in range(1):
+    for th in (threads,):
         p = subprocess.run([exe, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", str(th), "--batch", "16384", "--parse-only", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"],
                            capture_output=True, text=True, env=dict(os.environ, LAMSA_TRACE="1"))
         print("-t %d:" % th)
         print("\n".join(l for l in p.stderr.splitlines() if l.startswith("[scan]") or l.startswith("[prepare]") or "wall" in l), flush=True)
+# a whole run from the hit stream: the stages behind the GPU ([write]: result streams -> records, ranking + SAM text, the file)
+subprocess.run([exe, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", str(threads), "--batch", "16384", "--parse-only", "--save-hits", d + "/hits.bin", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
+for rep in range(2):
+    p = subprocess.run([exe, "aln", "-T", "ont2d", "-R", "0", "-t", str(threads), "--batch", "16384", "--hits", d + "/hits.bin", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"],
+                       capture_output=True, text=True, env=dict(os.environ, LAMSA_TRACE="1"))
+    print("--hits, whole run:")
+    print("\n".join(l for l in p.stderr.splitlines() if l.startswith("[write]") or l.startswith("[prepare]") or "wall" in l), flush=True)
