@@ -74,7 +74,15 @@ HP_FN void out_line(Ctx &cx, OutBuf &o, const LineRes &la)
         const Rec &rec = la.rec[j];
         out_put(cx, o, (int32_t)(rec.offset & 0xffffffffll)); out_put(cx, o, (int32_t)(rec.offset >> 32));
         out_put(cx, o, rec.chr); out_put(cx, o, rec.nstrand); out_put(cx, o, rec.score); out_put(cx, o, rec.NM); out_put(cx, o, rec.cig.n);
-        if (o.n + rec.cig.n <= o.cap) { for (int k = 0; k < rec.cig.n; ++k) o.w[o.n + k] = rec.cig.c[k]; o.n += rec.cig.n; }
+        if (o.n + rec.cig.n <= o.cap) {                               // the record's CIGAR, copied by the lanes (word by word it was 2 500 dependent trips per line: 14 % of the fill kernel)
+            HP_G int32_t *dst = (HP_G int32_t *)(o.w + o.n);
+            const HP_G cig_t *src = (const HP_G cig_t *)rec.cig.c;
+            const int cn = rec.cig.n;
+            wv::sync();
+            for (int b0 = 0; b0 < cn; b0 += 64) { WAVE_FOR(l) { const int k = b0 + l; if (k < cn) dst[k] = (int32_t)src[k]; } }
+            o.n += cn;
+            wv::sync();
+        }
         else cx.status |= ST_OVERFLOW;
     }
 }
