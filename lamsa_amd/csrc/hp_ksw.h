@@ -1103,6 +1103,22 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
                 else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
             }
             // shrink the band for the next row, :775-778
+            if constexpr (NS == 1) {
+                // One register set: the ballots hold eh[j] != 0 for j in [beg, end] only, so "the first one below end" is the first one once
+                // index `end` is set aside, and "the last one from there on" is the last one of all -- no range masks.
+                const unsigned long long e_bit = 1ull << ((end >> 1) & 63);
+                const bool end_nz = ((end & 1) ? nz1[0] : nz0[0]) & e_bit;
+                const unsigned long long l0 = (end & 1) ? nz0[0] : nz0[0] & ~e_bit, l1 = (end & 1) ? nz1[0] & ~e_bit : nz1[0];
+                int nb, jl;
+                if (l0 | l1) {
+                    const int a0 = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b0 = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
+                    nb = a0 < b0 ? a0 : b0;
+                    const int a1 = nz0[0] ? 2 * (63 - __builtin_clzll(nz0[0])) : -1, b1 = nz1[0] ? 2 * (63 - __builtin_clzll(nz1[0])) + 1 : -1;
+                    jl = a1 > b1 ? a1 : b1;
+                } else { nb = end; jl = end_nz ? end : end - 1; }
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+            } else
             {
                 int nb = end, jl;                                          // first non-zero index in [beg, end), else end
                 bool got = false;
