@@ -864,21 +864,24 @@ HP_NOINL ExtRes ksw_extend_regn(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
                 if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
                 else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
             }
-            // shrink the band for the next row, :775-778
+            // shrink the band for the next row, :775-778.  The ballots hold eh[j] != 0 for j in [beg, end] only: "the first one below end" is the
+            // first one once index `end` is set aside, "the last one from there on" the last one of all -- no range masks.
             {
-                int nb = end, jl;                                          // first non-zero index in [beg, end), else end
-                bool got = false;
+                const int e_set = end >> 6;
+                const unsigned long long e_bit = 1ull << (end & 63);
+                bool end_nz = false, got = false;
+                int nb = end, jl = -1;
 #pragma unroll
                 for (int c = 0; c < NS; ++c) {
-                    const unsigned long long lo = nzm[c] & lt_mask64(end - 64 * c);
+                    unsigned long long lo = nzm[c];
+                    if (c == e_set) { end_nz = lo & e_bit; lo &= ~e_bit; }
                     if (!got && lo) { nb = 64 * c + __builtin_ctzll(lo); got = true; }
                 }
-                jl = nb - 1; got = false;                                  // last non-zero index in [nb, end], else nb - 1
+                if (got) {
+                    bool gl = false;
 #pragma unroll
-                for (int c = NS - 1; c >= 0; --c) {
-                    const unsigned long long up = nzm[c] & ~lt_mask64(nb - 64 * c);
-                    if (!got && up) { jl = 64 * c + 63 - __builtin_clzll(up); got = true; }
-                }
+                    for (int c = NS - 1; c >= 0; --c) if (!gl && nzm[c]) { jl = 64 * c + 63 - __builtin_clzll(nzm[c]); gl = true; }
+                } else jl = end_nz ? end : end - 1;
                 beg = nb;
                 end = jl + 2 < qlen ? jl + 2 : qlen;
             }
@@ -1120,27 +1123,31 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
                 end = jl + 2 < qlen ? jl + 2 : qlen;
             } else
             {
-                int nb = end, jl;                                          // first non-zero index in [beg, end), else end
+                // several sets: the same two facts set by set (the ballots hold eh[j] != 0 for j in [beg, end] only)
+                const int e_set = end >> 7;
+                const unsigned long long e_bit = 1ull << ((end >> 1) & 63);
+                bool end_nz = false;
+                int nb = end, jl = -1;
                 bool got = false;
 #pragma unroll
                 for (int c = 0; c < NS; ++c) {
-                    const int e_c = end - 128 * c;                          // columns of this set below `end`: even ones 2l < e_c, odd ones 2l + 1 < e_c
-                    const unsigned long long l0 = nz0[c] & lt_mask64((e_c + 1) >> 1), l1 = nz1[c] & lt_mask64(e_c >> 1);
+                    unsigned long long l0 = nz0[c], l1 = nz1[c];
+                    if (c == e_set) { if (end & 1) { end_nz = l1 & e_bit; l1 &= ~e_bit; } else { end_nz = l0 & e_bit; l0 &= ~e_bit; } }
                     if (!got && (l0 | l1)) {
-                        const int a = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
-                        nb = 128 * c + (a < b ? a : b); got = true;
+                        const int a0 = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b0 = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
+                        nb = 128 * c + (a0 < b0 ? a0 : b0); got = true;
                     }
                 }
-                jl = nb - 1; got = false;                                  // last non-zero index in [nb, end], else nb - 1
+                if (got) {
+                    bool gl = false;
 #pragma unroll
-                for (int c = NS - 1; c >= 0; --c) {
-                    const int n_c = nb - 128 * c;                           // columns of this set from `nb` on: even ones 2l >= n_c, odd ones 2l + 1 >= n_c
-                    const unsigned long long u0 = nz0[c] & ~lt_mask64((n_c + 1) >> 1), u1 = nz1[c] & ~lt_mask64(n_c >> 1);
-                    if (!got && (u0 | u1)) {
-                        const int a = u0 ? 2 * (63 - __builtin_clzll(u0)) : -1, b = u1 ? 2 * (63 - __builtin_clzll(u1)) + 1 : -1;
-                        jl = 128 * c + (a > b ? a : b); got = true;
+                    for (int c = NS - 1; c >= 0; --c) {
+                        if (!gl && (nz0[c] | nz1[c])) {
+                            const int a1 = nz0[c] ? 2 * (63 - __builtin_clzll(nz0[c])) : -1, b1 = nz1[c] ? 2 * (63 - __builtin_clzll(nz1[c])) + 1 : -1;
+                            jl = 128 * c + (a1 > b1 ? a1 : b1); gl = true;
+                        }
                     }
-                }
+                } else jl = end_nz ? end : end - 1;
                 beg = nb;
                 end = jl + 2 < qlen ? jl + 2 : qlen;
             }
