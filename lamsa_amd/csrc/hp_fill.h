@@ -465,7 +465,9 @@ struct MergeSrc { const cig_t *p; int n, first, last, reflen, readlen; };       
 struct MergeLoc { int n, readend; int64_t refend; };
 HP_INL void mloc_out(const MergeLoc &m, Rec &res) { res.cig.n = m.n; res.refend = m.refend; res.readend = m.readend; }
 HP_INL void mloc_in(MergeLoc &m, const Rec &res) { m.n = res.cig.n; m.refend = res.refend; m.readend = res.readend; }
-HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &ovf, int chr, const MergeSrc &S)
+// dst / cap: the record's CIGAR buffer and its capacity, read once by the caller (through `res` they are a load from memory in front of every
+// store: the compiler cannot keep them across the stores of the copy)
+HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &ovf, int chr, const MergeSrc &S, HP_G cig_t *dst, int cap)
 {
     if (S.n == 0) return true;
     Ctx &cx = r.cx;
@@ -487,18 +489,17 @@ HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &o
             }
             wv::sync();
             mloc_in(m, res);
-            tail = m.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[m.n - 1] : 0;
+            tail = m.n > 0 ? (int)dst[m.n - 1] : 0;
             return ok && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
         }
     }
-    HP_G cig_t *dst = (HP_G cig_t *)res.cig.c;
     int j = 0;
     if (n1 > 0) {
         if ((tail & 0xf) == (S.first & 0xf)) { tail = tail + ((S.first >> 4) << 4); dst[n1 - 1] = tail; j = 1; }
         else if (((tail & 0xf) == C_I && (S.first & 0xf) == C_S) || ((tail & 0xf) == C_S && (S.first & 0xf) == C_I)) { tail = (((tail >> 4) + (S.first >> 4)) << 4) | C_S; dst[n1 - 1] = tail; j = 1; }
     }
     const int mm = S.n - j;
-    if (n1 + mm > res.cig.cap) ovf = true;
+    if (n1 + mm > cap) ovf = true;
     else if (mm > 0) {
         if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
         else dst[n1] = S.first;
@@ -518,10 +519,14 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
     if (!pl) return false;
     HP_G int32_t *g_pl = (HP_G int32_t *)pl;
     wv::sync();
-    int tail = res.cig.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[res.cig.n - 1] : 0;
     bool ok = true, ovf = false;
     long long cs_ = 0;                               // seed-CIGAR words appended (accounting, flushed once)
     MergeLoc ml; mloc_in(ml, res);                   // the record's running state, in registers
+    // what the sequential loop below needs of the structures it is handed, read once into (scalar) registers
+    HP_G cig_t *const res_c = (HP_G cig_t *)wv::uni64((long long)res.cig.c); const int res_cap = wv::uni(res.cig.cap);
+    const cig_t *const seed_cigs = (const cig_t *)wv::uni64((long long)r.cig); const cig_t *const job_cigs = (const cig_t *)wv::uni64((long long)F.jarena);
+    const int seed_len = wv::uni(P->seed_len);
+    int tail = ml.n > 0 ? (int)res_c[ml.n - 1] : 0;
     for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
         HP_T0(tg64_);
         // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
@@ -562,10 +567,10 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
             // frag_extend, :332-410
             if (wv::bcast(V[0], q)) {
                 MergeSrc S;
-                S.p = r.cig + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
-                S.reflen = wv::bcast(V[6], q); S.readlen = P->seed_len;
+                S.p = seed_cigs + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
+                S.reflen = wv::bcast(V[6], q); S.readlen = seed_len;
                 cs_ += S.n;
-                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[7], q), S);
+                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[7], q), S, res_c, res_cap);
             } else {
                 mloc_out(ml, res);
                 wv::sync();
@@ -574,7 +579,7 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                 HP_TADD_FILL(cx, 20, tfm_);
                 wv::sync();
                 mloc_in(ml, res);
-                tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
+                tail = ml.n > 0 ? (int)res_c[ml.n - 1] : 0;
             }
             if (!ok || t == nfr - 1) continue;
             // split_mapping, :416-564
@@ -587,12 +592,12 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                 HP_TADD_FILL(cx, 18, tsm_);
                 wv::sync();
                 mloc_in(ml, res);
-                tail = ml.n > 0 ? (int)((const HP_G cig_t *)res.cig.c)[ml.n - 1] : 0;
+                tail = ml.n > 0 ? (int)res_c[ml.n - 1] : 0;
             } else if (kind != 0) {
                 MergeSrc S;
-                S.p = kind == 2 ? F.jarena + wv::bcast(V[9], q) : nullptr; S.n = wv::bcast(V[10], q); S.first = wv::bcast(V[11], q); S.last = wv::bcast(V[12], q);
+                S.p = kind == 2 ? job_cigs + wv::bcast(V[9], q) : nullptr; S.n = wv::bcast(V[10], q); S.first = wv::bcast(V[11], q); S.last = wv::bcast(V[12], q);
                 S.reflen = wv::bcast(V[13], q); S.readlen = wv::bcast(V[14], q);
-                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[15], q), S);
+                ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[15], q), S, res_c, res_cap);
             }
         }
     }
