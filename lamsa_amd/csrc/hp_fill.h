@@ -53,26 +53,27 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
 // _push_cigar (frag_check.h:158-184) with what the caller already holds in registers: `last` = the vector's last element (used when it
 // is not empty), `c0` = the first source element (which may differ from c[0] in memory: the repair below shortens it).  Returns the
 // vector's new last element.  Nothing is loaded but the body of the copy.
-HP_FN int cig_pushv_known(Ctx &cx, CigV &v, int last, const cig_t *c, int n, int c0)
+// dst / vn / cap: the vector's buffer, length (updated) and capacity as the caller holds them -- through the vector they would be loads from memory
+// that wait behind every store.
+HP_FN int cig_pushv_known(Ctx &cx, HP_G cig_t *dst, int &vn_io, int cap, int last, const cig_t *c, int n, int c0)
 {
     if (n == 0) return last;
     const HP_G cig_t *src = (const HP_G cig_t *)c;
-    HP_G cig_t *dst = (HP_G cig_t *)v.c;
-    const int vn = v.n;
+    const int vn = vn_io;
     int j = 0;
     if (vn > 0) {
         if ((last & 0xf) == (c0 & 0xf)) { last = last + ((c0 >> 4) << 4); dst[vn - 1] = last; j = 1; }
         else if (((last & 0xf) == C_I && (c0 & 0xf) == C_S) || ((last & 0xf) == C_S && (c0 & 0xf) == C_I)) { last = (((last >> 4) + (c0 >> 4)) << 4) | C_S; dst[vn - 1] = last; j = 1; }
     }
     const int m = n - j;
-    if (vn + m > v.cap) { cx.status |= ST_OVERFLOW; return last; }
+    if (vn + m > cap) { cx.status |= ST_OVERFLOW; return last; }
     if (m > 0) {
         wv::Lane<int> w;
         WAVE_FOR(l) { w[l] = 0; }
         for (int b0 = 0; b0 < m; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < m) { w[l] = j + i == 0 ? c0 : (int)src[j + i]; dst[vn + i] = w[l]; } } }
         last = wv::bcast(w, (m - 1) & 63);
     }
-    v.n = vn + m;
+    vn_io = vn + m;
     wv::sync();
     return last;
 }
@@ -89,8 +90,13 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
     Ctx &cx = r.cx;
     HP_T0(tmf_);
     const lamsa_hp_para *P = cx.P;
-    const HP_G cig_t *g1 = (const HP_G cig_t *)c1.c, *g2 = (const HP_G cig_t *)_c2;
-    const int n1_0 = c1.n;
+    // what is needed of the vector and of the record's ends, read once (they lie in memory: every later use would be a load behind the stores)
+    HP_G cig_t *const c1c = (HP_G cig_t *)wv::uni64((long long)c1.c);
+    const int n1_0 = wv::uni(c1.n), c1cap = wv::uni(c1.cap);
+    const int64_t refend0 = *c1_refend; const int readend0 = wv::uni(*c1_readend), read_L = wv::uni(r.L);
+    const uint8_t *const cur_read = (const uint8_t *)wv::uni64((long long)r.cur_read);
+    const HP_G cig_t *g1 = c1c, *g2 = (const HP_G cig_t *)_c2;
+    int vn = n1_0;
     wv::Lane<int> T1, T2;                                     // T1[l] = c1[n1_0 - 1 - l] (the top first), T2[l] = c2[l]
     WAVE_FOR(l) { T1[l] = l < n1_0 ? (int)g1[n1_0 - 1 - l] : 0; T2[l] = l < c2_n ? (int)g2[l] : 0; }
     bool repair = false;
@@ -100,7 +106,7 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
         if ((((top == C_I || top == C_D) && (t >> 4) <= 3) && hop != C_S && hop != C_H) ||
             (((hop == C_I || hop == C_D) && (h >> 4) <= 3) && top != C_S && top != C_H)) repair = true;
     }
-    if (!repair) cig_pushv_known(cx, c1, wv::bcast(T1, 0), _c2, c2_n, wv::bcast(T2, 0));
+    if (!repair) cig_pushv_known(cx, c1c, vn, c1cap, wv::bcast(T1, 0), _c2, c2_n, wv::bcast(T2, 0));
     else {
         const size_t mark = arena_mark(cx.tmp);
         int len1, len11 = 0, len2, len21 = 0, len22 = 0, len_dif1 = 0, len_dif2 = 0;
@@ -126,8 +132,8 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
                     else { left = -1; break; }
                 }
                 len11 = len21 + len_dif1;
-                read_start = *c1_readend - len21 + 1;
-                ref_start = *c1_refend - len11 + 1;
+                read_start = readend0 - len21 + 1;
+                ref_start = refend0 - len11 + 1;
             }
             if (right) {
                 while (ci < c2_n) {
@@ -144,10 +150,10 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
             const size_t m2 = arena_mark(cx.tmp);
             uint8_t *seq1 = (uint8_t *)arena_alloc(cx, (size_t)(len1 > 0 ? len1 : 0) + 16);
             int32_t l1 = len1;
-            if (!seq1 || len2 < 0 || read_start < 1 || read_start - 1 + len2 > r.L || !ref_fetch(r, chr, ref_start - 1, &l1, seq1)) { cx.status |= seq1 ? ST_REFEXIT : ST_OVERFLOW; ok = false; break; }
+            if (!seq1 || len2 < 0 || read_start < 1 || read_start - 1 + len2 > read_L || !ref_fetch(r, chr, ref_start - 1, &l1, seq1)) { cx.status |= seq1 ? ST_REFEXIT : ST_OVERFLOW; ok = false; break; }
             len1 = l1;
             if (!cig_alloc(cx, bd, len1 + len2 + 8)) { ok = false; break; }
-            ksw_global(cx, len2, seq_fwd(r.cur_read + read_start - 1), len1, seq_fwd(seq1), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, b, &bd);
+            ksw_global(cx, len2, seq_fwd(cur_read + read_start - 1), len1, seq_fwd(seq1), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, b, &bd);
             if (bd.n == 0) { cx.status |= ST_REFEXIT; ok = false; break; }    // the reference dereferences an empty CIGAR here
             {   // its first and last element, in one trip
                 wv::Lane<int> fl;
@@ -167,16 +173,17 @@ HP_NOINL bool merge_cigar_full(ReadCtx &r, CigV &c1, int64_t *c1_refend, int *c1
 #undef HP_MF_E1
 #undef HP_MF_E2
         if (ok) {
-            c1.n = n1;
-            if (n1 > 0) ((HP_G cig_t *)c1.c)[n1 - 1] = e1;                      // the top of c1 as the walk left it (the push may merge into it and store it again)
-            const int last = cig_pushv_known(cx, c1, e1, bd.c, bd.n, bd_first);
-            cig_pushv_known(cx, c1, last, _c2 + ci, c2_n - ci, e2);
+            vn = n1;
+            if (n1 > 0) c1c[n1 - 1] = e1;                                       // the top of c1 as the walk left it (the push may merge into it and store it again)
+            const int last = cig_pushv_known(cx, c1c, vn, c1cap, e1, bd.c, bd.n, bd_first);
+            cig_pushv_known(cx, c1c, vn, c1cap, last, _c2 + ci, c2_n - ci, e2);
         }
         arena_release(cx.tmp, mark);
         if (!ok) return false;
     }
-    *c1_refend += c2_reflen;
-    *c1_readend += c2_readlen;
+    c1.n = vn;
+    *c1_refend = refend0 + c2_reflen;
+    *c1_readend = readend0 + c2_readlen;
     HP_TADD_FILL(cx, 16, tmf_);
     return true;
 }
