@@ -1742,7 +1742,7 @@ HP_NOINL bool chain_first(ReadCtx &r, FLines &F, FlStore *fs = nullptr)
 #endif
     HP_CSTAMP(6);
 #if defined(HP_CHAIN_STOP) && HP_CHAIN_STOP == 1
-    return true;                 // traffic experiment (tools/chain_stops.sh): nothing after the MIN pass
+    return true;                 // traffic experiment (tools/chain_stops.sh): nothing after the clusters are cut (the MIN pass runs with the main pass below)
 #endif
     if (seed_out > 1) {                                                                           // main pass, :1345-1350
         // cluster by cluster out of LDS; clusters that do not fit LDS through dp_update_range; then the son lists

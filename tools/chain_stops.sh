@@ -1,6 +1,7 @@
 #!/bin/bash
 # Where do k_chain1's time and HBM traffic come from?  Builds of the library that leave chain_first after the sort index and node records
-# (s0), the clusters and the MIN pass (s1), the main pass and the son lists (s2), branch tracking (s3), the line loop (s4) --
+# (s0), the clusters (s1: their cut only -- since round 3 the MIN pass runs inside the cluster pass of s2), the main pass with the MIN pass
+# and the son lists (s2), branch tracking (s3), the line loop (s4) --
 # lamsa_amd/lib/var/lib_s*.so, made with `make OUT=../lib/var/lib_s<n>.so EXTRA=-DHP_CHAIN_STOP=<n>` -- and the full library, each profiled
 # for kernel time, FETCH_SIZE and WRITE_SIZE (run on the GPU box):  tools/chain_stops.sh <tag> <bench args>
 tag=$1; shift
