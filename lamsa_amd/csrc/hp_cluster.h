@@ -255,9 +255,18 @@ HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int
 #define CW(e, w) strip[((e) * 6 + (w)) * 64]
     int m = 0, sp = 0; int64_t pos0 = 0;
     unsigned is_min = 0, promoted = 0;                                                  // bit e: entry e is a MIN hit / has just become one
-    for (int i = 0; i < n; ++i) {                                                       // the cluster's hits (do_me) or its MIN hits, ascending hit order
-        const int id = g_csrt[lo + i];
-        const NodeS Q = node_load(ns + id);
+    for (int i0 = 0; i0 < n; i0 += 3) {                                                 // the cluster's hits (do_me) or its MIN hits, ascending hit order
+      // three at a time: their ids, then their records, requested together (one after the other every hit is two dependent trips)
+      int ids[3]; NodeS Qs[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) ids[u] = g_csrt[lo + (i0 + u < n ? i0 + u : n - 1)];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) Qs[u] = node_load(ns + ids[u]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (i0 + u >= n) continue;
+        const int id = ids[u];
+        const NodeS Q = Qs[u];
         if (Q.dp_flag != MIN_FLAG && !(do_me && Q.dp_flag == MULTI_FLAG)) continue;
         if (m == 0) { pos0 = Q.pos; sp = Q.strand; }
         if (Q.dp_flag == MIN_FLAG) is_min |= 1u << m;
@@ -265,6 +274,7 @@ HP_INL void cluster_lane(ReadCtx &r, const EdgeK &K, const Clusters &C, HP_L int
         CW(m, 3) = (int)(((unsigned)Q.score << 16) | (unsigned)(Q.NM & 0xffff));
         CW(m, 4) = id; CW(m, 5) = (0xff << 24) | (1 << 16) | ((int)Q.son_flag << 8) | Q.match_flag;     // from (0xff = START) | node_n | son_flag | match_flag
         ++m;
+      }
     }
     if (do_me && is_min != 0 && is_min != (1u << m) - 1) {
         for (int a = 0; a < m; ++a) {
