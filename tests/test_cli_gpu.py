@@ -57,6 +57,18 @@ def test_end_to_end_files_at_scale(tmp_path):
     two = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", "4", "--hits", d + "/hits.bin", d + "/ref.fa", d + "/reads.fa"], capture_output=True, text=True)
     assert two.returncode == 0 and G.strip_pg(two.stdout) == b, two.stderr[-2000:]
     assert os.path.getsize(d + "/hits.bin") < os.path.getsize(d + "/reads.fa.seed.gem.map")            # compact form (one byte per seed-CIGAR element): smaller than the text
+    # --shard i/3 (one process after the other on this GPU), from the text and from the hit stream, each into a file of its own (-o: the
+    # chunk text goes through a mapping of the file, LAMSA_MAP_OUT_MIN lowered so that these small chunks take that path): the files written
+    # one after the other are the unsharded SAM
+    for src in ([], ["--hits", d + "/hits.bin"]):
+        text = ""
+        for i in range(3):
+            out = d + "/shard%d.sam" % i
+            p = subprocess.run([BIN, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", "8", "--batch", "200", "--shard", "%d/3" % i, "-o", out] + src + [d + "/ref.fa", d + "/reads.fa"],
+                               capture_output=True, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN="4096"))
+            assert p.returncode == 0, p.stderr[-2000:]
+            text += open(out).read()
+        assert G.strip_pg(text) == b, src
 
 
 @pytest.mark.parametrize("name", G.RESCUE_SCENARIOS)
