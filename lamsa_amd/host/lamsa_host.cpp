@@ -92,12 +92,13 @@ struct FastxReader::Impl {
 };
 bool FastxReader::mapped() const { return p->m != nullptr; }
 size_t FastxReader::size() const { return p->mn; }
-// is there a record header at offset `at` (which is the beginning of a line)?  '>' always; '@' only when the line after next begins
-// with '+' (a FASTQ quality line may begin with '@' too)
+// is there a record header at offset `at` (which is the beginning of a line)?  The file's first byte says which kind it is.  FASTA: a line
+// that begins with '>'.  FASTQ (four lines per record here, as every shardable file has): a line that begins with '@' and whose line after
+// next begins with '+' -- a quality line may begin with '@' or '>' (Phred 31 / 29) too, but the line two below such a one is a sequence line.
 static bool record_starts_at(const char *m, size_t n, size_t at)
 {
-    if (at >= n) return false;
-    if (m[at] == '>') return true;
+    if (at >= n || n == 0) return false;
+    if (m[0] != '@') return m[at] == '>';
     if (m[at] != '@') return false;
     const char *l1 = (const char *)memchr(m + at, '\n', n - at);
     if (!l1) return false;
@@ -874,6 +875,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
 {
     const double t_begin = now_s();
     double parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0;
+    long n_mapped_chunks = 0;                                // chunks whose SAM text went out through a mapping of the output file
     // Every way out of this function before the map has been read to its end -- an index that does not load, a map that does not match
     // the reads, a failed submit -- must not leave the mapper started by run_seeding running (and writing, on -t cores): it is told to
     // stop and waited for, and its exit status reported.
@@ -931,24 +933,43 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             if (si > 0) {
                 FastxReader probe; Read first;
                 if (probe.open(opt.reads)) probe.restrict(lo, hi);
-                if (!probe.next(first)) mapt.pos = mapt.n;       // no record starts in this part: nothing to do
+                // the first read of the part that has seeds at all (a read shorter than a seed has no line in the map)
+                bool have_first = probe.next(first);
+                while (have_first && seeds_of(P, (int)first.seq.size()) == 0) have_first = probe.next(first);
+                if (!have_first) mapt.pos = mapt.n;              // no record with seeds starts in this part: no map line is taken
                 else {
                     std::string nm = first.name.substr(0, first.name.find_first_of(" \t"));
-                    // the lines of a read's seeds are consecutive and begin "<read name>_<seed>" (split_seed, src/lamsa_aln.c:287): the first
-                    // of them at or after a guess of where this part begins, then back over the lines of the same read before it
+                    // the lines of a read's seeds are consecutive and begin "<read name>_<seed>:" (split_seed, src/lamsa_aln.c:287): the first
+                    // of them at or after a guess of where this part begins, then back over the lines of the same read before it.  A line of
+                    // ANOTHER read whose name merely begins with "<name>_" ("r1_2_0:0" for the read "r1") is told apart by what follows the
+                    // key: digits and a colon.
                     const std::string key = "\n" + nm + "_";
+                    auto is_seed_line = [&](const char *q) {       // q: just behind "<name>_"
+                        const char *e = mapt.p + mapt.n, *d = q;
+                        while (d < e && *d >= '0' && *d <= '9') ++d;
+                        return d > q && d < e && *d == ':';
+                    };
+                    auto find_from = [&](size_t from) -> const char * {
+                        while (from < mapt.n) {
+                            const char *h = (const char *)memmem(mapt.p + from, mapt.n - from, key.data(), key.size());
+                            if (!h) return nullptr;
+                            if (is_seed_line(h + key.size())) return h;
+                            from = (size_t)(h - mapt.p) + 1;
+                        }
+                        return nullptr;
+                    };
                     const size_t est = (size_t)((double)mapt.n * ((double)lo / (double)(S ? S : 1)));
                     const size_t from = est > (mapt.n >> 3) ? est - (mapt.n >> 3) : 0;
-                    const char *hit = (const char *)memmem(mapt.p + from, mapt.n - from, key.data(), key.size());
-                    if (!hit && from) hit = (const char *)memmem(mapt.p, mapt.n, key.data(), key.size());
-                    if (!hit && mapt.n >= key.size() - 1 && memcmp(mapt.p, key.data() + 1, key.size() - 1) == 0) hit = mapt.p - 1;      // the very first line
-                    if (!hit) { fprintf(stderr, "[lamsa_aln] --shard %d/%d: no line of %s begins with %s_ (the seeds of the shard's first read)\n", si, sn, map_path.c_str(), nm.c_str()); return 1; }
+                    const char *hit = find_from(from);
+                    if (!hit && from) hit = find_from(0);
+                    if (!hit && mapt.n >= key.size() - 1 && memcmp(mapt.p, key.data() + 1, key.size() - 1) == 0 && is_seed_line(mapt.p + key.size() - 1)) hit = mapt.p - 1;      // the very first line
+                    if (!hit) { fprintf(stderr, "[lamsa_aln] --shard %d/%d: no line of %s begins with %s_<seed>: (the seeds of the shard's first read)\n", si, sn, map_path.c_str(), nm.c_str()); return 1; }
                     size_t at = (size_t)(hit + 1 - mapt.p);
                     while (at > 1) {                            // the line before `at`: does it belong to the same read?
                         const char *pe = mapt.p + at - 1;       // its newline
                         const char *ps = (const char *)memrchr(mapt.p, '\n', (size_t)(pe - mapt.p));
                         const size_t b = ps ? (size_t)(ps - mapt.p) + 1 : 0;
-                        if (at - 1 - b >= key.size() - 1 && memcmp(mapt.p + b, key.data() + 1, key.size() - 1) == 0) at = b; else break;
+                        if (at - 1 - b >= key.size() - 1 && memcmp(mapt.p + b, key.data() + 1, key.size() - 1) == 0 && is_seed_line(mapt.p + b + key.size() - 1)) at = b; else break;
                     }
                     mapt.pos = at;
                 }
@@ -1246,10 +1267,12 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             size_t total = 0; for (const std::string &x : sams) total += x.size();
             struct stat st; const int fd = fileno(out);
             static const size_t map_min = getenv("LAMSA_MAP_OUT_MIN") ? (size_t)atol(getenv("LAMSA_MAP_OUT_MIN")) : ((size_t)8 << 20);      // (tests lower it)
-            if (threads > 1 && total >= map_min && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fflush(out) == 0) {
+            // only a descriptor open for reading AND writing can be mapped shared and writable (main.cpp opens -o that way; a shell's `>` is
+            // write-only and takes the fwrite path); the new end is allocated, not just declared: a store into a hole of a full disk is a SIGBUS
+            if (threads > 1 && total >= map_min && fd >= 0 && (fcntl(fd, F_GETFL) & O_ACCMODE) == O_RDWR && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fflush(out) == 0) {
                 const off_t base = lseek(fd, 0, SEEK_CUR);
                 const long pg = sysconf(_SC_PAGESIZE);
-                if (base >= 0 && pg > 0 && ftruncate(fd, base + (off_t)total) == 0) {
+                if (base >= 0 && pg > 0 && posix_fallocate(fd, base, (off_t)total) == 0) {
                     const off_t m0 = base / pg * pg;
                     void *m = mmap(nullptr, (size_t)(base - m0) + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
                     if (m != MAP_FAILED) {
@@ -1262,6 +1285,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                         munmap(m, (size_t)(base - m0) + total);
                         mapped_out = lseek(fd, base + (off_t)total, SEEK_SET) == base + (off_t)total;
                         if (!mapped_out) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
+                        ++n_mapped_chunks;
                     } else if (ftruncate(fd, base) != 0) { fprintf(stderr, "[lamsa_aln] cannot restore the output file's length\n"); return 2; }
                 }
             }
@@ -1338,6 +1362,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     if (reserver.joinable()) reserver.join();
     for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh);
     if (h_dp) lamsa_hp_destroy(h_dp);
+    if (trace) fprintf(stderr, "[write] %ld chunks written through a mapping of the output file\n", n_mapped_chunks);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
                  stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; stats->reserve_s = reserve_s; }
     return ret;

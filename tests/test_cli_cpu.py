@@ -4,6 +4,7 @@ binary with `-R 0`; tools/make_golden_reads.py).  On the CPU the host program is
 C-ABI (tests/emu); tests/test_cli_gpu.py runs the product binary on the MI355X."""
 import gzip
 import os
+import re
 import shutil
 import subprocess
 
@@ -62,9 +63,17 @@ def test_output_file_written_through_a_mapping_by_all_threads(cli, tmp_path):
     ref, reads, args, want = G.stage_scenario("c2_pacbio", str(tmp_path))
     out = str(tmp_path / "out.sam")
     for limit, t in (("1", "3"), ("1", "5"), ("100000000", "3")):
-        p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", t, "--batch", "7", "-o", out] + args + [ref, reads], capture_output=True, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN=limit))
+        p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", t, "--batch", "7", "-o", out] + args + [ref, reads], capture_output=True, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN=limit, LAMSA_TRACE="1"))
         assert p.returncode == 0, p.stderr[-2000:]
         assert G.strip_pg(open(out).read()) == G.strip_pg(want), (limit, t)
+        # the mapped path really ran (a write-only descriptor cannot be mapped: -o is opened read-write), and only when the chunk is large enough
+        mapped = int(re.search(r"\[write\] (\d+) chunks written through a mapping", p.stderr).group(1))
+        assert (mapped > 0) == (limit == "1"), (limit, t, mapped)
+    # a write-only descriptor (a shell's `>`) takes the fwrite path and writes the same text
+    with open(out, "w") as fo:
+        p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", "3", "--batch", "7"] + args + [ref, reads], stdout=fo, stderr=subprocess.PIPE, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN="1", LAMSA_TRACE="1"))
+    assert p.returncode == 0 and "[write] 0 chunks written through a mapping" in p.stderr, p.stderr[-2000:]
+    assert G.strip_pg(open(out).read()) == G.strip_pg(want)
 
 
 def test_seed_cigars_in_words_when_an_element_does_not_fit_a_byte(cli, tmp_path):
@@ -342,3 +351,77 @@ def test_shards_concatenate_to_the_unsharded_output(cli, name, n, tmp_path):
     assert G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout)
     bad = subprocess.run(base + ["--shard", "3/3", ref, reads], capture_output=True, text=True)
     assert bad.returncode != 0
+
+
+@pytest.mark.parametrize("qfirst", [">", "@"])
+def test_shards_of_a_fastq_whose_quality_lines_begin_like_headers(cli, qfirst, tmp_path):
+    """--shard on an uncompressed FASTQ: '>' (Phred 29) and '@' (Phred 31) are legal first characters of a quality line, and the byte cut of
+    the read file must not take such a line for a record start (kseq, src/kseq.h:179-225, consumes the quality by length).  Without -C the
+    SAM of a mapped read prints '*' for QUAL, so the shards concatenate to the FASTA run's output for every read that maps; unmapped
+    reads print their quality, so the comparison is against the unsharded FASTQ run."""
+    ref, reads, args, gold = G.stage_scenario("c3_ont", str(tmp_path))
+    recs, name, seq = [], None, []
+    for line in open(reads):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            if name is not None:
+                recs.append((name, "".join(seq)))
+            name, seq = line[1:], []
+        else:
+            seq.append(line)
+    recs.append((name, "".join(seq)))
+    fq = str(tmp_path / "reads.fq")
+    with open(fq, "w") as f:
+        for nm, sq in recs:
+            f.write("@%s\n%s\n+\n%s\n" % (nm, sq, qfirst + "I" * (len(sq) - 1)))
+    shutil.copy(reads + ".seed.gem.map", fq + ".seed.gem.map")
+    base = [cli, "aln", "-N", "-R", "0", "--batch", "16"] + args
+    whole = subprocess.run(base + [ref, fq], capture_output=True, text=True)
+    assert whole.returncode == 0, whole.stderr[-2000:]
+    for n in (2, 3, 7):
+        parts = [subprocess.run(base + ["--shard", "%d/%d" % (i, n), ref, fq], capture_output=True, text=True) for i in range(n)]
+        assert all(p.returncode == 0 for p in parts), [p.stderr[-500:] for p in parts]
+        assert G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout), n
+
+
+def test_shard_entry_is_not_fooled_by_a_longer_read_name(cli, tmp_path):
+    """The shard's first line in the GEM map is found by the first read's name; a read whose name has that name plus '_' as a prefix
+    ("r7_x" before "r7") must not be taken for it, and a shard whose first read is shorter than a seed takes the next read's lines."""
+    ref, reads, args, gold = G.stage_scenario("c3_ont", str(tmp_path))
+    text = open(reads).read().split(">")[1:]
+    names = [t.split("\n", 1)[0] for t in text]
+    mid = len(names) // 2
+    # rename: the read just before the middle gets the middle read's name plus "_x"; a 20-base read without seeds is put at the middle
+    new_name = {names[mid - 1]: names[mid] + "_x"}
+    with open(reads, "w") as f:
+        for k, t in enumerate(text):
+            nm, body = t.split("\n", 1)
+            if k == mid:
+                f.write(">tiny\nACGTACGTACGTACGTACGT\n")
+            f.write(">%s\n%s" % (new_name.get(nm, nm), body))
+    lines = open(reads + ".seed.gem.map").read().split("\n")
+    with open(reads + ".seed.gem.map", "w") as f:
+        for ln in lines:
+            if ln:
+                nm, rest = ln.rsplit("_", 1) if "\t" not in ln.split("_")[-1][:0] else (None, None)
+                head, tail = ln.split("\t", 1)
+                rn, seed = head.rsplit("_", 1)
+                f.write("%s_%s\t%s\n" % (new_name.get(rn, rn), seed, tail))
+    base = [cli, "aln", "-N", "-R", "0", "--batch", "16"] + args
+    whole = subprocess.run(base + [ref, reads], capture_output=True, text=True)
+    assert whole.returncode == 0, whole.stderr[-2000:]
+    size = os.path.getsize(reads)
+    pos = open(reads).read().index(">tiny")
+    # choose shard counts whose cut falls at or just before the tiny read, so that it is a shard's first record
+    tried = 0
+    for n in range(2, 40):
+        cuts = [size // n * i for i in range(1, n)]
+        if any(pos - 200 <= c <= pos for c in cuts):
+            parts = [subprocess.run(base + ["--shard", "%d/%d" % (i, n), ref, reads], capture_output=True, text=True) for i in range(n)]
+            assert all(p.returncode == 0 for p in parts), (n, [p.stderr[-500:] for p in parts])
+            assert G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout), n
+            tried += 1
+            if tried >= 2:
+                break
+    parts = [subprocess.run(base + ["--shard", "%d/2" % i, ref, reads], capture_output=True, text=True) for i in range(2)]
+    assert all(p.returncode == 0 for p in parts) and G.strip_pg("".join(p.stdout for p in parts)) == G.strip_pg(whole.stdout)
