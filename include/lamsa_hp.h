@@ -86,9 +86,14 @@ const char *lamsa_hp_last_error(const lamsa_hp_handle *h);
  *   kind 1: ksw_extend_core  src/ksw.c:667   (extension gap penalties, band w, h0)
  *   kind 2: ksw_bi_extend    src/ksw.c:862   (lh0 = rh0 = h0; w ignored)
  *   kind 4, 5, 6: the same three by the one-job-per-lane routines the read path runs its small jobs on (queries up to 160, targets up
- *           to 256 bases without N); kind 7: ksw_extend_core with ksw_bi_extend's band max(|qlen - tlen| + 3, band_w), four jobs per
- *           wavefront (queries up to 127, targets up to 255, one h0 per call).  One class per call.  When the handle's penalties do
- *           not keep 16-bit cells exact these kinds run on the routines of kinds 0-2, as the read path does.
+ *           to 256 bases without N).  When the handle's penalties do not keep 16-bit cells exact these kinds run on the routines of
+ *           kinds 0-2, as the read path does.
+ *   kind 8 .. 11: a job as the read path's wave-per-job launch runs it (targets without N): 8 = a junction's ksw_bi_extend (kind 2),
+ *           9 = a seed gap's ksw_global2 (kind 0), 10 / 11 = a line's head / tail extension -- ksw_extend_r (src/ksw.c:820) /
+ *           ksw_extend_c (:809) with (w, h0); unless the query was consumed the rest of it is appended as a soft clip, and the head's
+ *           CIGAR is turned round (frag_head_bound_fix / frag_tail_bound_fix, src/frag_check.c:640-648, :699-703); score / qle / tle
+ *           are the extension's.
+ *   One class (0-2, 4-6, 8-11) per call.
  * Sequences are 1 byte/base codes 0..4; job i uses query seq[q_off[i] .. q_off[i]+qlen[i])
  * and target seq[t_off[i] .. t_off[i]+tlen[i]).
  * ---------------------------------------------------------------------------------- */
@@ -101,8 +106,8 @@ typedef struct lamsa_hp_dp_jobs {
 } lamsa_hp_dp_jobs;
 
 typedef struct lamsa_hp_dp_out {       /* callee-owned, valid until the next call */
-    const int32_t *score;              /* kind 0/1: DP score; kind 2: return flag */
-    const int32_t *qle, *tle;          /* kind 1 only                             */
+    const int32_t *score;              /* kind 0/1 (4/5, 9-11): DP score; kind 2 (6, 8): return flag */
+    const int32_t *qle, *tle;          /* kind 1 (5, 10, 11) only                 */
     const int32_t *status;             /* LAMSA_HP_ST_* bits                      */
     const int64_t *cig_off;            /* [n_jobs+1] into cigar[]                 */
     const int32_t *cigar;              /* len<<4|op words, ops MIDNSH as in SAM   */
@@ -199,7 +204,9 @@ void  lamsa_hp_host_free(void *p);
  * batch just collected), measured with HIP events on the stream the kernels ran on; which = 0: the main pass,
  * 1: the second pass over the reads that overflowed their scratch (0 when none did); 2..6: the five launches the main
  * pass consists of (chaining round 1, gap fill of its lines, chaining round 2, gap fill of its lines, result assembly); 7..10: how long each of the first four spent draining (first wave
- * that found the queue empty -> last wave done, i.e. time with idle wave slots); 11, 12: lines filled in round 1 / round 2. */
+ * that found the queue empty -> last wave done, i.e. time with idle wave slots); 11, 12: lines filled in round 1 / round 2; 13: of "gap fill, round 1"
+ * the part before the fill launch proper (job listing + the two DP launches), 14: the listing, 15: the wave-per-job DP launch; 16: wave jobs listed,
+ * 17: their algorithmic bytes (MB: sequences read, CIGARs written), 18: lane jobs listed, 19: MB of CIGARs computed ahead of the fill. */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
 
 /* Cap the per-wave scratch slab of the first pass at `bytes` (0 = size it from the batch, the default).  The slab

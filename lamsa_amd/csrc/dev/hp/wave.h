@@ -142,6 +142,8 @@ HP_INL int scan_max_excl_top(Lane<int> &x, int ident) {
 
 // every lane receives the value of the lane below it; lane 0 receives `fill`
 HP_INL void shr1(Lane<int> &x, int fill) { x.v = dpp<0x138>(fill, x.v); }
+// the same round the wave: lane 0 receives lane 63's (wave_ror:1)
+HP_INL void ror1(Lane<int> &x) { x.v = dpp<0x13C>(x.v, x.v); }
 
 // ---- the same inside every 16-lane row of the wave (a DPP "row"): four independent groups of 16 lanes, one DP job each (hp_stripdp.h)
 // every lane of a row receives the row's maximum

@@ -110,52 +110,42 @@ __global__ __launch_bounds__(64, HP_LIST_WAVES_PER_SIMD) void k_filllist(const P
         phase_filllist(a, round, u, blockIdx.x, (HP_L int32_t *)nullptr);
     }
 }
-// the lane-per-job DP over the queues [b0, b1) of the round: the short jobs with HP_LJ_QSMALL-cell rows (a third of the LDS,
-// three times the waves), the long ones with HP_LJ_QCAP-cell rows
-template <int QCAP, int B0, int B1, int HEAD>
-__device__ __forceinline__ void filldp_loop(const PhaseArgs &a, int round, HP_L int32_t *lds)
-{
-    int n = 0;
-    for (int b = B0; b < B1; ++b) n += (a.ctl->lj_bucket_n[round][b] + 63) >> 6;
-    n = wv::uni(n);
-    for (;;) {
-        int g = 0;
-        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[HEAD], 1);
-        g = wv::uni(g);
-        if (g >= n) break;
-        int b = B0;
-        for (; b < B1 - 1; ++b) { const int gb = (a.ctl->lj_bucket_n[round][b] + 63) >> 6; if (g < gb) break; g -= gb; }
-        phase_filldp(a, round, b, g * 64, blockIdx.x, lds, QCAP);
-    }
-}
+// the lane-per-job DP over the round's queues (hp_lanedp.h): 64 jobs per wave, rows of HP_LJ_QSMALL cells per lane in LDS
 __global__ __launch_bounds__(64, 2) void k_filldp_small(const PhaseArgs *ap, int round)
 {
     __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QSMALL)];
-    filldp_loop<HP_LJ_QSMALL, LJ_NBIG, LJ_NBUCKET, 6>(*ap, round, (HP_L int32_t *)lds);
-}
-__global__ __launch_bounds__(64, 1) void k_filldp_big(const PhaseArgs *ap, int round)
-{
-    __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
-    filldp_loop<HP_LJ_QCAP, 0, LJ_NBIG, 7>(*ap, round, (HP_L int32_t *)lds);
-}
-// the junction jobs of the "big" queues, four per wave (hp_stripdp.h): registers only, no LDS
-#ifndef HP_STRIP_WAVES_PER_SIMD
-#define HP_STRIP_WAVES_PER_SIMD 6
-#endif
-__global__ __launch_bounds__(64, HP_STRIP_WAVES_PER_SIMD) void k_filldp_strip(const PhaseArgs *ap, int round)
-{
     const PhaseArgs &a = *ap;
     int n = 0;
-    for (int b = 0; b < LJ_NCLS_BIG; ++b) n += (a.ctl->lj_bucket_n[round][b] + 3) >> 2;
+    for (int b = 0; b < LJ_NBUCKET; ++b) n += (a.ctl->lj_bucket_n[round][b] + 63) >> 6;
+    n = wv::uni(n);
+    for (;;) {
+        int g = 0;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[6], 1);
+        g = wv::uni(g);
+        if (g >= n) break;
+        int b = 0;
+        for (; b < LJ_NBUCKET - 1; ++b) { const int gb = (a.ctl->lj_bucket_n[round][b] + 63) >> 6; if (g < gb) break; g -= gb; }
+        phase_filldp(a, round, b, g * 64, blockIdx.x, (HP_L int32_t *)lds, HP_LJ_QSMALL);
+    }
+}
+// the wave-per-job DP (hp_wavejob.h): the junctions beyond a lane job, the end extensions of every line; costliest class first.  A DP kernel's
+// budget: 4 waves per SIMD, 128 VGPRs, 9.5 KB of LDS per wave (the direction matrix of a 100-row junction stays on the CU).
+#ifndef HP_WJ_WAVES_PER_SIMD
+#define HP_WJ_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(64, HP_WJ_WAVES_PER_SIMD) void k_filldp_wave(const PhaseArgs *ap, int round)
+{
+    __shared__ int32_t lds[HP_WJ_LDS_WORDS];
+    const PhaseArgs &a = *ap;
+    int n = 0;
+    for (int b = 0; b < WJ_NBUCKET; ++b) n += a.ctl->wj_bucket_n[round][b];
     n = wv::uni(n);
     for (;;) {
         int g = 0;
         if (wv::leader()) g = atomicAdd(&a.ctl->q_head[7], 1);
         g = wv::uni(g);
         if (g >= n) break;
-        int b = 0;
-        for (; b < LJ_NCLS_BIG - 1; ++b) { const int gb = (a.ctl->lj_bucket_n[round][b] + 3) >> 2; if (g < gb) break; g -= gb; }
-        phase_filldp_strip(a, round, b, g * 4, blockIdx.x);
+        phase_wavejob(a, round, g, blockIdx.x, (HP_L int32_t *)lds);
     }
 }
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
@@ -225,6 +215,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint8_t *src, int64_t 
 
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static const bool g_trace = getenv("LAMSA_HP_TRACE") != nullptr;      // phase times of the host side on stderr
+static const bool g_nowave = getenv("LAMSA_HP_NO_WAVE_JOBS") != nullptr; // diagnostics: skip the wave-per-job DP launch (the fill then runs the junctions beyond a lane job and the end extensions itself)
 static const bool g_nolane = getenv("LAMSA_HP_NO_LANE_DP") != nullptr;  // diagnostics: skip the lane-per-job DP launches (the fill then runs every DP itself, one job per wave)
 static const bool g_mono = getenv("LAMSA_HP_ONE_KERNEL") != nullptr;  // diagnostics: the main pass through k_align_batch (the retry pass's kernel) instead of the phased launches
 
@@ -272,7 +263,7 @@ struct OutDev {
 struct Slot {                     // one batch on the device: its inputs, the outputs of its main pass, its launch state
     DevBuf bin, misc, slab, pers, prof; OutDev out1;
     HostBuf args_host;            // page-locked copy of the launch sequence's argument block: the asynchronous copy to the device reads it after launch_phased has returned
-    hipEvent_t ep[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass (ep[4]: after the lane DP of round 1)
+    hipEvent_t ep[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // between the phases of the main pass (of round 1: ep[5] after the listing, ep[6] after the wave-per-job DP, ep[4] after the lane DP)
     hipStream_t cs = nullptr;     // the compute stream of this slot: the two slots' kernels run on different streams, so
                                   // that the waves of the next batch fill the SIMDs the tail of the previous one leaves idle
     bool valid = false;           // a batch is resident
@@ -317,7 +308,7 @@ extern "C" void lamsa_hp_release_state_(lamsa_hp_handle *h)
     }
     if (h->stream) hipStreamSynchronize(h->stream);      // batches submitted and never collected
     if (h->stream_b) hipStreamSynchronize(h->stream_b);
-    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.prof.release(); T.args_host.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3], T.ep[4]}) if (e) hipEventDestroy(e); }
+    for (Slot &T : S->slot) { T.bin.release(); T.misc.release(); T.slab.release(); T.pers.release(); T.prof.release(); T.args_host.release(); T.out1.release(); for (hipEvent_t e : {T.e0, T.e1, T.ep[0], T.ep[1], T.ep[2], T.ep[3], T.ep[4], T.ep[5], T.ep[6]}) if (e) hipEventDestroy(e); }
     S->retry_list.release(); S->out2.release(); S->stream.release();
     delete S;
 }
@@ -468,9 +459,9 @@ static int upload_into(lamsa_hp_handle *h, Slot *S, const lamsa_hp_batch *B)
 // waves instead of the fill kernel's 8 192).
 static int cap_waves(int n_waves, size_t slab_per_wave, int n_cu)
 {
-    // a quarter of the device's memory per batch in flight (72 GB of an MI355X's 288 GB), from the device itself
-    static const size_t total = []() { size_t f = 0, t = 0; return hipMemGetInfo(&f, &t) == hipSuccess && t > 0 ? t : (size_t)288 << 30; }();
-    const size_t budget = total / 4;
+    // a quarter of the device's memory per batch in flight (72 GB of an MI355X's 288 GB), from the device itself -- and no more than a third of
+    // what was FREE when this process first asked (another process may hold part of the device: one shard per process and several on a GPU)
+    static const size_t budget = []() { size_t f = 0, t = 0; if (hipMemGetInfo(&f, &t) != hipSuccess || t == 0) { t = (size_t)288 << 30; f = t; } return std::min(t / 4, f / 3); }();
     if (slab_per_wave * (size_t)n_waves <= budget) return n_waves;
     size_t fit = budget / (slab_per_wave ? slab_per_wave : 1);
     if (n_cu > 0 && fit >= (size_t)n_cu) fit -= fit % (size_t)n_cu;
@@ -521,54 +512,69 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
 
 // state of a batch between the launches (hp_phase.h) in one device buffer: per-hit arrays indexed by global hit index + read index,
 // the fragment, line and job arenas, the fill units and their cost-class queues, the job queues of the lane DP
-struct PhasedLayout { size_t bytes, o[13]; int unit_cap, lj_cap; int64_t fl_cap, line_cap, job_cap; };
+struct PhasedLayout { size_t bytes, o[15]; int unit_cap, lj_cap, wj_cap; int64_t fl_cap, line_cap, job_cap; };
 static PhasedLayout phased_layout(int n, int64_t n_hits, int64_t n_bases, int64_t stream_cap)
 {
     PhasedLayout Y;
     const size_t n_ent = (size_t)n_hits + (size_t)n + 1;
     Y.unit_cap = 8 * n + 1024;
-    Y.fl_cap = 4 * n_hits + 2048 * (int64_t)n + 4096; Y.line_cap = stream_cap + 64 * (int64_t)Y.unit_cap;
-    Y.job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + n_bases);          // CIGARs of the small DP jobs (~ 0.2 words per read base)
-    Y.lj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 16 * (int64_t)n + n_bases / 100);   // small DP jobs of a round (~ one per 150 read bases)
+    Y.fl_cap = 4 * n_hits + 2304 * (int64_t)n + 4096; Y.line_cap = stream_cap + 64 * (int64_t)Y.unit_cap;
+    Y.job_cap = std::min<int64_t>(0x7fffff00ll, 4096 + 256 * (int64_t)n + 2 * n_bases);      // CIGARs of the DP jobs computed ahead (~ 0.4 words per read base)
+    Y.lj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 16 * (int64_t)n + n_bases / 100);   // lane DP jobs of a round (~ one per 150 read bases)
+    Y.wj_cap = (int)std::min<int64_t>(0x3fffffffll, 1024 + 32 * (int64_t)n + n_bases / 200);   // wave DP jobs of a round (~ one per 600 read bases, and two per line)
     size_t off = 0;
     auto place = [&](size_t bytes) { size_t o = off; off = al256(off + bytes + 16); return o; };
-    const size_t sz[13] = {sizeof(PhaseArgs), sizeof(PhaseCtl), sizeof(RdMeta) * ((size_t)n + 1), sizeof(NodeS) * n_ent, 4 * n_ent, 8 * n_ent, sizeof(UnitRec) * 2 * (size_t)Y.unit_cap,
-                           4 * 2 * (size_t)PH_NBUCKET * Y.unit_cap, 4 * (size_t)Y.fl_cap, 4 * (size_t)Y.line_cap, 4 * (size_t)Y.job_cap, sizeof(LjRec) * (size_t)Y.lj_cap, 4 * (size_t)LJ_NBUCKET * Y.lj_cap};
-    for (int k = 0; k < 13; ++k) Y.o[k] = place(sz[k]);
+    const size_t sz[15] = {sizeof(PhaseArgs), sizeof(PhaseCtl), sizeof(RdMeta) * ((size_t)n + 1), sizeof(NodeS) * n_ent, 4 * n_ent, 8 * n_ent, sizeof(UnitRec) * 2 * (size_t)Y.unit_cap,
+                           4 * 2 * (size_t)PH_NBUCKET * Y.unit_cap, 4 * (size_t)Y.fl_cap, 4 * (size_t)Y.line_cap, 4 * (size_t)Y.job_cap, sizeof(LjRec) * (size_t)Y.lj_cap, 4 * (size_t)LJ_NBUCKET * Y.lj_cap,
+                           sizeof(WjRec) * (size_t)Y.wj_cap, 4 * (size_t)WJ_NBUCKET * Y.wj_cap};
+    for (int k = 0; k < 15; ++k) Y.o[k] = place(sz[k]);
     Y.bytes = off;
     return Y;
 }
 static int64_t main_stream_cap(int n, int64_t n_bases) { return 1024 + (int64_t)n * 256 + 4 * n_bases; }
 
 // The main pass of the batch in slot `T` as the five launches of hp_phase.h, with the launch resources of slot `Ln`.
-static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, hipEvent_t e0, hipEvent_t e1)
+// scratch of a wave of each kind of launch (all launches of a batch share one allocation, one after the other): the chaining launches keep
+// per-hit arrays, the listing / lane-DP / fill launches result and CIGAR buffers and the small DPs the fill still runs itself, the
+// wave-per-job launch the direction matrix of the longest end extension
+struct SlabPlan { size_t chain, fill, wj; int w_chain, w_fill, w_dp, w_wj; size_t bytes; };
+static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H)
 {
-    const int n = T.n_reads;
-    const int64_t n_hits = T.n_hits;
-    size_t slab_per_wave = slab_bytes_for(h->para, T.max_L, T.max_H, 1);
-    if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
-    int pc = 0, pf = 0, pd = 0;
+    SlabPlan Q;
+    Q.chain = slab_bytes_for(h->para, max_L, max_H, 1);
+    Q.wj = Q.chain;
+    // the fill without the big direction matrix: 256 KiB + 128 B per base, and what a lane-DP group needs
+    Q.fill = al256(((size_t)256 << 10) + 128 * (size_t)max_L + sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
+    if (g_nowave) Q.fill = std::max(Q.fill, Q.chain);                    // (diagnostics: the fill runs every DP itself)
+    if (h->scratch_limit) { Q.chain = std::min(Q.chain, al256(h->scratch_limit)); Q.fill = std::min(Q.fill, al256(h->scratch_limit)); Q.wj = std::min(Q.wj, al256(h->scratch_limit)); }
+    int pc = 0, pf = 0, pd = 0, pw = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
-    int pdb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pdb, k_filldp_big, 64, 0) != hipSuccess || pdb < 1) pdb = 2;
-    int pds = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pds, k_filldp_strip, 64, 0) != hipSuccess || pds < 1) pds = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_filldp_wave, 64, 0) != hipSuccess || pw < 1) pw = 4;
     // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU cap the persistent grids below what fits a CU, so that the launches of two
     // batches in flight can share the CUs instead of the later one waiting for the earlier one's waves to exit
     { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0;
       if (cf > 0 && cf < pf) pf = cf;
       if (cc > 0 && cc < pc) pc = cc; }
-    int w_chain = h->n_cu * pc, w_fill = h->n_cu * pf, w_dp = h->n_cu * pd, w_dpb = h->n_cu * pdb, w_dps = h->n_cu * pds;
-    int n_waves = std::max(std::max(w_chain, w_fill), w_dp);
-    n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
-    w_chain = std::min(w_chain, n_waves); w_fill = std::min(w_fill, n_waves); w_dp = std::min(w_dp, n_waves); w_dpb = std::min(w_dpb, n_waves); w_dps = std::min(w_dps, n_waves);
+    Q.w_chain = cap_waves(h->n_cu * pc, Q.chain, h->n_cu); Q.w_fill = cap_waves(h->n_cu * pf, Q.fill, h->n_cu);
+    Q.w_dp = std::min(h->n_cu * pd, Q.w_fill); Q.w_wj = cap_waves(h->n_cu * pw, Q.wj, h->n_cu);
+    Q.bytes = std::max(std::max(Q.chain * (size_t)Q.w_chain, Q.fill * (size_t)Q.w_fill), Q.wj * (size_t)Q.w_wj);
+    return Q;
+}
+
+// The main pass of the batch in slot `T` as the launch sequence of hp_phase.h, with the launch resources of slot `Ln`.
+static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, OutDev &O, hipEvent_t e0, hipEvent_t e1)
+{
+    const int n = T.n_reads;
+    const int64_t n_hits = T.n_hits;
+    const SlabPlan Q = slab_plan(h, T.max_L, T.max_H);
+    const int w_chain = Q.w_chain, w_fill = Q.w_fill, w_dp = Q.w_dp, w_wj = Q.w_wj;
     const PhasedLayout Y = phased_layout(n, n_hits, T.n_bases, O.stream_cap);
     const int unit_cap = Y.unit_cap, lj_cap = Y.lj_cap; const int64_t fl_cap = Y.fl_cap, line_cap = Y.line_cap, job_cap = Y.job_cap;
     const size_t off = Y.bytes, o_args = Y.o[0], o_ctl = Y.o[1], o_meta = Y.o[2], o_nd = Y.o[3], o_ns = Y.o[4], o_sx = Y.o[5], o_un = Y.o[6], o_bq = Y.o[7], o_fl = Y.o[8], o_ln = Y.o[9],
-                 o_jb = Y.o[10], o_lj = Y.o[11], o_lq = Y.o[12];
-    if (grow(h, Ln.slab, slab_per_wave * (size_t)n_waves) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
+                 o_jb = Y.o[10], o_lj = Y.o[11], o_lq = Y.o[12], o_wj = Y.o[13], o_wq = Y.o[14];
+    if (grow(h, Ln.slab, Q.bytes) || grow(h, Ln.pers, off) || Ln.misc.ensure(256)) { h->err = "hipMalloc(slab)"; return LAMSA_HP_ENOMEM; }
     char *d = (char *)Ln.pers.p;
     PhaseArgs a;
     a.P = h->para;
@@ -576,7 +582,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.in = T.in;
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.read_work = O.work(n); a.out.stream = O.stream(n);
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64); a.out.diag = O.diag(n);
-    a.slab = (char *)Ln.slab.p; a.slab_per_wave = slab_per_wave; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
+    a.slab = (char *)Ln.slab.p; a.slab_per_wave = Q.chain; a.slab_fill = Q.fill; a.slab_wj = Q.wj; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
     a.order = T.d_order; a.n_reads = n; a.prof = nullptr;
 #ifdef HP_PROF
     if (Ln.prof.ensure(sizeof(long long) * 64 * ((size_t)n + 1))) { h->err = "hipMalloc(prof)"; return LAMSA_HP_ENOMEM; }
@@ -587,7 +593,9 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.units = (UnitRec *)(d + o_un); a.unit_cap = unit_cap; a.bucket_q = (int32_t *)(d + o_bq);
     a.fl_base = (int32_t *)(d + o_fl); a.fl_cap = fl_cap; a.line_base = (int32_t *)(d + o_ln); a.line_cap = line_cap; a.ctl = (PhaseCtl *)(d + o_ctl);
     a.job_base = (int32_t *)(d + o_jb); a.job_cap = job_cap;
-    a.ljobs = (LjRec *)(d + o_lj); a.lj_bucket = (int32_t *)(d + o_lq); a.lj_cap = lj_cap;
+    a.ljobs = (LjRec *)(d + o_lj); a.lj_bucket = (int32_t *)(d + o_lq); a.lj_cap = g_nolane ? 0 : lj_cap;
+    a.wjobs = (WjRec *)(d + o_wj); a.wj_bucket = (int32_t *)(d + o_wq); a.wj_cap = g_nowave ? 0 : Y.wj_cap;
+    const bool list = !g_nolane || !g_nowave;
     hipStream_t s = Ln.cs;
     HIPCHK(h, hipMemsetAsync(Ln.misc.p, 0, 128, s), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipMemsetAsync(d + o_ctl, 0, (o_meta - o_ctl) + sizeof(RdMeta) * ((size_t)n + 1), s), LAMSA_HP_EKERNEL);      // counters + per-read state
@@ -598,23 +606,23 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
-    if (!g_nolane) {
+    if (list) {
         hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 0);
-        if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 0);
-        else if (HP_STRIP_RT) hipLaunchKernelGGL(k_filldp_strip, dim3(w_dps), dim3(64), 0, s, da, 0);
-        hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 0);
-    }
+        HIPCHK(h, hipEventRecord(Ln.ep[5], s), LAMSA_HP_EKERNEL);
+        if (!g_nowave) hipLaunchKernelGGL(k_filldp_wave, dim3(w_wj), dim3(64), 0, s, da, 0);       // the long jobs first: the short ones fill the SIMDs its tail leaves idle
+        HIPCHK(h, hipEventRecord(Ln.ep[6], s), LAMSA_HP_EKERNEL);
+        if (!g_nolane) hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 0);
+    } else { HIPCHK(h, hipEventRecord(Ln.ep[5], s), LAMSA_HP_EKERNEL); HIPCHK(h, hipEventRecord(Ln.ep[6], s), LAMSA_HP_EKERNEL); }
     HIPCHK(h, hipEventRecord(Ln.ep[4], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
     HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
-    if (!g_nolane) {
-        HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 12, s), LAMSA_HP_EKERNEL);          // the three queue heads of the lane DP launches
+    if (list) {
+        HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 12, s), LAMSA_HP_EKERNEL);          // the three queue heads of the listing and DP launches
         hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 1);
-        if (HP_LJ_QLIST > HP_LJ_QSMALL) hipLaunchKernelGGL(k_filldp_big, dim3(w_dpb), dim3(64), 0, s, da, 1);
-        else if (HP_STRIP_RT) hipLaunchKernelGGL(k_filldp_strip, dim3(w_dps), dim3(64), 0, s, da, 1);
-        hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);
+        if (!g_nowave) hipLaunchKernelGGL(k_filldp_wave, dim3(w_wj), dim3(64), 0, s, da, 1);
+        if (!g_nolane) hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);
     }
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 1);
     HIPCHK(h, hipEventRecord(Ln.ep[3], s), LAMSA_HP_EKERNEL);
@@ -712,7 +720,10 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
         const unsigned long long *dg = Ln.out1.h_diag(n);          // drain of the four long launches: first wave out -> last wave out (100 MHz ticks)
         for (int k = 0; k < 4; ++k) h->kernel_ms[7 + k] = dg[2 * k + 1] >= dg[2 * k] && dg[2 * k + 1] ? (float)((double)(dg[2 * k + 1] - dg[2 * k]) * 1e-5) : 0.f;
         h->kernel_ms[11] = (float)dg[8]; h->kernel_ms[12] = (float)dg[9];                // fill units of the two rounds
-        hipEventElapsedTime(&h->kernel_ms[13], Ln.ep[0], Ln.ep[4]);                         // of "fill1" (kernel_ms[3]): the lane-per-job DP launch
+        hipEventElapsedTime(&h->kernel_ms[13], Ln.ep[0], Ln.ep[4]);                         // of "fill1" (kernel_ms[3]): listing + the two DP launches
+        hipEventElapsedTime(&h->kernel_ms[14], Ln.ep[0], Ln.ep[5]);                         // ... the listing
+        hipEventElapsedTime(&h->kernel_ms[15], Ln.ep[5], Ln.ep[6]);                         // ... the wave-per-job DP launch
+        h->kernel_ms[16] = (float)dg[12]; h->kernel_ms[17] = (float)((double)dg[13] * 1e-6); h->kernel_ms[18] = (float)dg[14]; h->kernel_ms[19] = (float)((double)dg[15] * 4e-6);   // wave jobs, their algorithmic MB, lane jobs, MB of CIGARs computed ahead
 #ifdef HP_PROF
         prof_report(T, (const long long *)Ln.prof.p, n);
 #endif
@@ -871,15 +882,7 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
     AlignState *S = state_of(h);
     if (S->n_fifo || S->n_res) { h->err = "batches are in flight"; return LAMSA_HP_EINVAL; }
-    size_t slab_per_wave = slab_bytes_for(h->para, max_read_len, max_hits_per_read, 1);
-    if (h->scratch_limit && slab_per_wave > h->scratch_limit) slab_per_wave = al256(h->scratch_limit);
-    int per_cu = 16;                                         // the widest grid of the launch sequence (launch_phased): the fill kernel's
-    { int pc = 0, pf = 0, pd = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) == hipSuccess && pc > per_cu) per_cu = pc;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) == hipSuccess && pf > per_cu) per_cu = pf;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) == hipSuccess && pd > per_cu) per_cu = pd; }
-    int n_waves = h->n_cu * per_cu;
-    n_waves = cap_waves(n_waves, slab_per_wave, h->n_cu);
+    const SlabPlan Q = slab_plan(h, max_read_len, max_hits_per_read);
     const int64_t cap = main_stream_cap(n_reads, n_bases);
     const PhasedLayout Y = phased_layout(n_reads, n_hits, n_bases, cap);
     // the packed input of a batch (upload_into): every array plus its 256-byte alignment, both CIGAR forms' staging included
@@ -887,7 +890,7 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     for (Slot &T : S->slot) {
         int rc = slot_events(h, T);
         if (rc) return rc;
-        if (T.slab.ensure(slab_per_wave * (size_t)n_waves) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) {
+        if (T.slab.ensure(Q.bytes) || T.pers.ensure(Y.bytes) || T.misc.ensure(256) || T.bin.ensure(in_bytes) || T.out1.ensure(n_reads, cap)) {
             for (Slot &U : S->slot) { U.slab.release(); U.pers.release(); U.bin.release(); U.out1.release(); }       // nothing half reserved stays behind: the first batch sizes its own buffers
             h->err = "hipMalloc(reserve)"; return LAMSA_HP_ENOMEM;
         }

@@ -9,7 +9,7 @@
 #include <vector>
 #include <string>
 #include "hp_dp_batch.h"
-#include "hp_stripdp.h"
+#include "hp_wavejob.h"
 
 using namespace hp;
 
@@ -28,9 +28,9 @@ __global__ __launch_bounds__(64) void k_dp_batch(DpBatchArgs a)
     }
 }
 
-// The same jobs by the routines the read path's small-job launches use: kinds 4 / 5 / 6 = ksw_global2 / ksw_extend_core / ksw_bi_extend one
-// job per LANE (hp_lanedp.h, what k_filldp_small runs), kind 7 = ksw_extend_core with ksw_bi_extend's band, four jobs per wave
-// (hp_stripdp.h).  Targets come 2 bits per base (tk: first base of every job in `pac`), as those routines read the reference.
+// The same jobs by the routines the read path's lane-per-job launch uses: kinds 4 / 5 / 6 = ksw_global2 / ksw_extend_core / ksw_bi_extend one
+// job per LANE (hp_lanedp.h, what k_filldp_small runs).  Targets come 2 bits per base (tk: first base of every job in `pac`), as those
+// routines read the reference.
 __global__ __launch_bounds__(64, 1) void k_dp_batch_lane(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
 {
     __shared__ int32_t lds[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
@@ -66,31 +66,28 @@ __global__ __launch_bounds__(64, 1) void k_dp_batch_lane(DpBatchArgs a, const ui
         wv::sync();
     }
 }
-__global__ __launch_bounds__(64, 4) void k_dp_batch_strip(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
+// Kinds 8 .. 11: a job as the wave-per-job launch of the read path runs it (hp_wavejob.h: k_filldp_wave's registers and LDS, sequences staged
+// from the read bytes and the packed reference, the direction matrix in LDS where it fits): 8 = a junction's ksw_bi_extend(h0, h0), 9 = a
+// seed gap's ksw_global2(w), 10 / 11 = a line's head / tail extension (ksw_extend_r / ksw_extend_c with (w, h0), the rest of the query
+// clipped, the head's CIGAR turned round -- frag_check.c:640-648, :699-703).
+__global__ __launch_bounds__(64, 4) void k_dp_batch_wave(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
 {
-    char *slab = a.slab + (size_t)blockIdx.x * a.slab_per_wave;
+    __shared__ int32_t lds[HP_WJ_LDS_WORDS];
     for (;;) {
-        int g = 0;
-        if (wv::leader()) g = atomicAdd(a.counter, 1);
-        g = wv::uni(g);
-        if (g * 4 >= a.n_jobs) break;
-        StripJob J;
-        WAVE_FOR(l) {
-            const int job = g * 4 + (l >> 4);
-            J.on[l] = job < a.n_jobs; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0;
-            if (job < a.n_jobs) { J.q[l] = (long long)(a.seq + a.q_off[job]); J.qlen[l] = a.qlen[job]; J.tlen[l] = a.tlen[job]; J.tk[l] = tk[job]; }
-        }
-        StripRes O;
-        cig_t *cb = (cig_t *)(slab + (size_t)4 * HP_ST_ZROWS * 16 * 4);
-        strip_extend(&a.P, (const HP_G uint8_t *)pac, J, wv::uni(a.h0[g * 4]), (uint32_t *)slab, cb, O);
-        WAVE_FOR(l) {
-            const int job = g * 4 + (l >> 4);
-            if (job < a.n_jobs) {
-                if ((l & 15) == 0) { a.score[job] = O.score[l]; a.qle[job] = O.qle[l]; a.tle[job] = O.tle[l]; a.status[job] = 0; a.cig_n[job] = O.n_cig[l]; }
-                cig_t *dst = a.cig + a.cig_cap_off[job]; const cig_t *src = cb + (size_t)(l >> 4) * HP_ST_CIG;
-                for (int k = l & 15; k < O.n_cig[l]; k += 16) dst[k] = src[k];
-            }
-        }
+        int job = 0;
+        if (wv::leader()) job = atomicAdd(a.counter, 1);
+        job = wv::uni(job);
+        if (job >= a.n_jobs) break;
+        Ctx cx;
+        cx.P = &a.P; cx.lds = (HP_L int32_t *)lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr;
+        arena_init(cx.tmp, a.slab + (size_t)blockIdx.x * a.slab_per_wave, a.slab_per_wave);
+        const int type = wv::uni(a.kind[job]) - 7, qlen = wv::uni(a.qlen[job]), tlen = wv::uni(a.tlen[job]);
+        const bool back = type == WJ_HEAD;
+        CigV out; cig_bind(out, a.cig + a.cig_cap_off[job], (int)(a.cig_cap_off[job + 1] - a.cig_cap_off[job]));
+        WjOut o;
+        wj_run(cx, a.seq, pac, type, 0, a.q_off[job] + (back && qlen > 0 ? qlen - 1 : 0), back ? -1 : 1, qlen, tk[job] + (back && tlen > 0 ? tlen - 1 : 0), back ? -1 : 1, tlen,
+               wv::uni(a.w[job]), wv::uni(a.h0[job]), out, o);
+        if (wv::leader()) { a.score[job] = o.score; a.qle[job] = o.qle; a.tle[job] = o.tle; a.status[job] = cx.status; a.cig_n[job] = out.n; }
         wv::sync();
     }
 }
@@ -144,7 +141,7 @@ extern "C" void lamsa_hp_destroy(lamsa_hp_handle *h)
 }
 
 extern "C" const char *lamsa_hp_last_error(const lamsa_hp_handle *h) { return h ? h->err.c_str() : "null handle"; }
-extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 16) ? h->kernel_ms[which] : -1.f; }
+extern "C" float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which) { return (h && which >= 0 && which < 24) ? h->kernel_ms[which] : -1.f; }
 
 
 extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, lamsa_hp_dp_out *O)
@@ -160,7 +157,7 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         if (ql < 0) ql = 0;
         if (tl < 0) tl = 0;
         if (J->q_off[i] < 0 || J->t_off[i] < 0 || J->q_off[i] + ql > J->seq_bytes || J->t_off[i] + tl > J->seq_bytes) { h->err = "dp job sequence out of range"; return LAMSA_HP_EINVAL; }
-        cap_off[i + 1] = cap_off[i] + ql + tl + 8;
+        cap_off[i + 1] = cap_off[i] + ql + tl + (J->kind[i] >= 8 ? 72 : 8);
         // worst-case scratch of one job: H,E rows + row bounds + direction matrix + 3 temporary CIGARs (bi-extend)
         size_t wmax = (size_t)(abs(ql - tl) + 3 > (J->kind[i] == 2 ? h->para.band_w : J->w[i]) ? abs(ql - tl) + 3 : (J->kind[i] == 2 ? h->para.band_w : J->w[i]));
         size_t ncol = (size_t)ql < 2 * wmax + 1 ? (size_t)ql : 2 * wmax + 1;
@@ -168,24 +165,23 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         size_t need = 2 * 4 * ((size_t)ql + 18) + 8 * ((size_t)tl + 17) + ncol * tl + 64 + 3 * 4 * ((size_t)ql + tl + 24) + 1024;
         if (need > z_need) z_need = need;
     }
-    // kinds 4..7: the lane-per-job / four-per-wave routines (one class per call); they take jobs up to their buffers' sizes and, like the
-    // read path, only when the handle's penalties keep their 16-bit cells exact -- else the jobs run on the wave routines (kind & 3)
-    int cls = 0;                                          // 0: wave routines, 1: a job per lane, 2: four jobs per wave
+    // kinds 4..6: the lane-per-job routines (they take jobs up to their buffers' sizes and, like the read path, only when the handle's penalties
+    // keep their 16-bit cells exact -- else the jobs run on the wave routines, kind - 4); kinds 8..11: a job as the wave-per-job launch runs it.
+    // One class per call.
+    int cls = 0;                                          // 0: wave routines (k_dp_batch), 1: a job per lane, 2: the wave-per-job launch's way
     std::vector<int32_t> kind_v;
     std::vector<uint8_t> pac; std::vector<int64_t> tkv;
     if (n > 0 && J->kind[0] >= 4) {
-        cls = J->kind[0] == 7 ? 2 : 1;
+        cls = J->kind[0] >= 8 ? 2 : 1;
         for (int i = 0; i < n; ++i) {
             const int k = J->kind[i];
-            if (k < 4 || k > 7 || (k == 7) != (cls == 2)) { h->err = "dp batch mixes job classes"; return LAMSA_HP_EINVAL; }
-            if (cls == 2 && J->h0[i] != J->h0[0]) { h->err = "kind 7 jobs of one call share h0"; return LAMSA_HP_EINVAL; }
-            const int qcap = cls == 1 ? HP_LJ_QCAP : HP_ST_QMAX, tcap = cls == 1 ? HP_LJ_TCAP : HP_ST_TMAX;
-            if (J->qlen[i] < 0 || J->qlen[i] > qcap || J->tlen[i] < 0 || J->tlen[i] > tcap || (k != 4 && J->h0[i] <= 0)) { h->err = "dp job beyond the lane routines' buffers"; return LAMSA_HP_EINVAL; }
+            if (k < 4 || k == 7 || k > 11 || (k >= 8) != (cls == 2)) { h->err = "dp batch mixes job classes"; return LAMSA_HP_EINVAL; }
+            if (cls == 1 && (J->qlen[i] < 0 || J->qlen[i] > HP_LJ_QCAP || J->tlen[i] < 0 || J->tlen[i] > HP_LJ_TCAP || (k != 4 && J->h0[i] <= 0))) { h->err = "dp job beyond the lane routines' buffers"; return LAMSA_HP_EINVAL; }
+            if (cls == 2 && (J->qlen[i] < 0 || J->tlen[i] < 0 || (k != 9 && J->h0[i] <= 0))) { h->err = "dp job with a negative length or without a start score"; return LAMSA_HP_EINVAL; }
         }
-        const bool ok16 = cls == 1 ? lj_params_ok(&h->para) : st_params_ok(&h->para, J->h0[0]);
-        if (!ok16) {                                       // as the read path does: these parameters stay on the wave routines
+        if (cls == 1 && !lj_params_ok(&h->para)) {          // as the read path does: these parameters stay on the wave routines
             kind_v.assign(J->kind, J->kind + n);
-            for (int i = 0; i < n; ++i) kind_v[i] = kind_v[i] == 7 ? 1 : kind_v[i] - 4;
+            for (int i = 0; i < n; ++i) kind_v[i] -= 4;
             cls = 0;
         } else {
             int64_t tot = 0;
@@ -196,16 +192,26 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
                 tkv[i] = k;
                 for (int j = 0; j < J->tlen[i]; ++j, ++k) {
                     const uint8_t b = J->seq[J->t_off[i] + j];
-                    if (b > 3) { h->err = "the lane routines read the target 2 bits per base: no N"; return LAMSA_HP_EINVAL; }
+                    if (b > 3) { h->err = "these routines read the target 2 bits per base: no N"; return LAMSA_HP_EINVAL; }
                     pac[(size_t)(k >> 2)] |= (uint8_t)(b << ((~k & 3) << 1));
                 }
             }
-            z_need = cls == 1 ? sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 : (size_t)HP_ST_SLAB_BYTES;
+            if (cls == 1) z_need = sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64;
         }
     }
     const int32_t *kind_src = kind_v.empty() ? J->kind : kind_v.data();
-    const size_t slab_per_wave = al256(z_need);
+    size_t slab_per_wave = al256(z_need);
     int n_waves = h->n_cu * (cls == 1 ? 3 : (cls == 2 ? 16 : 8));
+    if (cls == 2) {   // every job's worst case: the wave routines' scratch (above: computed from the forward band) plus the staged sequences
+        size_t zz = 4096;
+        for (int i = 0; i < n; ++i) {
+            const size_t ql = (size_t)J->qlen[i], tl = (size_t)J->tlen[i];
+            const size_t wmax = std::max<size_t>((size_t)abs((int)ql - (int)tl) + 3, (size_t)std::max(J->w[i], h->para.band_w));
+            const size_t ncol = std::max<size_t>(std::min(ql, 2 * wmax + 1), 256);
+            zz = std::max(zz, 2 * (ql + tl + 64) + 2 * 4 * (ql + 18) + 8 * (tl + 17) + ncol * tl + 64 + 4 * 4 * (ql + tl + 72) + 4096);
+        }
+        slab_per_wave = al256(zz);
+    }
     if (n_waves > n) n_waves = n > 0 ? n : 1;
     while (n_waves > 1 && slab_per_wave * (size_t)n_waves > ((size_t)64 << 30)) n_waves /= 2;
 
@@ -228,12 +234,6 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         HIPCHK(h, hipMemcpyAsync(din + o_ql, J->qlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_tl, J->tlen, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_kind, kind_src, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
-        std::vector<int32_t> w_v;
-        if (!kind_v.empty()) {                              // a kind-7 job on the wave routines: the band ksw_bi_extend gives it (src/ksw.c:873)
-            w_v.assign(J->w, J->w + n);
-            for (int i = 0; i < n; ++i) if (J->kind[i] == 7) { const int d = abs(J->qlen[i] - J->tlen[i]) + 3; w_v[i] = d > h->para.band_w ? d : h->para.band_w; }
-            HIPCHK(h, hipMemcpy(din + o_w, w_v.data(), 4 * (size_t)n, hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
-        } else
         HIPCHK(h, hipMemcpyAsync(din + o_w, J->w, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpyAsync(din + o_h0, J->h0, 4 * (size_t)n, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
     }
@@ -257,7 +257,7 @@ extern "C" int lamsa_hp_dp_batch(lamsa_hp_handle *h, const lamsa_hp_dp_jobs *J, 
         HIPCHK(h, hipMemcpy(h->pac2.p, pac.data(), pac.size(), hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
         HIPCHK(h, hipMemcpy((char *)h->pac2.p + pb, tkv.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice), LAMSA_HP_EKERNEL);
         if (cls == 1) hipLaunchKernelGGL(k_dp_batch_lane, dim3(n_waves), dim3(64), 0, s, a, (const uint8_t *)h->pac2.p, (const int64_t *)((char *)h->pac2.p + pb));
-        else hipLaunchKernelGGL(k_dp_batch_strip, dim3(n_waves), dim3(64), 0, s, a, (const uint8_t *)h->pac2.p, (const int64_t *)((char *)h->pac2.p + pb));
+        else hipLaunchKernelGGL(k_dp_batch_wave, dim3(n_waves), dim3(64), 0, s, a, (const uint8_t *)h->pac2.p, (const int64_t *)((char *)h->pac2.p + pb));
     }
     HIPCHK(h, hipGetLastError(), LAMSA_HP_EKERNEL);
     HIPCHK(h, hipEventRecord(h->ev1, s), LAMSA_HP_EKERNEL);

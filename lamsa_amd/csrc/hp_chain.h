@@ -1545,6 +1545,10 @@ struct FLines {
     // words, target length after clipping at the contig end, 1 = present}: jt[4 * f] for the junction between fragments f and
     // f + 1, gt[4 * p] for the gap in front of the seed at position p of fr_seed
     int32_t *jt, *gt;
+    // the same for the two end extensions of a line (frag_head_bound_fix / frag_tail_bound_fix), computed ahead by the job launch of
+    // hp_wavejob.h: ht[16 * line] = head, ht[16 * line + 8] = tail, eight words per slot {offset into jarena, words, reference bases and
+    // read bases the CIGAR covers, 1 = present, -, -, -}
+    int32_t *ht;
     const int32_t *jarena;
 };
 
@@ -1552,12 +1556,13 @@ struct FLines {
 // hands them from the chaining kernel to the fill kernel through an arena in HBM shared by the batch (`base`, bump
 // cursor advanced once per read and round).
 struct FlStore { int32_t *base; int64_t cap; unsigned long long *cursor; int64_t got_off; int32_t got_tot; };
-HP_INL int flines_words(int line_n, int tot) { return 4 * (line_n + 1) + (tot + 2) + tot + 4 + 8 * (tot + 2); }
+HP_INL int flines_words(int line_n, int tot) { return 4 * (line_n + 1) + (tot + 2) + tot + 4 + 8 * (tot + 2) + 16 * (line_n + 1); }
 HP_INL void flines_bind(FLines &F, int32_t *m, int line_n, int tot)
 {
     F.line_score = m; F.left_bound = m + (line_n + 1); F.right_bound = m + 2 * (line_n + 1); F.frag_off = m + 3 * (line_n + 1);
     F.fr_seed_off = m + 4 * (line_n + 1); F.fr_seed = F.fr_seed_off + (tot + 2);
     F.jt = F.fr_seed + tot + 4; F.gt = F.jt + 4 * (tot + 2);          // fragments <= seeds = tot
+    F.ht = F.gt + 4 * (tot + 2);
     F.jarena = nullptr;
 }
 
@@ -1578,7 +1583,7 @@ HP_NOINL bool build_flines(ReadCtx &r, LSet &L, int line_n, FLines &F, FlStore *
     } else m = (int32_t *)arena_alloc(r.cx, sizeof(int32_t) * (size_t)flines_words(line_n, tot));
     if (!m) return false;
     flines_bind(F, m, line_n, tot);
-    { HP_G int32_t *gj = (HP_G int32_t *)F.jt; const int nw = 8 * (tot + 2); for (int b0 = 0; b0 < nw; b0 += 64) { WAVE_FOR(l) { if (b0 + l < nw) gj[b0 + l] = 0; } } }      // nothing precomputed yet
+    { HP_G int32_t *gj = (HP_G int32_t *)F.jt; const int nw = 8 * (tot + 2) + 16 * (line_n + 1); for (int b0 = 0; b0 < nw; b0 += 64) { WAVE_FOR(l) { if (b0 + l < nw) gj[b0 + l] = 0; } } }      // nothing precomputed yet
     const lamsa_hp_para *P = r.cx.P;
     // Both passes below walk a line node by node with a decision that depends on the previous one, so they stay
     // sequential; what they read about a node is fetched 64 nodes at a time by the lanes and handed out by readlane.

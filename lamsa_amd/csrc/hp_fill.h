@@ -639,6 +639,17 @@ HP_NOINL bool head_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
         read_start = left_bound == 0 ? 0 : r.last_len + left_bound * P->seed_step - P->seed_inv;
     }
     res.offset = r.h_pos[s];
+    {   const int32_t *ht = F.ht ? F.ht + 16 * line : nullptr;
+        if (ht && ht[4] && F.jarena) {                                      // the extension was computed ahead (hp_wavejob.h): its CIGAR, clipped and turned round
+            HP_STAT(20);
+            res.offset -= ht[2];
+            res.refend = res.offset - 1;
+            cig_pushv(cx, res.cig, F.jarena + ht[0], ht[1]);                // _push_cigar_e, frag_check.h:193
+            res.refend += ht[2];
+            res.readend += ht[3];
+            return !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+        }
+    }
     int32_t ref_len = read_len + P->hash_step * 2;
     int64_t ref_start = r.h_pos[s] - ref_len;
     if (ref_start < 1) { ref_start = 1; ref_len = (int32_t)(r.h_pos[s] - 1); }
@@ -681,6 +692,12 @@ HP_NOINL bool tail_fix(ReadCtx &r, const FLines &F, int line, Rec &res)
         read_start = sid(r, r.n_seed[s]) * P->seed_step - P->seed_inv + r.last_len;
         read_len = (right_bound == r.seed_all + 1 ? 0 : P->seed_inv) + (right_bound - 1 - sid(r, r.n_seed[s])) * P->seed_step;
         if (read_len < 0) { cx.status |= ST_REFEXIT; return false; }
+    }
+    {   const int32_t *ht = F.ht ? F.ht + 16 * line + 8 : nullptr;
+        if (ht && ht[4] && F.jarena) {                                      // computed ahead (hp_wavejob.h), clipped
+            HP_STAT(21);
+            return merge_cigar(r, res.cig, &res.refend, &res.readend, r.h_chr[s], F.jarena + ht[0], ht[1], ht[2], ht[3]) && !(cx.status & (ST_REFEXIT | ST_OVERFLOW));
+        }
     }
     int32_t ref_len = read_len + P->hash_step * 2;
     const int64_t ref_start = r.h_pos[s] + P->seed_len + r.h_len_dif[s];

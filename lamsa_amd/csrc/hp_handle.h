@@ -37,7 +37,7 @@ struct lamsa_hp_handle {
     // host-side result storage (callee-owned outputs)
     std::vector<int32_t> h_i32; std::vector<int64_t> h_i64; std::vector<int32_t> h_cig;
     std::vector<int32_t> h_score, h_qle, h_tle, h_status;
-    float kernel_ms[16] = {0};
+    float kernel_ms[24] = {0};
     size_t scratch_limit = 0;      // lamsa_hp_set_scratch_limit
     std::string err;
 };

@@ -22,7 +22,11 @@ namespace hp {
 // LDS direction matrix: a cell needs 4 bits (move into H: 2, "E extends": 1, "F extends": 1; the reference's byte is
 // h | e << 2 | f << 5), 0xF = never written.  A row is filled with 0xFF and every computed cell ANDs its nibble in.
 #define HP_ZSTRIDE(n_col) ((((n_col) + 7) >> 3) << 2)          // bytes per row
-#define HP_ZFITS(n_col, rows) ((size_t)HP_ZSTRIDE(n_col) * (size_t)(rows) <= HP_LDS_Z_BYTES)
+// what the wave's LDS leaves for the matrix behind the rows and the query window: HP_LDS_Z_BYTES in the fill kernel (8 waves per SIMD), ten times
+// that in the job launch of hp_wavejob.h (4 waves per SIMD); the two-columns-per-lane routines keep no rows in LDS and use all of it (z_cap_pk)
+HP_INL size_t z_cap(const Ctx &cx) { const int w = cx.lds_words - (2 * HP_LDS_CELLS + HP_LDS_CELLS / 4); return w > 0 ? (size_t)w * 4 : 0; }
+HP_INL size_t z_cap_pk(const Ctx &cx) { return cx.lds_words > 0 ? (size_t)cx.lds_words * 4 : 0; }
+#define HP_ZFITS(n_col, rows) ((size_t)HP_ZSTRIDE(n_col) * (size_t)(rows) <= z_cap(cx))
 HP_INL int z_nibble(int dir) { return (dir & 3) | ((dir >> 2) & 1) << 2 | ((dir >> 5) & 1) << 3; }
 HP_INL void z_row_clear(HP_L uint8_t *LZ, int row, int n_col) {
     HP_L int *p = (HP_L int *)(LZ + row * HP_ZSTRIDE(n_col));
@@ -40,7 +44,10 @@ HP_INL void z_put(HP_L uint8_t *LZ, int row, int n_col, int c, int dir) {       
 // routine the per-row band limits (rowb) say which cells were written.
 HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const int32_t *rowb, int n_col, int w, int i, int k, CigV &out, int pk_stride = 0)
 {
-    pk_stride = wv::uni(pk_stride);                                        // > 0: the HBM matrix of the two-columns-per-lane routine, a nibble per cell, rows of pk_stride bytes indexed by the column itself
+    pk_stride = wv::uni(pk_stride);                                        // > 0: the matrix of the two-columns-per-lane routines (in HBM, or in LDS with 0xF = never written), a nibble per cell, rows of pk_stride bytes indexed by the column itself
+    // Which matrix: the one in LDS exactly when no slab matrix was handed over.  (Not "lz != nullptr": a null pointer into LDS is offset 0, and the
+    // matrix of the two-columns-per-lane routines BEGINS at offset 0 of the wave's LDS -- DESIGN.md, hazards.)
+    const bool in_lds = z == nullptr;
     const HP_G uint8_t *gz = (const HP_G uint8_t *)wv::uni64((long long)z);
     const HP_G hp_v2i *grb = (const HP_G hp_v2i *)wv::uni64((long long)rowb);     // HBM matrix of the extension routine: [beg, end) of every row
     HP_G cig_t *oc = (HP_G cig_t *)wv::uni64((long long)out.c);
@@ -60,9 +67,11 @@ HP_FN void dp_backtrack(Ctx &cx, const HP_L uint8_t *lz, const uint8_t *z, const
     // one cell of the matrix as the reference's byte; 255 = never written (outside the window or the band)
 #define HP_BT_CELL(ii, kk, cell_) do { const int off_ = (ii) > w ? (ii) - w : 0; cell_ = 255; \
         if ((kk) >= off_ && (kk) - off_ < n_col) { \
-            if (lz) { const int c_ = (kk) - off_, nib_ = (lz[(ii) * zstride + (c_ >> 1)] >> ((c_ & 1) << 2)) & 0xf; \
+            if (in_lds && pk_stride) { const int nib_ = (lz[(ii) * pk_stride + ((kk) >> 1)] >> (((kk) & 1) << 2)) & 0xf; \
                       cell_ = nib_ == 0xf ? 255 : ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)); } \
-            else if (pk_stride) { const int nib_ = (gz[(long)(ii) * pk_stride + ((kk) >> 1)] >> (((kk) & 1) << 2)) & 0xf; \
+            else if (in_lds) { const int c_ = (kk) - off_, nib_ = (lz[(ii) * zstride + (c_ >> 1)] >> ((c_ & 1) << 2)) & 0xf; \
+                      cell_ = nib_ == 0xf ? 255 : ((nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0)); } \
+            else if (pk_stride) { const int nib_ = (gz[(long)(ii) * pk_stride + (((kk) & (2 * pk_stride - 1)) >> 1)] >> (((kk) & 1) << 2)) & 0xf; \
                    cell_ = (nib_ & 3) | ((nib_ & 4) ? 1 << 2 : 0) | ((nib_ & 8) ? 2 << 4 : 0); \
                    if (grb) { const hp_v2i be_ = grb[(ii)]; if (!((kk) >= be_.x && (kk) < be_.y)) cell_ = 255; } } \
             else { const int zc_ = gz[(long)(ii) * n_col + ((kk) - off_)]; \
@@ -933,12 +942,16 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
     const size_t mark = arena_mark(cx.tmp);
-    uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1);
-    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
-    if (!z || !rowb) { arena_release(cx.tmp, mark); return er; }
+    // the matrix in LDS when the wave's share holds it (every byte of a row is written, 0xF = a cell outside the row's band); else in the
+    // slab with the band limits of every row beside it
+    const bool zl = (size_t)zs * (size_t)tlen <= z_cap_pk(cx);
+    uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1);
+    int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
 #ifdef HP_PROF
-    if (cx.prof) { cx.prof[52] += (long long)zs * tlen; cx.prof[53] += 1; }
+    if (!zl && cx.prof) { cx.prof[52] += (long long)zs * tlen; cx.prof[53] += 1; }
 #endif
+    HP_L uint8_t *LZ = (HP_L uint8_t *)cx.lds;
     HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
     HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
     const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
@@ -978,7 +991,7 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
             cells_ += end > beg ? end - beg : 0;
-            { WAVE_FOR(l) { if (l < 2) growb[2 * i + l] = l ? end : beg; } }
+            if (!zl) { WAVE_FOR(l) { if (l < 2) growb[2 * i + l] = l ? end : beg; } }
             int h1_init;
             if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
             else h1_init = 0;
@@ -1028,7 +1041,8 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
                     const int in = inb[c][l];
                     Es[c][l] = pk::sel(in, ee, Es[c][l]);
                     hcur[c][l] = pk::sel(in, h, -1);
-                    if (in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
+                    if (zl) { const int dn = pk::sel(in, d, 0x000f000f); LZ[i * zs + 64 * c + l] = (uint8_t)((dn | (dn >> 12)) & 0xff); }
+                    else if (in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
                 }
                 carry = top > carry ? top : carry;
             }
@@ -1157,8 +1171,241 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
     if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
     else { i = max_ie; k = qlen - 1; }
     er.qle = k + 1; er.tle = i + 1; er.score = max;
-    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out, zs); HP_TADD(cx, 28, tb0_); }
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out, zs); HP_TADD(cx, 28, tb0_); }
     cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
+    arena_release(cx.tmp, mark);
+    HP_TADD(cx, 26, te0_);
+    return er;
+}
+
+// ksw_extend_core for LONG queries -- the end extensions of a line, up to the whole read (frag_head_bound_fix / frag_tail_bound_fix,
+// src/frag_check.c:576-707) -- with the row's live WINDOW in registers, int16 pairs, 2 * NS consecutive columns per lane.
+// A row of the extension only touches the columns [beg, end], at most 2w + 2 of them, and the window only moves right: column j of the
+// reference's eh[] array lives in slot j mod (128 * NS) -- lane (j / (2 NS)) mod 64, register (j mod 2 NS) / 2, half j & 1 -- so a lane holds
+// 2 NS neighbouring columns (NS registers of pairs), then the 2 NS columns 128 NS further on, and so on; the slots of columns the band has
+// left behind are given to the columns ahead of it eight lanes at a time, with the value the reference's first-row initialisation left
+// there (:692-694), i.e. what it reads from its full-length array when the band reaches a cell it never wrote.
+// What that buys over the LDS tiles (ksw_extend_lds: 64 columns per pass, ~90 instructions and eight LDS operations each, four passes
+// for a band of 201): everything a row does across lanes is done ONCE per row whatever NS -- the F scan (a lane scans its own columns,
+// then one exclusive prefix maximum over the lanes' totals, in two halves because the window wraps round the wave), the row maximum
+// (one reduction of (H << 16 | column) keys: "last column among equals" is the larger key, :743-744), the one-column shift of H (inside
+// a lane but for one wave rotation), the first and last non-zero cell (:775-778: a ballot over the lanes, then two lanes' bit patterns).
+// Same recurrences, tie rules, band and z-drop logic as ksw_extend_pk; scores are bounded as there (pkb_extend_ok), the scan's keys use
+// columns relative to the row's first one.  The direction matrix is a nibble per cell in the wave's slab, a row = 64 * NS bytes indexed by
+// the slot, with the band limits of every row beside it.
+HP_INL int pkb_sets(int w) { return 2 * w + 3 + 18 <= 128 ? 1 : (2 * w + 3 + 36 <= 256 ? 2 : (2 * w + 3 + 72 <= 512 ? 4 : 0)); }      // window >= band + 2 + the eight lanes being refilled + one lane of slack
+HP_INL bool pkb_extend_ok(const lamsa_hp_para *P, int qlen, int h0, int ns)
+{
+    const int mx = P->match > P->mis ? P->match : P->mis;
+    const int pen = (P->ins_ext_o > P->del_ext_o ? P->ins_ext_o : P->del_ext_o) + (P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e);
+    const int ext = P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e;
+    return ns > 0 && mx > 0 && mx < 256 && pen >= 0 && pen < 4000 && P->ins_ext_e >= 0 && P->del_ext_e >= 0 && P->ins_ext_o >= 0 && P->del_ext_o >= 0 &&
+           (long long)h0 + (long long)qlen * mx < 23000 && (long long)(128 * ns + 2) * ext < 8000 && qlen + 128 * ns < 32000;
+}
+template <int NS>
+HP_NOINL ExtRes ksw_extend_band(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
+{
+    long long cells_ = 0;
+    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
+    HP_T0(te0_);
+    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
+    const lamsa_hp_para *P = cx.P;
+    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
+    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    constexpr int LC = 2 * NS, WN = 128 * NS, zs = 64 * NS;              // columns per lane, slots of the window, bytes of a row of the direction matrix
+    const size_t mark = arena_mark(cx.tmp);
+    uint8_t *z = (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 16);
+    int32_t *rowb = (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
+    if (!z || !rowb) { arena_release(cx.tmp, mark); return er; }
+#ifdef HP_PROF
+    if (cx.prof) { cx.prof[52] += (long long)zs * tlen; cx.prof[53] += 1; }
+#endif
+    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
+    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
+    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
+    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
+    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
+    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int OEI = pk::rep(oe_ins), OED = pk::rep(oe_del), EI = pk::rep(e_ins), ED = pk::rep(e_del);
+    const int DSC = pk::rep(sc_match - sc_mis), MIS = pk::rep(sc_mis), IDENT = pk::rep(HP_PK_IDENT);
+#define HP_PKB_EH0(j) ((j) == 0 ? h0 : ((j) == 1 ? h1v : (((j) <= qlen && h1v - ((j) - 2) * e_ins > e_ins) ? h1v - ((j) - 1) * e_ins : 0)))      /* first row, :692-694 */
+    // a lane's columns jb .. jb + LC - 1: cells, query bases (one bit of four per column; N and beyond the query: score -1)
+#define HP_PKB_LOAD(jb_) do { \
+        _Pragma("unroll") for (int r_ = 0; r_ < NS; ++r_) { \
+            int hv_[2], oh_ = 0, nn_ = 0; \
+            _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_) { \
+                const int j_ = (jb_) + 2 * r_ + b_; \
+                hv_[b_] = HP_PKB_EH0(j_); \
+                const int code_ = j_ < qlen ? (int)gq[(long)j_ * qs] : 4; \
+                if (code_ < 4) oh_ |= 1 << (code_ + 16 * b_); else nn_ |= (int)(0xffffu << (16 * b_)); \
+            } \
+            Hs[r_][l] = pk::pack(hv_[0], hv_[1]); Es[r_][l] = 0; qoh[r_][l] = oh_; qN[r_][l] = nn_; \
+        } \
+        JB[l] = pk::rep(jb_); } while (0)
+    wv::Lane<int> Hs[NS], Es[NS], qoh[NS], qN[NS], hcur[NS], M[NS], INB[NS], JRE[NS], pre[NS], JB, tl;
+    WAVE_FOR(l) { tl[l] = 4; HP_PKB_LOAD(LC * l); }
+    int top = WN;                                                          // columns [0, top) have been given their slots
+    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
+    int beg = 0, end = qlen;
+    bool stop_rows = false;
+    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
+        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
+        const int ti_first = wv::bcast(tl, 0);
+        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
+        for (int i = ib; i < ie; ++i) {
+            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
+            if (beg < i - w) beg = i - w;                                  // :718-720
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            cells_ += end > beg ? end - beg : 0;
+            { WAVE_FOR(l) { if (l < 2) growb[2 * i + l] = l ? end : beg; } }
+            int h1_init;
+            if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
+            else h1_init = 0;
+            if (beg >= end) {
+                // the row is empty: eh[end] = {h1, 0} (:758), its maximum is 0 and the loop ends (:763) -- nothing reads the cells again
+                if (beg == qlen) { max_ie = gscore > h1_init ? max_ie : i; gscore = gscore > h1_init ? gscore : h1_init; }       // :759-762 (the loop variable stands at beg)
+                stop_rows = true; break;
+            }
+            if (end + 3 > top) {                                           // the band's right edge (next row's at most two further) nears the loaded columns: eight more lanes
+                const int lr = (top / LC) & 63;
+                WAVE_FOR(l) { const int d = (l - lr) & 63; if (d < 8) { const int jb = top + d * LC; HP_PKB_LOAD(jb); } }
+                top += 8 * LC;
+            }
+            const int tsh = ti & 3, tN = ti > 3 ? -1 : 0;                   // a target N scores -1 against everything
+            const int BEG = pk::rep(beg), END = pk::rep(end), H1 = pk::rep(h1_init);
+            const int l0 = (beg / LC) & 63;                                // the lane of the window's first column: lanes l0 .. 63, then 0 .. l0 - 1, hold ascending columns
+            // ---- the lane's own columns: M, the scan keys max(M - oe_ins, 0) + (j - beg) * e_ins and their running maximum
+            wv::Lane<int> ka, kb;
+            WAVE_FOR(l) {
+                int run = HP_PK_IDENT;
+#pragma unroll
+                for (int r = 0; r < NS; ++r) {
+                    const int jp = pk::add(JB[l], pk::pack(2 * r, 2 * r + 1));
+                    const int in = pk::neg_mask(pk::sub(jp, END)) & ~pk::neg_mask(pk::sub(jp, BEG));       // beg <= j < end, per half
+                    const int eq = (qoh[r][l] >> tsh) & 0x00010001;
+                    const int S = pk::add(pk::mul(eq, DSC), MIS) | qN[r][l] | tN;                          // HP_SUB(ti, qb)
+                    const int hm = Hs[r][l];
+                    const int m = pk::mul(pk::add(hm, S), pk::min_u(hm, 0x00010001));                      // hm ? hm + S : 0   (:737; hm is never negative)
+                    const int t1 = pk::max(pk::sub(m, OEI), 0);
+                    const int jre = pk::mul(pk::sub(jp, BEG), EI);
+                    const int k = pk::sel(in, pk::add(t1, jre), IDENT);
+                    const int klo = pk::lo(k), khi = pk::hi(k);
+                    const int p0 = run; run = run > klo ? run : klo;
+                    const int p1 = run; run = run > khi ? run : khi;
+                    M[r][l] = m; INB[r][l] = in; JRE[r][l] = jre; pre[r][l] = pk::pack(p0, p1);
+                }
+                ka[l] = l >= l0 ? run : HP_PK_IDENT; kb[l] = l < l0 ? run : HP_PK_IDENT;
+            }
+            // F along the row: the exclusive prefix maximum over the lanes before this one in column order
+            const int topA = wv::scan_max_excl_top(ka, HP_PK_IDENT);
+            wv::scan_max_excl(kb, HP_PK_IDENT);
+            wv::Lane<int> best;
+            WAVE_FOR(l) {
+                const int pl = l >= l0 ? ka[l] : (topA > kb[l] ? topA : kb[l]);
+                const int PP = pk::rep(pl);
+                int zw = 0, bk = -1;
+#pragma unroll
+                for (int r = 0; r < NS; ++r) {
+                    const int jre = JRE[r][l], in = INB[r][l], m = M[r][l];
+                    const int pr = pk::max(pre[r][l], PP);
+                    int f = pk::max(pk::add(pk::sub(pr, jre), EI), pk::sub(0, jre));                        // F(i,beg) = 0 carried along the row
+                    const int tI = pk::max(pk::sub(m, OEI), 0);
+                    int ee = Es[r][l];
+                    const int m1 = pk::neg_mask(pk::sub(ee, m));                                           // M > E
+                    int h = pk::max(m, ee);                                                                // ties: E over M   :738-739
+                    const int m2 = pk::neg_mask(pk::sub(f, h));                                            // h > F
+                    int d = pk::sel(m2, ~m1 & 0x00010001, 0x00020002);                                     //       F over both :740-741
+                    h = pk::max(h, f);
+                    const int tD = pk::max(pk::sub(m, OED), 0);
+                    ee = pk::sub(ee, ED);
+                    d |= pk::neg_mask(pk::sub(tD, ee)) & 0x00040004;                                       // E extends, :745-750
+                    ee = pk::max(ee, tD);
+                    f = pk::sub(f, EI);
+                    d |= pk::neg_mask(pk::sub(tI, f)) & 0x00080008;                                        // F extends, :751-755
+                    Es[r][l] = pk::sel(in, ee, Es[r][l]);
+                    const int hc = pk::sel(in, h, -1);
+                    hcur[r][l] = hc;
+                    zw |= ((d | (d >> 12)) & 0xff) << (8 * r);
+                    // row maximum, last column among equals (:743-744): the larger of (H << 16 | column); a column outside the band gives a negative key
+                    const int jp = pk::add(JB[l], pk::pack(2 * r, 2 * r + 1));
+                    const int k0 = (int)(((unsigned)hc << 16) | ((unsigned)jp & 0xffffu)), k1 = (int)(((unsigned)hc & 0xffff0000u) | ((unsigned)jp >> 16));
+                    bk = bk > k0 ? bk : k0; bk = bk > k1 ? bk : k1;
+                }
+                best[l] = bk;
+                if constexpr (NS == 1) gz[(long)i * zs + l] = (uint8_t)zw;
+                else if constexpr (NS == 2) *(HP_G uint16_t *)(gz + (long)i * zs + 2 * l) = (uint16_t)zw;
+                else *(HP_G uint32_t *)(gz + (long)i * zs + 4 * l) = (uint32_t)zw;
+            }
+            int mrow = 0, mj = -1;
+            { const int b = wv::reduce_max(best); if (b >= 0) { mrow = b >> 16; mj = b & 0xffff; } }
+            int h_last;                                                     // H(i, end - 1)
+            {
+                const int le = ((end - 1) / LC) & 63, sl = (end - 1) % LC;
+                int v = 0;
+#pragma unroll
+                for (int r = 0; r < NS; ++r) if ((sl >> 1) == r) v = wv::bcast(hcur[r], le);
+                h_last = (sl & 1) ? pk::hi(v) : pk::lo(v);
+            }
+            // eh[j+1].h = H(i,j): the row one column up -- inside the lane, and the lane's first column from the lane below's last
+            wv::Lane<int> rot = hcur[NS - 1], LB;
+            wv::ror1(rot);
+            WAVE_FOR(l) {
+                int bits = 0;
+#pragma unroll
+                for (int r = 0; r < NS; ++r) {
+                    const int below = r > 0 ? hcur[r > 0 ? r - 1 : 0][l] : rot[l];
+                    const int hsh = pk::shift_up(hcur[r][l], below);
+                    const int in = INB[r][l];
+                    const int upd = ~pk::neg_mask(hsh);                    // beg < j <= end (columns the row did not compute arrive as -1)
+                    int hs = Hs[r][l], es = Es[r][l];
+                    hs = pk::sel(upd, hsh, hs);
+                    hs = pk::sel(in & ~upd, H1, hs);                       // j == beg
+                    es &= ~(upd & ~in);                                    // eh[end].e = 0, :758
+                    Hs[r][l] = hs; Es[r][l] = es;
+                    const int nzh = pk::min_u((hs | es) & (in | upd), 0x00010001);      // eh[j] not zero, j in [beg, end]: one bit per half
+                    bits |= ((nzh | (nzh >> 15)) & 3) << (2 * r);
+                }
+                LB[l] = bits;
+            }
+            if (end == qlen) {                                             // :759-762
+                max_ie = gscore > h_last ? max_ie : i;
+                gscore = gscore > h_last ? gscore : h_last;
+            }
+            if (mrow == 0) { stop_rows = true; break; }                    // :763
+            if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
+            else if (zdrop > 0) {                                          // :767-773
+                if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
+                else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
+            }
+            // shrink the band for the next row, :775-778: the first non-zero eh[j] below `end`, the last one from there up to `end`
+            {
+                const unsigned long long any = wv::ballot(LB);
+                int nb = end, jl = end - 1;
+                if (any) {
+                    const unsigned long long rt = l0 ? ((any >> l0) | (any << (64 - l0))) : any;          // bit d: the lane d lanes after l0
+                    const int df = __builtin_ctzll(rt), dl = 63 - __builtin_clzll(rt);
+                    const int bf = wv::bcast(LB, (l0 + df) & 63), bl = wv::bcast(LB, (l0 + dl) & 63);
+                    const int bb = beg / LC;
+                    const int jf = (bb + df) * LC + __builtin_ctz((unsigned)bf), jx = (bb + dl) * LC + (31 - __builtin_clz((unsigned)bl));
+                    if (jf < end) nb = jf;
+                    jl = jx;                                               // (index `end` alone: nb = end, jl = end)
+                }
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+            }
+        }
+    }
+#undef HP_PKB_LOAD
+#undef HP_PKB_EH0
+    int i, k;
+    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
+    else { i = max_ie; k = qlen - 1; }
+    er.qle = k + 1; er.tle = i + 1; er.score = max;
+    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, nullptr, z, rowb, n_col, w, i, k, *out, zs); HP_TADD(cx, 28, tb0_); }
+    cx.n_cells += cells_;
     arena_release(cx.tmp, mark);
     HP_TADD(cx, 26, te0_);
     return er;
@@ -1187,8 +1434,10 @@ HP_NOINL int ksw_global_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int o_del,
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;                 // :559
     const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
     const size_t mark = arena_mark(cx.tmp);
-    uint8_t *z = out ? (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1) : nullptr;
-    if (out && !z) { arena_release(cx.tmp, mark); return 0; }
+    const bool zl = (size_t)zs * (size_t)tlen <= z_cap_pk(cx);            // the matrix in LDS when the wave's share holds it
+    uint8_t *z = (out && !zl) ? (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1) : nullptr;
+    if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
+    HP_L uint8_t *LZ = (HP_L uint8_t *)cx.lds;
     HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
     const int sc_match = wv::uni(cx.P->match), sc_mis = -wv::uni(cx.P->mis);
     const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
@@ -1263,7 +1512,8 @@ HP_NOINL int ksw_global_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int o_del,
                     const int in = inb[c][l];
                     Es[c][l] = pk::sel(in, ee, Es[c][l]);
                     hcur[c][l] = h;
-                    if (out && in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
+                    if (out && zl) LZ[i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);     // (the traceback of a global alignment stays inside the band)
+                    else if (out && in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
                 }
                 carry = top > carry ? top : carry;
             }
@@ -1293,7 +1543,7 @@ HP_NOINL int ksw_global_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int o_del,
         const int k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;           // :638
         wv::sync();
         HP_T0(tb0_);
-        dp_backtrack(cx, nullptr, z, nullptr, n_col, w, i, k, *out, zs);
+        dp_backtrack(cx, zl ? LZ : nullptr, z, nullptr, n_col, w, i, k, *out, zs);
         HP_TADD(cx, 28, tb0_);
     }
     cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
@@ -1512,6 +1762,11 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
     if (qlen <= HP_REG_QMAX) er = ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out);
     else if (HP_PK_RT && qlen <= HP_PK_QMAX(2) && pk_extend_ok(cx.P, qlen, h0))
         { HP_STAT(16); er = qlen <= HP_PK_QMAX(1) ? ksw_extend_pk<1>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_pk<2>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (HP_PK_RT && qlen > HP_PK_QMAX(2) && pkb_extend_ok(cx.P, qlen, h0, pkb_sets(w))) {
+        HP_STAT(22);
+        const int ns = pkb_sets(w);
+        er = ns == 1 ? ksw_extend_band<1>(cx, qlen, q, tlen, t, w, h0, out) : (ns == 2 ? ksw_extend_band<2>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_band<4>(cx, qlen, q, tlen, t, w, h0, out));
+    }
     else if (qlen <= HP_REGN_QMAX(2)) { HP_STAT(17); er = ksw_extend_regn<2>(cx, qlen, q, tlen, t, w, h0, out); }
     else if (qlen <= HP_REGN_QMAX(3) && HP_REGN_SETS >= 3) { HP_STAT(17); er = ksw_extend_regn<3>(cx, qlen, q, tlen, t, w, h0, out); }
     else if (qlen <= HP_REGN_QMAX(4) && HP_REGN_SETS >= 4) { HP_STAT(17); er = ksw_extend_regn<4>(cx, qlen, q, tlen, t, w, h0, out); }

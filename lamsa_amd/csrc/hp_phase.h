@@ -1,6 +1,8 @@
 // hp_phase.h -- the per-read path of hp_align.h cut at frag_dp_path into separate launches:
 //
 //   chain1  (one read per wave)   sort index, frag_line_BCC                       lamsa_dp_con.c:1305-1445
+//   list    (one LINE per wave)   the line's DP jobs into the queues of the batch (small ones for the lane-per-job launch, the others for the wave-per-job launch)
+//   dp      (64 jobs / one job per wave)   hp_lanedp.h / hp_wavejob.h: the CIGARs into the job arena
 //   fill    (one LINE per wave)   frag_check of one line of round 1 + its get_reg  frag_check.c:856-961, lamsa_aln.c:571-605
 //   chain2  (one read per wave)   get_remain_reg, frag_line_remain                lamsa_aln.c:550-569, lamsa_dp_con.c:1252-1302
 //   fill    (one LINE per wave)   frag_check of one line of round 2
@@ -19,7 +21,7 @@
 #pragma once
 #include "hp_align.h"
 #include "hp_lanedp.h"
-#include "hp_stripdp.h"
+#include "hp_wavejob.h"
 
 namespace hp {
 
@@ -47,7 +49,9 @@ struct PhaseCtl {                // counters of one launch sequence, zeroed befo
     int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
     int32_t bucket_n[2][PH_NBUCKET];
     unsigned long long fl_cursor, line_cursor, job_cursor;
-    int32_t lj_n[2], lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (size group x kind x query-length class; LJ_NBUCKET <= 24)
+    int32_t lj_n[2], lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (kind x query-length class; LJ_NBUCKET <= 24)
+    int32_t wj_n[2], wj_bucket_n[2][WJ_NBUCKET];      // wave-per-job DP (hp_wavejob.h): jobs listed per round, and per cost class
+    unsigned long long wj_bytes;                       // algorithmic bytes of the wave-per-job launches: query bases + 2-bit target bases read, CIGAR words + slots written
     // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
     // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
     // draining, i.e. with idle wave slots
@@ -74,6 +78,8 @@ struct PhaseArgs {
     int32_t *line_base; int64_t line_cap;        // line arena (words)
     int32_t *job_base; int64_t job_cap;          // CIGARs of the lane-per-job DPs (words, < 2^31)
     struct LjRec *ljobs; int32_t *lj_bucket; int32_t lj_cap;     // [lj_cap] job records and [LJ_NBUCKET][lj_cap] queues of job indices of the round being filled
+    WjRec *wjobs; int32_t *wj_bucket; int32_t wj_cap;            // the same for the wave-per-job launch: [wj_cap] records, [WJ_NBUCKET][wj_cap] queues; wj_cap 0: no such launch
+    size_t slab_fill, slab_wj;                                   // scratch of a wave of the listing / lane-DP / fill launches and of the wave-per-job launch (slab_per_wave: the chaining launches)
     PhaseCtl *ctl;
 };
 
@@ -191,7 +197,7 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
     if (*(volatile int32_t *)&M.status & ST_DEAD) return;       // the read is lost already (another line or phase failed)
     PH_T0();
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, HP_LDS_WORDS);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_fill, a.slab_fill, lds, a.prof, HP_LDS_WORDS);
     pers_bind(r, a, rd);
     Ctx &cx = r.cx;
     FLines F;
@@ -247,37 +253,73 @@ HP_NOINL void phase_fill(const PhaseArgs &a, int round, int u, int wave_slot, HP
 }
 
 
-// ---------------------------------------------------------------- fill, step 1: the small DP jobs of the lines, one job per lane
-// (hp_lanedp.h).  phase_filllist (one line per wave) lists the line's junctions of the mismatch class with read bases in between
-// (split_mapping, frag_check.c:547-559) and the gaps between neighbouring seeds of its fragments (frag_extend, :360-400), with
-// the geometry the fill would compute, into job queues of the whole batch by kind and query length; phase_filldp (64 jobs per
-// wave, longest queries first, so that the lanes of a wave run alike) leaves the CIGARs in the job arena and their slots in
-// FLines::jt / gt, where the fill finds them.
-// Which jobs are listed for the lanes.  Measured on the MI355X (profiles/r02_*): jobs with queries of up to 64 bases are cheaper one per
-// lane than one per wave; longer ones (rows of 160 cells need 52 KB of LDS per wave, three waves per CU) are not, and stay with the
-// wave-per-job routines unless HP_LJ_BIG is set.
-#ifdef HP_LJ_BIG
-#define HP_LJ_QLIST HP_LJ_QCAP
-#define HP_LJ_TLIST HP_LJ_TCAP
-#else
-#define HP_LJ_QLIST HP_LJ_QSMALL
-#define HP_LJ_TLIST HP_LJ_TSMALL
-#endif
-// Junction jobs (type 1) beyond that, up to HP_ST_QMAX query bases, can be listed for the four-jobs-per-wave routine of hp_stripdp.h (into
-// the "big" queues).  OFF in the product: measured on the MI355X (profiles/r03_strip_dp.txt) the routine takes 28 ms per step for the
-// 1.0 M jobs of the ont10k batch and saves the fill kernel 19 ms -- a cell costs ~25 lane operations however the lanes are dealt out, and
-// the 27 % of the jobs whose left extension does not end the call are computed twice.  The tests' CPU build runs it both ways.
-#ifndef HP_STRIP_RT
-#define HP_STRIP_RT 0
-#endif
+// ---------------------------------------------------------------- fill, step 1: the DP jobs of the lines, computed ahead of the fill.
+// phase_filllist (one line per wave) lists the line's junctions of the mismatch class with read bases in between (split_mapping,
+// frag_check.c:547-559), the gaps between neighbouring seeds of its fragments (frag_extend, :360-400) and its two end extensions
+// (frag_head_bound_fix :576-654, frag_tail_bound_fix :656-707), with the geometry the fill would compute, into job queues of the whole batch:
+// jobs with queries of up to HP_LJ_QSMALL bases by kind and query length for phase_filldp (64 jobs per wave, one per LANE, hp_lanedp.h:
+// measured on the MI355X they are cheaper that way than one per wave, profiles/r02_*), everything else by cost for phase_wavejob (one job per
+// WAVE, hp_wavejob.h).  Both leave the CIGARs in the job arena and their slots in FLines::jt / gt / ht, where the fill finds them.
 struct LjRec { int64_t qaddr, tk, slot; int32_t rd; uint16_t tlen; uint8_t qlen; int8_t type_comp; };      // type_comp: type (1: ksw_bi_extend(100, 100), 2: ksw_global2) | complement << 4
-// queues: [big jobs (query > HP_LJ_QSMALL): kind 1 longest first, kind 2 longest first][short jobs: the same]; LJ_NBIG queues are "big"
-enum { LJ_NCLS_BIG = (HP_LJ_QCAP - HP_LJ_QSMALL) / 16, LJ_NCLS_SMALL = HP_LJ_QSMALL / 16, LJ_NBIG = 2 * LJ_NCLS_BIG, LJ_NBUCKET = 2 * (LJ_NCLS_BIG + LJ_NCLS_SMALL) };
-HP_INL int lj_bucket_of(int type, int qlen, int tlen)
+// queues of the lane jobs: kind 1 longest first, kind 2 longest first
+enum { LJ_NCLS = HP_LJ_QSMALL / 16, LJ_NBUCKET = 2 * LJ_NCLS };
+HP_INL int lj_bucket_of(int type, int qlen)
 {
-    const int cls = (qlen > 0 ? qlen - 1 : 0) >> 4;                            // 0 .. HP_LJ_QCAP / 16 - 1
-    if (qlen > HP_LJ_QSMALL || tlen > HP_LJ_TSMALL) { int c = cls < LJ_NCLS_SMALL ? LJ_NCLS_SMALL : cls; if (c > LJ_NCLS_SMALL + LJ_NCLS_BIG - 1) c = LJ_NCLS_SMALL + LJ_NCLS_BIG - 1; return (type == 1 ? 0 : LJ_NCLS_BIG) + (LJ_NCLS_BIG - 1 - (c - LJ_NCLS_SMALL)); }
-    return LJ_NBIG + (type == 1 ? 0 : LJ_NCLS_SMALL) + (LJ_NCLS_SMALL - 1 - cls);
+    const int cls = (qlen > 0 ? qlen - 1 : 0) >> 4;                            // 0 .. HP_LJ_QSMALL / 16 - 1
+    return (type == 1 ? 0 : LJ_NCLS) + (LJ_NCLS - 1 - cls);
+}
+
+// end extension of line `line` as frag_head_bound_fix (head) / frag_tail_bound_fix computes it, with the line's bounds as the fill will see
+// them (a '-' line's are flipped, frag_check.c:926-930; r.flip must be set accordingly).  false: there is no DP to run ahead (no read base
+// to extend over, or a geometry the reference exits on, which is left to the fill to flag).
+struct EndGeo { int s, read_start, read_len, chr; int64_t start0; int32_t ref_len; };
+HP_INL bool end_geo(const ReadCtx &r, const FLines &F, int line, int strand, bool head, EndGeo &G)
+{
+    const lamsa_hp_para *P = r.cx.P;
+    const int f0 = F.frag_off[line], fl = F.frag_off[line + 1] - 1;
+    const int lb = strand == 1 ? F.left_bound[line] : r.seed_all + 1 - F.right_bound[line];
+    const int rb = strand == 1 ? F.right_bound[line] : r.seed_all + 1 - F.left_bound[line];
+    const int s_first = F.fr_seed[F.fr_seed_off[f0]], s_last = F.fr_seed[F.fr_seed_off[fl + 1] - 1];
+    int64_t ref_start;
+    if (head) {                                                                  // :592-640
+        if (strand == 1) {
+            G.s = s_last;
+            const int id = sid(r, r.n_seed[G.s]);
+            if (id == 1) return false;
+            G.read_len = (lb == 0 ? 0 : P->seed_inv) + (id - lb - 1) * P->seed_step;
+            G.read_start = lb == 0 ? 0 : lb * P->seed_step - P->seed_inv;
+        } else {
+            G.s = s_first;
+            G.read_len = (lb == 0 ? r.last_len : P->seed_inv) + (sid(r, r.n_seed[G.s]) - 1 - lb) * P->seed_step;
+            G.read_start = lb == 0 ? 0 : r.last_len + lb * P->seed_step - P->seed_inv;
+        }
+        if (G.read_len <= 0) return false;
+        G.ref_len = G.read_len + P->hash_step * 2;
+        ref_start = r.h_pos[G.s] - G.ref_len;
+        if (ref_start < 1) { ref_start = 1; G.ref_len = (int32_t)(r.h_pos[G.s] - 1); }
+    } else {                                                                     // :670-699
+        if (strand == 1) {
+            G.s = s_first;
+            const int id = sid(r, r.n_seed[G.s]);
+            G.read_start = id * P->seed_step - P->seed_inv;
+            G.read_len = (rb == r.seed_all + 1 ? r.last_len : P->seed_inv) + (rb - 1 - id) * P->seed_step;
+        } else {
+            G.s = s_last;
+            const int id = sid(r, r.n_seed[G.s]);
+            if (id == r.seed_all) return false;
+            G.read_start = id * P->seed_step - P->seed_inv + r.last_len;
+            G.read_len = (rb == r.seed_all + 1 ? 0 : P->seed_inv) + (rb - 1 - id) * P->seed_step;
+        }
+        if (G.read_len <= 0) return false;
+        G.ref_len = G.read_len + P->hash_step * 2;
+        ref_start = r.h_pos[G.s] + P->seed_len + r.h_len_dif[G.s];
+    }
+    G.chr = r.h_chr[G.s];
+    G.start0 = ref_start - 1;                                                    // pac2fa_core, bntseq.c:469-474
+    const int32_t clen = r.ref.seq_len[G.chr - 1];
+    if (G.start0 > clen || G.start0 < 0) return false;
+    if (G.start0 + G.ref_len > clen) G.ref_len = (int32_t)(clen - G.start0);
+    return G.ref_len > 0 && G.read_start >= 0 && G.read_start + G.read_len <= r.L;
 }
 
 HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot, HP_L int32_t *lds)
@@ -287,18 +329,18 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
     RdMeta &M = a.meta[rd];
     if (*(volatile int32_t *)&M.status & ST_DEAD) return;
     ReadCtx r;
-    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave, lds, a.prof, 0);
+    read_bind(r, a.P, a.ref, a.in, rd, a.slab + (size_t)wave_slot * a.slab_fill, a.slab_fill, lds, a.prof, 0);
     pers_bind(r, a, rd);
     const lamsa_hp_para *P = r.cx.P;
-    if (!lj_params_ok(P)) return;
-    const bool strip_ok = st_params_ok(P, 100) && (size_t)HP_ST_SLAB_BYTES <= a.slab_per_wave;
+    const bool lane_ok = lj_params_ok(P) && a.lj_cap > 0, wave_ok = a.wj_cap > 0;
+    if (!lane_ok && !wave_ok) return;
     FLines F;
     F.n = M.fl_n[round]; F.nfrag = M.fl_nfrag[round];
     flines_bind(F, a.fl_base + M.fl_off[round], F.n, M.fl_tot[round]);
     const int f0 = F.frag_off[line], nfr = F.frag_off[line + 1] - f0;
     const int p0 = F.fr_seed_off[f0], np = F.fr_seed_off[f0 + nfr] - p0;       // the line's seeds in fr_seed
     const int strand = r.h_strand[F.fr_seed[p0]];
-    const int n_cand = (nfr - 1) + np;
+    const int n_junc = (nfr - 1) + np, n_cand = n_junc + 2;                    // junctions, seed gaps, then the head and the tail extension
     r.flip = strand != 1;                                                      // seed ids as a '-' line sees them (frag_check.c:926)
     const int64_t rbase = a.in.read_off[rd];
     long long tb = 0;
@@ -312,10 +354,11 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
         wv::sync();
     }
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
-        wv::Lane<int> ty, qo, ql, tl; wv::Lane<long long> tk, sl;
+        // ty: 0 none, 1 / 2 junction / seed gap (WJ_BI / WJ_GLOBAL), 3 / 4 head / tail; qo: where the query begins in the strand-appropriate read
+        wv::Lane<int> ty, qo, ql, tl, qrev; wv::Lane<long long> tk, sl;
         WAVE_FOR(l) {
             const int c = c0 + l;
-            int type = 0, qoff = 0, qlen = 0, tlen = 0; long long k0 = 0, slot = 0;
+            int type = 0, qoff = 0, qlen = 0, tlen = 0, rev = 0; long long k0 = 0, slot = 0;
             if (c < nfr - 1) {                                                  // junction between fragments jf and jf + 1, split_mapping :416-470
                 const int jf = f0 + c;
                 const int f1 = strand == 1 ? jf + 1 : jf, f2 = strand == 1 ? jf : jf + 1;
@@ -330,20 +373,17 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                 const int64_t exp = at1_off + at1_ld + (int64_t)(did * P->seed_step);
                 const int dis = (int)(at2_off - exp);
                 const int match_dis = P->match_dis * ((P->aln_mode & 2) ? did : 1);
-                const int q_list = (HP_STRIP_RT && strip_ok && HP_ST_QMAX > HP_LJ_QLIST) ? HP_ST_QMAX : HP_LJ_QLIST;
-                if (s_qlen > 0 && s_qlen <= q_list && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
+                if (s_qlen > 0 && dis <= match_dis && dis >= -match_dis && s_qlen + dis >= 0) {
                     const int64_t start0 = at1_off + P->seed_len + at1_ld - 1;
                     const int32_t clen = r.ref.seq_len[at1_chr - 1];
                     if (start0 <= clen && start0 >= 0) {                        // pac2fa_core, bntseq.c:469-474
                         int tl_ = s_qlen + dis;
                         if (start0 + tl_ > clen) tl_ = (int)(clen - start0);
-                        if ((s_qlen <= HP_LJ_QLIST && tl_ <= HP_LJ_TLIST) || (HP_STRIP_RT && strip_ok && s_qlen <= HP_ST_QMAX && tl_ <= HP_ST_TMAX)) {
-                            type = 1; qlen = s_qlen; tlen = tl_; slot = (F.jt + 4 * jf) - a.fl_base; k0 = r.ref.seq_off[at1_chr - 1] + start0;
-                            qoff = (strand == 1 ? 0 : r.last_len) + id1 * P->seed_step - P->seed_inv;      // get_read_intv, :116
-                        }
+                        type = 1; qlen = s_qlen; tlen = tl_; slot = (F.jt + 4 * jf) - a.fl_base; k0 = r.ref.seq_off[at1_chr - 1] + start0;
+                        qoff = (strand == 1 ? 0 : r.last_len) + id1 * P->seed_step - P->seed_inv;      // get_read_intv, :116
                     }
                 }
-            } else if (c < n_cand) {                                            // gap in front of the seed at position p, frag_extend :360-385
+            } else if (c < n_junc) {                                            // gap in front of the seed at position p, frag_extend :360-385
                 const int p = p0 + (c - (nfr - 1));
                 const int lo = ((const HP_G int32_t *)frag_of)[p - p0];        // its fragment
                 const int fb = F.fr_seed_off[lo], fe = F.fr_seed_off[lo + 1], i = p - fb, seed_n = fe - fb;
@@ -360,43 +400,89 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                     const int idl = sid(r, r.n_seed[last]), ids = sid(r, r.n_seed[s]);
                     const int qi = (strand == 1 ? 0 : r.last_len) + idl * P->seed_step - P->seed_inv, qe = (strand == 1 ? 0 : r.last_len) + (ids - 1) * P->seed_step;
                     const int len1 = qe > qi ? qe - qi : 0;
-                    if (ok && len1 <= HP_LJ_QLIST && len2 <= HP_LJ_TLIST) {
-                        type = 2; qlen = len1; tlen = len2; slot = (F.gt + 4 * p) - a.fl_base; qoff = qi; k0 = r.ref.seq_off[r.h_chr[last] - 1] + start;
-                    }
+                    if (ok) { type = 2; qlen = len1; tlen = len2; slot = (F.gt + 4 * p) - a.fl_base; qoff = qi; k0 = r.ref.seq_off[r.h_chr[last] - 1] + start; }
+                }
+            } else if (c < n_cand && wave_ok) {                                 // the end extensions, frag_head_bound_fix :576 / frag_tail_bound_fix :656
+                const bool head = c == n_junc;
+                EndGeo G;
+                if (end_geo(r, F, line, strand, head, G)) {
+                    type = head ? 3 : 4; qlen = G.read_len; tlen = G.ref_len; slot = (F.ht + 16 * line + (head ? 0 : 8)) - a.fl_base;
+                    // the head runs on both sequences reversed (ksw_extend_r, src/ksw.c:820): query base j = base read_len - 1 - j of the interval
+                    qoff = head ? G.read_start + G.read_len - 1 : G.read_start; rev = head;
+                    k0 = r.ref.seq_off[G.chr - 1] + G.start0 + (head ? G.ref_len - 1 : 0);
                 }
             }
-            ty[l] = type; qo[l] = qoff; ql[l] = qlen; tl[l] = tlen; sl[l] = slot; tk[l] = k0;
+            // which launch takes it
+            const bool small = type != 0 && type <= 2 && qlen <= HP_LJ_QSMALL && tlen <= HP_LJ_TSMALL;
+            if (type != 0 && !(small ? lane_ok : wave_ok)) type = 0;
+            if (type != 0 && !small) type |= 16;                                // bit 4: a job of the wave-per-job launch
+            ty[l] = type; qo[l] = qoff; ql[l] = qlen; tl[l] = tlen; sl[l] = slot; tk[l] = k0; qrev[l] = rev;
         }
-        wv::Lane<int> has;
-        WAVE_FOR(l) has[l] = ty[l] != 0;
-        const unsigned long long m = wv::ballot(has);
-        if (!m) continue;
-        const int cnt = __builtin_popcountll(m);
-        int base = 0;
-        if (wv::leader()) base = atomicAdd(&a.ctl->lj_n[round], cnt);
-        base = wv::uni(base);
-        if (base + cnt > a.lj_cap) continue;                                    // queue full: these stay with the fill
-        wv::Lane<int> at, tbl;
-        WAVE_FOR(l) {
-            at[l] = base + __builtin_popcountll(m & ((1ull << l) - 1)); tbl[l] = ty[l] ? tl[l] : 0;
-            if (ty[l]) {
-                LjRec &J = a.ljobs[at[l]];
-                // the query in the read as stored: a '-' line reads the reverse complement, base j of it is the complement of base L-1-j
-                J.qaddr = strand == 1 ? rbase + qo[l] : rbase + (r.L - 1 - qo[l]);
-                J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = (uint8_t)ql[l]; J.tlen = (uint16_t)tl[l]; J.type_comp = (int8_t)(ty[l] | (strand == 1 ? 0 : 16));
-            }
+        wv::Lane<int> has, big, tbl;
+        WAVE_FOR(l) { has[l] = ty[l] != 0 && !(ty[l] & 16); big[l] = (ty[l] & 16) != 0; tbl[l] = ty[l] ? tl[l] : 0; }
+        const unsigned long long m = wv::ballot(has), mw = wv::ballot(big);
+        if (m) {                                                                // ---- the lane jobs
+            const int cnt = __builtin_popcountll(m);
+            int base = 0;
+            if (wv::leader()) base = atomicAdd(&a.ctl->lj_n[round], cnt);
+            base = wv::uni(base);
+            if (base + cnt <= a.lj_cap) {                                       // (queue full: these stay with the fill)
+                wv::Lane<int> at;
+                WAVE_FOR(l) {
+                    at[l] = base + __builtin_popcountll(m & ((1ull << l) - 1));
+                    if (has[l]) {
+                        LjRec &J = a.ljobs[at[l]];
+                        // the query in the read as stored: a '-' line reads the reverse complement, base j of it is the complement of base L-1-j
+                        J.qaddr = strand == 1 ? rbase + qo[l] : rbase + (r.L - 1 - qo[l]);
+                        J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = (uint8_t)ql[l]; J.tlen = (uint16_t)tl[l]; J.type_comp = (int8_t)(ty[l] | (strand == 1 ? 0 : 16));
+                    }
+                }
+                for (int b = 0; b < LJ_NBUCKET; ++b) {                          // into the queue of its kind and length class
+                    wv::Lane<int> inb;
+                    WAVE_FOR(l) inb[l] = has[l] && lj_bucket_of(ty[l], ql[l]) == b;
+                    const unsigned long long mb = wv::ballot(inb);
+                    if (!mb) continue;
+                    int bb = 0;
+                    if (wv::leader()) bb = atomicAdd(&a.ctl->lj_bucket_n[round][b], __builtin_popcountll(mb));
+                    bb = wv::uni(bb);
+                    WAVE_FOR(l) { if (inb[l]) a.lj_bucket[(size_t)b * a.lj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                }
+            } else { WAVE_FOR(l) { if (has[l]) tbl[l] = 0; } }
+        }
+        if (mw) {                                                               // ---- the wave jobs
+            const int cnt = __builtin_popcountll(mw);
+            int base = 0;
+            if (wv::leader()) base = atomicAdd(&a.ctl->wj_n[round], cnt);
+            base = wv::uni(base);
+            if (base + cnt <= a.wj_cap) {
+                wv::Lane<int> at, bk;
+                WAVE_FOR(l) {
+                    at[l] = base + __builtin_popcountll(mw & ((1ull << l) - 1)); bk[l] = -1;
+                    if (big[l]) {
+                        const int type = ty[l] & 15;
+                        WjRec &J = a.wjobs[at[l]];
+                        // query base j of the job = base qo + j (qo - j when walked backwards) of the strand-appropriate read; in the read as
+                        // stored a '-' line's base x is the complement of base L - 1 - x, so its walk runs the other way
+                        const int back = qrev[l] ? 1 : 0, comp = strand == 1 ? 0 : 1;
+                        J.qaddr = strand == 1 ? rbase + qo[l] : rbase + (r.L - 1 - qo[l]);
+                        J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = ql[l]; J.tlen = tl[l];
+                        J.type_comp = type | (comp << 4) | ((back ^ comp) << 5) | (back << 6);
+                        bk[l] = wj_bucket_of(P, type, ql[l], tl[l]);
+                    }
+                }
+                for (int b = 0; b < WJ_NBUCKET; ++b) {
+                    wv::Lane<int> inb;
+                    WAVE_FOR(l) inb[l] = bk[l] == b;
+                    const unsigned long long mb = wv::ballot(inb);
+                    if (!mb) continue;
+                    int bb = 0;
+                    if (wv::leader()) bb = atomicAdd(&a.ctl->wj_bucket_n[round][b], __builtin_popcountll(mb));
+                    bb = wv::uni(bb);
+                    WAVE_FOR(l) { if (inb[l]) a.wj_bucket[(size_t)b * a.wj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                }
+            } else { WAVE_FOR(l) { if (big[l]) tbl[l] = 0; } }
         }
         tb += wv::reduce_sum(tbl);
-        for (int b = 0; b < LJ_NBUCKET; ++b) {                                  // into the queue of its kind and length class
-            wv::Lane<int> inb;
-            WAVE_FOR(l) inb[l] = ty[l] && lj_bucket_of(ty[l], ql[l], tl[l]) == b;
-            const unsigned long long mb = wv::ballot(inb);
-            if (!mb) continue;
-            int bb = 0;
-            if (wv::leader()) bb = atomicAdd(&a.ctl->lj_bucket_n[round][b], __builtin_popcountll(mb));
-            bb = wv::uni(bb);
-            WAVE_FOR(l) { if (inb[l]) a.lj_bucket[(size_t)b * a.lj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
-        }
     }
     r.flip = false;
     r.t_bases = tb;
@@ -408,10 +494,10 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
 {
     const lamsa_hp_para *P = &a.P;
     const int cnt = a.ctl->lj_bucket_n[round][bucket] - off < 64 ? a.ctl->lj_bucket_n[round][bucket] - off : 64;
-    char *slab = a.slab + (size_t)wave_slot * a.slab_per_wave;
+    char *slab = a.slab + (size_t)wave_slot * a.slab_fill;
     cig_t *cbuf = (cig_t *)slab;                                               // per lane three CIGAR buffers
     uint8_t *zbuf = (uint8_t *)(slab + sizeof(cig_t) * 3 * HP_LJ_CIG * 64);     // the lane-interleaved direction matrices
-    if (sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 > a.slab_per_wave) return;
+    if (sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 > a.slab_fill) return;
     const int32_t *bq = a.lj_bucket + (size_t)bucket * a.lj_cap + off;
     wv::Lane<int> nw, rdl, cel; wv::Lane<long long> slotl;
     wv::sync();
@@ -452,79 +538,43 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
     wv::sync();
 }
 
-// four jobs of one of the round's "big" junction queues (type 1: ksw_bi_extend(100, 100)) through hp_stripdp.h: the left extension, and
-// when it ends the call (ksw.c:875-880) the CIGAR into the job arena and its slot into FLines::jt, where the fill finds it.  A job whose
-// left extension stops inside both sequences is left alone: the fill runs its ksw_bi_extend as before.
-HP_INL void phase_filldp_strip(const PhaseArgs &a, int round, int bucket, int off, int wave_slot)
+// job `g` of the round's wave-job queues, costliest class first (hp_wavejob.h)
+HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot, HP_L int32_t *lds)
 {
+    int b = 0;
+    for (; b < WJ_NBUCKET - 1; ++b) { const int nb = a.ctl->wj_bucket_n[round][b]; if (g < nb) break; g -= nb; }
+    const WjRec R = a.wjobs[a.wj_bucket[(size_t)b * a.wj_cap + g]];
+    const int rd = wv::uni(R.rd), type = wv::uni(R.type_comp) & 15, comp = (wv::uni(R.type_comp) >> 4) & 1;
+    const int qs = (wv::uni(R.type_comp) >> 5) & 1 ? -1 : 1, ts = (wv::uni(R.type_comp) >> 6) & 1 ? -1 : 1;
+    const int qlen = wv::uni(R.qlen), tlen = wv::uni(R.tlen);
+    if (*(volatile int32_t *)&a.meta[rd].status & ST_DEAD) return;
+    Ctx cx;
+    cx.P = &a.P; cx.lds = lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
+    arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_wj, a.slab_wj);
+    CigV out;
+    if (!cig_alloc(cx, out, qlen + tlen + 64)) return;
+    WjOut o;
     const lamsa_hp_para *P = &a.P;
-    const int left = a.ctl->lj_bucket_n[round][bucket] - off;
-    const int cnt = left < 4 ? left : 4;
-    char *slab = a.slab + (size_t)wave_slot * a.slab_per_wave;
-    if ((size_t)HP_ST_SLAB_BYTES > a.slab_per_wave || cnt <= 0) return;
-    uint32_t *zbuf = (uint32_t *)slab;
-    cig_t *cbuf = (cig_t *)(slab + (size_t)4 * HP_ST_ZROWS * 16 * 4);
-    const int32_t *bq = a.lj_bucket + (size_t)bucket * a.lj_cap + off;
-    StripJob J; wv::Lane<int> rdl; wv::Lane<long long> slotl;
-    wv::sync();
-    WAVE_FOR(l) {
-        const int g = l >> 4;
-        J.on[l] = g < cnt; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0; rdl[l] = -1; slotl[l] = 0;
-        if (g < cnt) {
-            const LjRec R = a.ljobs[bq[g]];
-            const int comp = (R.type_comp >> 4) & 1;
-            J.q[l] = (long long)(a.in.read_seq + R.qaddr); J.qs[l] = comp ? -1 : 1; J.qcomp[l] = comp; J.qlen[l] = R.qlen; J.tlen[l] = R.tlen; J.tk[l] = R.tk;
-            rdl[l] = R.rd; slotl[l] = R.slot;
-            if (R.qlen > HP_ST_QMAX || R.tlen > HP_ST_TMAX || (R.type_comp & 15) != 1) J.on[l] = 0;      // never listed; a guard for the buffers
-        }
-    }
-    StripRes O;
-    strip_extend(P, (const HP_G uint8_t *)a.ref.pac, J, 100, zbuf, cbuf, O);
-    // ksw_bi_extend after the left extension, :874-880
-    wv::Lane<int> nw;
-    WAVE_FOR(l) {
-        int n = 0;
-        if (J.on[l]) {
-            const int ql = J.qlen[l], tl = J.tlen[l], res = O.qle[l] == ql ? 0 : (O.tle[l] == tl ? 1 : 2);
-            if (res < 2) {
-                HP_G cig_t *c = (HP_G cig_t *)cbuf + (size_t)(l >> 4) * HP_ST_CIG;
-                n = O.n_cig[l];
-                const cig_t tail = res == 0 ? (cig_t)(((tl - O.tle[l]) << 4) | C_D) : (cig_t)(((ql - O.qle[l]) << 4) | C_I);
-                if ((tail >> 4) != 0) {                                                  // _push_cigar1
-                    if (n > 0 && (c[n - 1] & 0xf) == (tail & 0xf)) { if ((l & 15) == 0) c[n - 1] += (tail >> 4) << 4; }
-                    else { c[n] = tail; ++n; }
-                }
-                HP_STAT(9);
-            }
-        }
-        nw[l] = n;
-    }
-    wv::sync();
-    // publish: one reservation in the job arena per wave
-    wv::Lane<int> nw0, pre;
-    WAVE_FOR(l) nw0[l] = (l & 15) == 0 ? nw[l] : 0;
-    pre = nw0;
-    wv::scan_add_excl(pre);
-    const int total = wv::reduce_sum(nw0);
-    WAVE_FOR(l) { if ((l & 15) != 0) pre[l] = -1; }
-    wv::row16_allmax(pre);
+    const bool ok = wj_run(cx, a.in.read_seq, a.ref.pac, type, comp, wv::uni64(R.qaddr), qs, qlen, wv::uni64(R.tk), ts, tlen,
+                           P->band_w, type == WJ_BI ? 100 : P->seed_len * P->match, out, o);
+    if (cx.n_cells > 0 && wv::leader()) atomicAdd(&a.meta[rd].cells, (int)(cx.n_cells > 0x3fffffffLL ? 0x3fffffffLL : cx.n_cells));
+    if (!ok) return;                                                           // left to the fill, which runs the job itself and flags what there is to flag
     unsigned long long base = 0;
-    if (total > 0) {
-        if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)total);
-        base = (unsigned long long)wv::uni64((long long)base);
-    }
-    const bool room = (int64_t)(base + (unsigned long long)total) <= a.job_cap;       // arena full: these stay with the fill
-    WAVE_FOR(l) {
-        if (J.on[l]) {
-            if (nw[l] > 0 && room) {
-                const HP_G cig_t *src = (const HP_G cig_t *)cbuf + (size_t)(l >> 4) * HP_ST_CIG;
-                HP_G int32_t *dst = (HP_G int32_t *)(a.job_base + base + pre[l]);
-                for (int k = l & 15; k < nw[l]; k += 16) dst[k] = src[k];
-                if ((l & 15) == 0) { int32_t *slot = a.fl_base + slotl[l]; slot[0] = (int32_t)(base + pre[l]); slot[1] = nw[l]; slot[2] = J.tlen[l]; slot[3] = 1; }
-            }
-            if ((l & 15) == 0 && O.cells[l] > 0) atomicAdd(&a.meta[rdl[l]].cells, O.cells[l]);
+    if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)out.n);
+    base = (unsigned long long)wv::uni64((long long)base);
+    if ((int64_t)(base + (unsigned long long)out.n) > a.job_cap) return;       // arena full: stays with the fill
+    {
+        HP_G int32_t *dst = (HP_G int32_t *)(a.job_base + base);
+        const HP_G cig_t *src = (const HP_G cig_t *)out.c;
+        for (int b0 = 0; b0 < out.n; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < out.n) dst[i] = src[i]; } }
+        HP_G int32_t *slot = (HP_G int32_t *)(a.fl_base + wv::uni64(R.slot));
+        WAVE_FOR(l) {
+            if (type == WJ_BI || type == WJ_GLOBAL) { if (l < 4) slot[l] = l == 0 ? (int32_t)base : (l == 1 ? out.n : (l == 2 ? tlen : 1)); }
+            else if (l < 8) slot[l] = l == 0 ? (int32_t)base : (l == 1 ? out.n : (l == 2 ? o.reflen : (l == 3 ? o.readlen : (l == 4 ? 1 : 0))));
         }
     }
+    if (wv::leader()) atomicAdd(&a.ctl->wj_bytes, (unsigned long long)(qlen + (tlen + 3) / 4 + 4 * out.n + 32));
+    HP_STAT(9);
     wv::sync();
 }
 
@@ -614,6 +664,8 @@ HP_INL void publish_diag(const PhaseArgs &a)
         for (int k = 0; k < 4; ++k) { a.out.diag[2 * k] = ~a.ctl->t_first_inv[k]; a.out.diag[2 * k + 1] = a.ctl->t_last[k]; }
         a.out.diag[8] = (unsigned long long)a.ctl->n_units[0]; a.out.diag[9] = (unsigned long long)a.ctl->n_units[1];
         a.out.diag[10] = a.ctl->fl_cursor; a.out.diag[11] = a.ctl->line_cursor;
+        a.out.diag[12] = (unsigned long long)(a.ctl->wj_n[0] + a.ctl->wj_n[1]); a.out.diag[13] = a.ctl->wj_bytes; a.out.diag[14] = (unsigned long long)(a.ctl->lj_n[0] + a.ctl->lj_n[1]);
+        a.out.diag[15] = a.ctl->job_cursor;
     }
 }
 

@@ -10,8 +10,7 @@ int g_emu_gaptab_cap = 1 << 30;        // tests: reads with more seed slots than
 #define HP_GAPTAB_CAP_RT(cap) (g_emu_gaptab_cap < (cap) ? g_emu_gaptab_cap : (cap))
 int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than this take the wave-wide routine (hp_gaps.h)
 #define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
-int g_emu_strip = 0;                   // tests: 1 = junction jobs of 65 .. 127 query bases go to the four-jobs-per-wave routine (hp_stripdp.h; off in the product)
-#define HP_STRIP_RT g_emu_strip
+int g_emu_wave_jobs = 1;               // tests: 0 = no wave-per-job launch (hp_wavejob.h): the fill runs the junctions beyond a lane job and the end extensions itself
 int g_emu_pk = 1;                      // tests: 0 = extensions of 63 .. 254 query bases take the int32 register sets instead of the packed int16 routine (hp_ksw.h)
 #define HP_PK_RT g_emu_pk
 #include <vector>
@@ -96,7 +95,7 @@ extern "C" void emu_set_lane_dp(int on) { g_emu_lane_dp = on; }           // 0: 
 extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab_cap > 0 ? tab_cap : (tab_cap < 0 ? 0 : 1 << 30); g_emu_gap_mcap = mcap > 0 ? mcap : (mcap < 0 ? 0 : 1 << 30); }
-extern "C" void emu_set_strip(int on) { g_emu_strip = on; }
+extern "C" void emu_set_wave_jobs(int on) { g_emu_wave_jobs = on; }
 extern "C" void emu_set_pk(int on) { g_emu_pk = on; }
 extern "C" long long emu_stat(int i) { return g_emu_stat[i & 31]; }
 extern "C" void emu_dplog_on(int on) { g_emu_dplog_on = on; g_emu_dplog.clear(); }
@@ -127,7 +126,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     if (scale == 1 && g_emu_phased) {
         // the product's main pass: chain1 -> fill -> chain2 -> fill -> publish, every phase over the whole batch before the next starts
         PhaseArgs p;
-        p.P = a.P; p.ref = a.ref; p.in = a.in; p.out = a.out; p.slab = slab.data(); p.slab_per_wave = slab_bytes;
+        p.P = a.P; p.ref = a.ref; p.in = a.in; p.out = a.out; p.slab = slab.data(); p.slab_per_wave = slab_bytes; p.slab_fill = slab_bytes; p.slab_wj = slab_bytes;
         p.sort_pb = a.sort_pb; p.sort_cb = a.sort_cb; p.order = nullptr; p.n_reads = B->n_reads; p.prof = nullptr;
         const int n = B->n_reads;
         const int64_t n_hits = n ? B->hit_off[B->seed_off[n]] : 0, n_bases = n ? B->read_off[n] : 0;
@@ -137,25 +136,30 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
         std::vector<UnitRec> units(2 * (size_t)p.unit_cap); std::vector<int32_t> bq(2 * (size_t)PH_NBUCKET * p.unit_cap);
         p.fl_cap = 16 * (n_hits + n) + 1024 * (int64_t)n + 1024; p.line_cap = stream_cap + 16 * 2 * (int64_t)p.unit_cap;
         p.fl_cap = 32 * (n_hits + n) + 4096 * (int64_t)n + 4096;
-        p.job_cap = g_emu_lane_dp ? 4096 + 1024 * (int64_t)n + 8 * n_bases : 0;
+        p.job_cap = (g_emu_lane_dp || g_emu_wave_jobs) ? 4096 + 1024 * (int64_t)n + 8 * n_bases : 0;
         std::vector<int32_t> fl((size_t)p.fl_cap), lines((size_t)p.line_cap), jobsv((size_t)p.job_cap + 4);
         p.job_base = jobsv.data();
         p.lj_cap = g_emu_lane_dp ? (int)(1024 + 64 * (int64_t)n + n_bases / 8) : 0;
         std::vector<LjRec> ljv((size_t)p.lj_cap + 1); std::vector<int32_t> ljq((size_t)LJ_NBUCKET * p.lj_cap + 1);
         p.ljobs = ljv.data(); p.lj_bucket = ljq.data();
+        p.wj_cap = g_emu_wave_jobs ? (int)(1024 + 64 * (int64_t)n + n_bases / 8) : 0;
+        std::vector<WjRec> wjv((size_t)p.wj_cap + 1); std::vector<int32_t> wjq((size_t)WJ_NBUCKET * p.wj_cap + 1);
+        p.wjobs = wjv.data(); p.wj_bucket = wjq.data();
         static thread_local int32_t lds_lj[HP_LJ_LDS_WORDS(HP_LJ_QCAP)];
+        static thread_local int32_t lds_wj[HP_WJ_LDS_WORDS];
         PhaseCtl ctl; memset(&ctl, 0, sizeof ctl);
         p.g_nd = nd.data(); p.g_nseed = nseed.data(); p.g_sidx = sidx.data(); p.meta = meta.data(); p.units = units.data(); p.bucket_q = bq.data();
         p.fl_base = fl.data(); p.line_base = lines.data(); p.ctl = &ctl;
         (void)n_bases;
         auto fill_all = [&](int round) {
-            if (g_emu_lane_dp) {
+            if (g_emu_lane_dp || g_emu_wave_jobs) {
                 for (int b = 0; b < PH_NBUCKET; ++b)
                     for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filllist(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
-                for (int b = 0; b < LJ_NBUCKET; ++b) {
-                    if (b < LJ_NCLS_BIG && HP_LJ_QLIST <= HP_LJ_QSMALL) { for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 4) phase_filldp_strip(p, round, b, off, 0); continue; }
-                    for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 64) phase_filldp(p, round, b, off, 0, lds_lj, b < LJ_NBIG ? HP_LJ_QCAP : HP_LJ_QSMALL);
-                }
+                int nw = 0;
+                for (int b = 0; b < WJ_NBUCKET; ++b) nw += ctl.wj_bucket_n[round][b];
+                for (int g = 0; g < nw; ++g) phase_wavejob(p, round, g, 0, lds_wj);
+                for (int b = 0; b < LJ_NBUCKET; ++b)
+                    for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 64) phase_filldp(p, round, b, off, 0, lds_lj, HP_LJ_QSMALL);
             }
             for (int b = 0; b < PH_NBUCKET; ++b)
                 for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
@@ -189,31 +193,26 @@ extern "C" int emu_split_indel_map(const lamsa_hp_para *P, const uint8_t *read, 
     return out.n;
 }
 
-// ---------------------------------------------------------------- the four-jobs-per-wave extension (hp_stripdp.h) on explicit jobs:
-// ksw_extend_core(w = max(|qlen - tlen| + 3, band_w), h0) with traceback; targets packed 2 bits per base as the kernel reads them
-extern "C" int emu_strip_extend(const lamsa_hp_para *P, int n, const uint8_t *seq, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,
-                                int h0, int32_t *score, int32_t *qle, int32_t *tle, int32_t *cig_n, int32_t *cig /* n * HP_ST_CIG words */)
+// ---------------------------------------------------------------- a job as the wave-per-job launch runs it (hp_wavejob.h: wj_run with that
+// launch's LDS, sequences staged from the read bytes and the packed reference): type 1 = a junction's ksw_bi_extend(h0, h0), 2 = ksw_global2(w),
+// 3 / 4 = a line's head / tail extension (both sequences walked backwards for the head; the rest of the query clipped, the head's CIGAR turned round)
+extern "C" int emu_wave_job(const lamsa_hp_para *P, int n, const uint8_t *seq, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off, const int32_t *tlen,
+                            int type, int w, int h0, size_t slab_bytes, int32_t *score, int32_t *qle, int32_t *tle, int32_t *status, int32_t *cig_n, int32_t *cig, const int64_t *cig_off)
 {
     int64_t tot = 0;
     for (int i = 0; i < n; ++i) tot += tlen[i];
     std::vector<uint8_t> pac((size_t)tot / 4 + 8, 0); std::vector<int64_t> tk((size_t)n + 1, 0);
-    { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } }
-    std::vector<char> slab(HP_ST_SLAB_BYTES + 64);
-    if (!st_params_ok(P, h0)) return -2;
-    for (int j0 = 0; j0 < n; j0 += 4) {
-        StripJob J;
-        for (int l = 0; l < 64; ++l) {
-            const int i = j0 + (l >> 4);
-            J.on[l] = i < n; J.q[l] = 0; J.qs[l] = 1; J.qcomp[l] = 0; J.qlen[l] = 0; J.tlen[l] = 0; J.tk[l] = 0;
-            if (i < n) { if (qlen[i] > HP_ST_QMAX || tlen[i] > HP_ST_TMAX) return -1; J.q[l] = (long long)(seq + q_off[i]); J.qlen[l] = qlen[i]; J.tlen[l] = tlen[i]; J.tk[l] = tk[i]; }
-        }
-        StripRes O;
-        strip_extend(P, pac.data(), J, h0, (uint32_t *)slab.data(), (cig_t *)(slab.data() + (size_t)4 * HP_ST_ZROWS * 16 * 4), O);
-        for (int g = 0; g < 4 && j0 + g < n; ++g) {
-            const int i = j0 + g, l = 16 * g;
-            score[i] = O.score[l]; qle[i] = O.qle[l]; tle[i] = O.tle[l]; cig_n[i] = O.n_cig[l];
-            memcpy(cig + (size_t)i * HP_ST_CIG, (cig_t *)(slab.data() + (size_t)4 * HP_ST_ZROWS * 16 * 4) + (size_t)g * HP_ST_CIG, sizeof(cig_t) * (size_t)O.n_cig[l]);
-        }
+    { int64_t k = 0; for (int i = 0; i < n; ++i) { tk[i] = k; for (int j = 0; j < tlen[i]; ++j, ++k) { if (seq[t_off[i] + j] > 3) return -1; pac[k >> 2] |= (uint8_t)((seq[t_off[i] + j] & 3) << ((~k & 3) << 1)); } } }
+    std::vector<char> slab(slab_bytes);
+    static thread_local int32_t lds_wj[HP_WJ_LDS_WORDS];
+    for (int i = 0; i < n; ++i) {
+        Ctx cx; cx.P = P; cx.lds = lds_wj; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr;
+        arena_init(cx.tmp, slab.data(), slab.size());
+        const bool back = type == WJ_HEAD;
+        CigV out; cig_bind(out, cig + cig_off[i], (int)(cig_off[i + 1] - cig_off[i]));
+        WjOut o;
+        wj_run(cx, seq, pac.data(), type, 0, q_off[i] + (back && qlen[i] > 0 ? qlen[i] - 1 : 0), back ? -1 : 1, qlen[i], tk[i] + (back && tlen[i] > 0 ? tlen[i] - 1 : 0), back ? -1 : 1, tlen[i], w, h0, out, o);
+        score[i] = o.score; qle[i] = o.qle; tle[i] = o.tle; status[i] = cx.status; cig_n[i] = out.n;
     }
     return 0;
 }

@@ -226,7 +226,7 @@ def emu_capi_lib():
 def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20, pk=True, stats=None):
     """Run DP jobs through the emulated device code (same kernel sources, CPU lanes).  pk=False: extensions of 63 .. 254 query bases take the
     int32 register sets instead of the packed int16 routine; stats: a list that receives [extensions through the packed routine, through the int32 sets, global alignments of more than 62
-    query bases through the packed routine, through the LDS rows]."""
+    query bases through the packed routine, through the LDS rows, extensions of more than 254 query bases through the window-in-registers routine]."""
     import sys
     sys.path.insert(0, ROOT)
     from lamsa_amd.hp import pack_jobs
@@ -247,7 +247,7 @@ def emu_dp(jobs, hp_para, kind, w, h0, slab_bytes=64 << 20, pk=True, stats=None)
                    p(score), p(qle), p(tle), p(st), p(cn), p(cap), p(cig), slab_bytes)
     E.emu_set_pk(1)
     if stats is not None:
-        stats[:] = [int(E.emu_stat(16)), int(E.emu_stat(17)), int(E.emu_stat(18)), int(E.emu_stat(19))]
+        stats[:] = [int(E.emu_stat(16)), int(E.emu_stat(17)), int(E.emu_stat(18)), int(E.emu_stat(19)), int(E.emu_stat(22))]
     cigars = [cig[cap[i]:cap[i] + cn[i]].tolist() for i in range(n)]
     return dict(score=score, qle=qle, tle=tle, status=st, cigars=cigars)
 
@@ -406,31 +406,56 @@ def split_indel_map_three_ways(read, refw, ref_offset, lp, rp, hp_para, ref_star
     return o, r, e
 
 
-def emu_strip_extend(jobs, hp_para, h0):
-    """ksw_extend_core(max(|qlen - tlen| + 3, band_w), h0) through the four-jobs-per-wave routine of hp_stripdp.h, CPU lane emulation."""
+def emu_wave_job(jobs, hp_para, wtype, w, h0, slab_bytes=64 << 20):
+    """Jobs as the wave-per-job launch of the read path runs them (lamsa_amd/csrc/hp_wavejob.h, CPU lane emulation): wtype 1 = a junction's
+    ksw_bi_extend(h0, h0), 2 = ksw_global2(w), 3 / 4 = a line's head / tail extension (ksw_extend_r / ksw_extend_c with (w, h0), the rest of the
+    query soft-clipped, the head's CIGAR turned round)."""
     from lamsa_amd.hp import pack_jobs
     E = emu()
     n = len(jobs)
     seq, q_off, qlen, t_off, tlen = pack_jobs(jobs)
-    CIG = 127 + 255 + 8
-    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32); cn = np.zeros(n, np.int32); cig = np.zeros(n * CIG + 4, np.int32)
+    cig_off = np.zeros(n + 1, np.int64)
+    cig_off[1:] = np.cumsum(qlen.astype(np.int64) + tlen + 72)
+    score = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32); st = np.zeros(n, np.int32); cn = np.zeros(n, np.int32)
+    cig = np.zeros(int(cig_off[-1]) + 4, np.int32)
     p = lambda a: a.ctypes.data
-    E.emu_strip_extend.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 5
-    rc = E.emu_strip_extend(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), int(h0), p(score), p(qle), p(tle), p(cn), p(cig))
+    E.emu_wave_job.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_size_t] + [C.c_void_p] * 7
+    rc = E.emu_wave_job(C.byref(hp_para), n, p(seq), p(q_off), p(qlen), p(t_off), p(tlen), int(wtype), int(w), int(h0), slab_bytes, p(score), p(qle), p(tle), p(st), p(cn), p(cig), p(cig_off))
     assert rc == 0, rc
-    return dict(score=score, qle=qle, tle=tle, cigars=[cig[i * CIG:i * CIG + cn[i]].tolist() for i in range(n)])
+    return dict(score=score, qle=qle, tle=tle, status=st, cigars=[cig[cig_off[i]:cig_off[i] + cn[i]].tolist() for i in range(n)])
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None, strip=False):
+def end_extension_from_oracle(jobs, lp, head, w, h0):
+    """What frag_head_bound_fix / frag_tail_bound_fix make of an extension (src/frag_check.c:640-648, :699-703), from the oracle's
+    ksw_extend_core: the head runs on both sequences reversed; unless the query was consumed the rest of it is soft-clipped; the head's
+    CIGAR is turned round."""
+    js = [(q[::-1].copy(), t[::-1].copy()) for q, t in jobs] if head else jobs
+    want = oracle_dp(js, lp, 1, w, h0)
+    cigs = []
+    for k, (q, t) in enumerate(js):
+        c = list(want["cigars"][k])
+        if want["qle"][k] != len(q):
+            rest = (len(q) - int(want["qle"][k])) << 4 | 4
+            if rest >> 4:
+                if c and (c[-1] & 0xf) == 4:
+                    c[-1] += (rest >> 4) << 4
+                else:
+                    c.append(rest)
+        cigs.append(c[::-1] if head else c)
+    return dict(score=want["score"], qle=want["qle"], tle=want["tle"], cigars=cigs)
+
+
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None, wave_jobs=True):
     """Per-read result streams from the device sources compiled with the CPU lane emulation.
     phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
     cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h).
     gaptab_cap / gap_mcap: reads with more seed slots scan the gaps of a line by seed range instead of by cluster / gaps with more
-    survivors take the wave-wide mini DP (hp_gaps.h); < 0 = none qualifies.  stats: a list that receives the HP_STAT path counters."""
+    survivors take the wave-wide mini DP (hp_gaps.h); < 0 = none qualifies.  wave_jobs: False = no wave-per-job launch (hp_wavejob.h), the fill
+    runs the junctions beyond a lane job and the end extensions itself.  stats: a list that receives the HP_STAT path counters."""
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
     E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap)); E.emu_set_lane_dp(1 if lane_dp else 0)
-    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_set_strip(1 if strip else 0); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
+    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_set_wave_jobs(1 if wave_jobs else 0); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
     n = batch.n_reads
     hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
@@ -440,8 +465,8 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     E.emu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     E.emu_align_batch(C.byref(hp_para), C.byref(hr), C.byref(hb), scale, slab_bytes, stream.ctypes.data, cap, C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
     if stats is not None:
-        stats[:] = [int(E.emu_stat(i)) for i in range(16)]
-    E.emu_set_gap_caps(0, 0); E.emu_set_strip(0)
+        stats[:] = [int(E.emu_stat(i)) for i in range(32)]
+    E.emu_set_gap_caps(0, 0); E.emu_set_wave_jobs(1)
     return split_streams(stream, off[:n], ln[:n]), st[:n].copy()
 
 

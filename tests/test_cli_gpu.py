@@ -151,3 +151,22 @@ def test_sam_identical_to_the_reference_binary_at_bench_shapes(workload, n_reads
     assert want.returncode == 0, want.stderr[-2000:]
     res = bench.compare_with_product(d, args, 16, n_reads)
     assert res == "%d/%d reads" % (n_reads, n_reads), res
+
+
+GLUED = os.path.join(ROOT, "oracle", "_ref", "lamsa_glued")
+
+
+@pytest.mark.parametrize("name", ("c3_ont", "c5_sv", "c6_edge", "c7_rescue", "c9_rearr"))
+def test_reference_with_the_binding_on_the_gpu(name, tmp_path):
+    """The drop-in boundary on hardware: the REFERENCE's own `lamsa aln` (its file IO, GEM parsing, stage (4), ranking, SAM writer) with the
+    binding of INTEGRATION.md compiled in (oracle/Makefile `glued`: lamsa_amd/glue/lamsa_hp_glue.c + tools/apply_glue.py, linked against
+    liblamsa_hp.so), stages (2),(3),(2'),(3') on the MI355X through include/lamsa_hp.h: the SAM the reference writes without it (default run:
+    stage (4) on).  The binary is built in the build container and travels like oracle/_ref/lamsa."""
+    if not os.path.exists(GLUED):
+        pytest.skip("oracle/_ref/lamsa_glued was not built (needs the reference's sources: build container only)")
+    ref, reads, args, gold_r0 = G.stage_scenario(name, str(tmp_path))
+    gold = G.golden_full(name) if name in G.RESCUE_SCENARIOS else gold_r0
+    out = str(tmp_path / "out.sam")
+    p = subprocess.run([GLUED, "aln"] + args + ["-t", "3", "-N", ref, reads, "-o", out], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert G.strip_pg(open(out).read()) == G.strip_pg(gold)

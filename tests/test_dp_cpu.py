@@ -193,26 +193,35 @@ def test_lane_per_job_dp_matches_oracle(preset):
 
 
 @pytest.mark.parametrize("preset", ["default", "pacbio", "ont2d"])
-def test_four_jobs_per_wave_extension_matches_oracle(preset):
-    """hp_stripdp.h (a junction's left extension on a quarter of a wave, eight columns per lane in registers) against the oracle's
-    ksw_extend_core with the band ksw_bi_extend gives it, on ragged jobs up to the routine's capacity (127 x 255)."""
+def test_wave_jobs_match_oracle(preset):
+    """hp_wavejob.h (the jobs of the wave-per-job launch: a junction's ksw_bi_extend, a seed gap's ksw_global2, a line's head and tail
+    extension with their soft clip; sequences staged from the read bytes and the packed reference, the direction matrix in that launch's LDS
+    where it fits) against the oracle, on ragged jobs around the lengths where the routines and the matrix's place change (62 / 63, 126 / 127,
+    254 / 255 query bases; ~75 and ~150 rows of 64 and 128 bytes in 9.5 KB)."""
     from lamsa_amd.hp import HpPara
     lp = reflib.lo_para(preset)
     P = HpPara()
     for n, _ in HpPara._fields_:
         setattr(P, n, getattr(lp, n))
-    jobs = [(q, t) for q, t in dpjobs.make_jobs(777, 700, 130, (0.05, 0.05, 0.05)) if len(q) <= 127 and len(t) <= 255 and (len(t) == 0 or t.max() < 4)]
-    assert len(jobs) > 400
+    jobs = [(q, t) for q, t in dpjobs.make_jobs(778, 500, 300, (0.05, 0.05, 0.05)) if len(t) == 0 or t.max() < 4]
+    jobs += [(q, t) for q, t in dpjobs.make_jobs(779, 160, 300, (0.04, 0.04, 0.04), tail_noise=True) if len(t) == 0 or t.max() < 4]
+    for ql in (60, 61, 62, 63, 64, 74, 75, 76, 100, 125, 126, 127, 128, 150, 151, 200, 253, 254, 255, 256, 300):
+        jobs += [(q[:ql], t[:ql + d]) for (q, t), d in zip(dpjobs.make_jobs(1000 + ql, 6, 400, (0.05, 0.05, 0.05)), (-9, -3, 0, 2, 7, 12)) if len(q) >= ql and t.max() < 4]
+    assert len(jobs) > 600
     for h0 in (100, 10):
-        got = reflib.emu_strip_extend(jobs, P, h0)
-        # the oracle one job at a time: every job has its own band, max(|qlen - tlen| + 3, band_w) (src/ksw.c:873)
-        by_w = {}
-        for i, (q, t) in enumerate(jobs):
-            by_w.setdefault(max(abs(len(q) - len(t)) + 3, lp.band_w), []).append(i)
-        for w, idx in by_w.items():
-            want = reflib.oracle_dp([jobs[i] for i in idx], lp, 1, w, h0)
-            for k, i in enumerate(idx):
-                assert (want["score"][k], want["qle"][k], want["tle"][k], list(want["cigars"][k])) == (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i])), (preset, h0, i)
+        want = reflib.oracle_dp(jobs, lp, 2, 0, h0)
+        got = reflib.emu_wave_job(jobs, P, 1, 0, h0)
+        assert goldenlib.same_dp(want, got, 2) == [], (preset, h0)
+    for w in (lp.band_w, 7):
+        want = reflib.oracle_dp(jobs, lp, 0, w, 0)
+        got = reflib.emu_wave_job(jobs, P, 2, w, 0)
+        assert goldenlib.same_dp(want, got, 0) == [], (preset, w)
+    for head in (True, False):
+        for w, h0 in ((lp.band_w, 50), (12, 8)):
+            want = reflib.end_extension_from_oracle(jobs, lp, head, w, h0)
+            got = reflib.emu_wave_job(jobs, P, 3 if head else 4, w, h0)
+            bad = [i for i in range(len(jobs)) if (want["score"][i], want["qle"][i], want["tle"][i], list(want["cigars"][i])) != (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i]))]
+            assert bad == [] and (got["status"] == 0).all(), (preset, head, w, h0, bad[:5])
 
 
 def test_no_caller_local_is_handed_by_address_to_a_non_inlined_device_routine(tmp_path):
@@ -299,3 +308,56 @@ def test_kmer_split_mapper_three_ways(preset):
             assert r == o, ("oracle vs reference", n, len(read), ref_len, off)
         n += 1
     assert n > 300 and E.emu_stat(13) > 0
+
+
+def _hp_para_of(lp):
+    from lamsa_amd.hp import HpPara
+    P = HpPara()
+    for n, _ in HpPara._fields_:
+        setattr(P, n, getattr(lp, n))
+    return P
+
+
+def _long_jobs(seed, n, lo, hi, err, noise):
+    """Long extension jobs: a query of lo .. hi bases against its (mutated) target, some with an unrelated stretch of 0 .. `noise` bases in the
+    middle or at the end (z-drop, local end), some shorter or longer than the target."""
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for k in range(n):
+        tl = int(rng.integers(lo, hi + 1))
+        t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+        q = dpjobs.mutate(rng, t, *err, 0.0)
+        mode = k % 5
+        if mode == 1:
+            cut = int(rng.integers(len(q) // 4, len(q)))
+            q = np.concatenate([q[:cut], rng.integers(0, 4, size=int(rng.integers(0, noise + 1)), dtype=np.uint8)])
+        elif mode == 2:
+            a = int(rng.integers(len(q) // 4, 3 * len(q) // 4))
+            q = np.concatenate([q[:a], rng.integers(0, 4, size=int(rng.integers(1, noise + 1)), dtype=np.uint8), q[a:]])
+        elif mode == 3:
+            q = q[:int(rng.integers(256, len(q) + 1))] if len(q) > 256 else q
+        elif mode == 4:
+            t = t[:int(rng.integers(len(t) // 2, len(t) + 1))]
+        jobs.append((np.ascontiguousarray(q, np.uint8), np.ascontiguousarray(t, np.uint8)))
+    return jobs
+
+
+@pytest.mark.parametrize("preset", ["default", "pacbio", "ont2d"])
+def test_long_extensions_with_the_window_in_registers(preset):
+    """ksw_extend_band (hp_ksw.h): ksw_extend_core for queries of more than 254 bases -- the end extensions of a line -- with the row's live
+    window in registers, 2 / 4 / 8 columns per lane for bands up to 53 / 108 / 218; against the oracle on jobs of 255 .. 3 000 bases with
+    every band class, with start scores that let the band shrink and grow again, z-drop inside unrelated stretches, queries and targets that
+    end first; and the routine is really the one that ran.  With the packed routines off the same jobs take the LDS rows."""
+    lp = reflib.lo_para(preset)
+    P = _hp_para_of(lp)
+    err = {"default": (0.01, 0.01, 0.01), "pacbio": (0.015, 0.09, 0.045), "ont2d": (0.04, 0.04, 0.04)}[preset]
+    jobs = _long_jobs(5, 40, 255, 700, err, 400) + _long_jobs(6, 12, 1200, 3000, err, 600)
+    for w, h0 in ((lp.band_w, 50), (30, 50), (53, 8), (54, 100), (108, 20), (109, 50), (200, 50), (218, 19), (219, 50), (7, 10)):
+        want = reflib.oracle_dp(jobs, lp, 1, w, h0)
+        stats = []
+        got = reflib.emu_dp(jobs, P, 1, w, h0, stats=stats)
+        assert goldenlib.same_dp(want, got, 1) == [], (preset, w, h0)
+        assert stats[4] > 0 or w > 218, (w, stats)          # (ksw_extend_core narrows a band that the penalties cannot fill, src/ksw.c:696-704: 219 may still run here)
+    stats = []
+    got = reflib.emu_dp(jobs, P, 1, lp.band_w, 50, pk=False, stats=stats)
+    assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 1, lp.band_w, 50), got, 1) == [] and stats[4] == 0

@@ -130,25 +130,35 @@ def test_hip_lane_per_job_routines_match_oracle(handles, rt):
 
 
 @pytest.mark.parametrize("rt", ["default", "pacbio", "ont2d"])
-def test_hip_four_jobs_per_wave_extension_matches_oracle(handles, rt):
-    """hp_stripdp.h on the MI355X (kind 7 of lamsa_hp_dp_batch): a junction's left extension on one 16-lane DPP row -- row_shr scans and
-    row all-reduces confined to the row, which the CPU emulation only models."""
+def test_hip_wave_jobs_match_oracle(handles, rt):
+    """hp_wavejob.h on the MI355X (kinds 8 .. 11 of lamsa_hp_dp_batch: jobs as the wave-per-job launch of the read path runs them -- k_filldp_wave's
+    128 registers and 9.5 KB of LDS, sequences staged from the read bytes and the packed reference, the direction matrix of the packed routines in
+    LDS where it fits, which the CPU emulation only models): a junction's ksw_bi_extend, a seed gap's ksw_global2, a line's head and tail
+    extension with their soft clip, at every length around the limits of the routines (62 / 63, 126 / 127, 254 / 255 query bases) and of the
+    LDS matrix (~150 rows of 64 bytes, ~75 of 128), and whole-read extensions beyond them.  Against the oracle, bit for bit."""
     lp = reflib.lo_para(rt)
-    jobs = _lane_jobs(300 + len(rt), ERR[rt], 127, 255)
+    jobs = [(q, t) for q, t in dpjobs.make_jobs(880 + len(rt), 900, 320, ERR[rt]) if len(t) == 0 or t.max() < 4]
+    for ql in (60, 61, 62, 63, 64, 74, 75, 76, 100, 125, 126, 127, 128, 150, 151, 152, 200, 253, 254, 255, 256, 300):
+        jobs += [(q[:ql], t[:ql + d]) for (q, t), d in zip(dpjobs.make_jobs(2000 + ql, 8, 420, ERR[rt]), (-9, -3, 0, 2, 7, 12, 20, 33)) if len(q) >= ql and t.max() < 4]
+    jobs += [(q, t) for q, t in dpjobs.make_jobs(41, 6, 6000, ERR[rt]) if len(q) > 1500 and t.max() < 4]
+    assert len(jobs) > 900
     for h0 in (100, 10):
-        got = handles[rt].dp_batch(jobs, 7, 0, h0)
-        by_w = {}
-        for i, (q, t) in enumerate(jobs):
-            by_w.setdefault(max(abs(len(q) - len(t)) + 3, lp.band_w), []).append(i)
-        for w, idx in by_w.items():
-            want = reflib.oracle_dp([jobs[i] for i in idx], lp, 1, w, h0)
-            for k, i in enumerate(idx):
-                assert (want["score"][k], want["qle"][k], want["tle"][k], list(want["cigars"][k])) == (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i])), (rt, h0, i)
+        got = handles[rt].dp_batch(jobs, 8, 0, h0)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 2, 0, h0), got, 2) == [], (rt, h0)
+    for w in (lp.band_w, 7):
+        got = handles[rt].dp_batch(jobs, 9, w, 0)
+        assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 0, w, 0), got, 0) == [], (rt, w)
+    for head in (True, False):
+        for w, h0 in ((lp.band_w, 50), (12, 8)):
+            want = reflib.end_extension_from_oracle(jobs, lp, head, w, h0)
+            got = handles[rt].dp_batch(jobs, 10 if head else 11, w, h0)
+            bad = [i for i in range(len(jobs)) if (want["score"][i], want["qle"][i], want["tle"][i], list(want["cigars"][i])) != (got["score"][i], got["qle"][i], got["tle"][i], list(got["cigars"][i]))]
+            assert bad == [] and (got["status"] == 0).all(), (rt, head, w, h0, bad[:5])
 
 
 def test_hip_lane_kinds_fall_back_when_sixteen_bit_cells_are_not_exact():
     """Penalties beyond lj_params_ok (a gap extension of 60 makes 16-bit cells unsafe): the read path keeps such a handle's small jobs on
-    the wave routines, and so do kinds 4-7 -- same results as the oracle with those penalties."""
+    the wave routines, and so do kinds 4-6 -- same results as the oracle with those penalties."""
     from lamsa_amd import hp
     over = dict(ins_gape=60, del_gape=60, ins_ext_e=60, del_ext_e=60)
     lp = reflib.lo_para("ont2d", **over)

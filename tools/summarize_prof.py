@@ -14,7 +14,7 @@ import os
 import shutil
 import sys
 
-KERNELS = ("k_chain1", "k_filllist", "k_filldp_small", "k_filldp_big", "k_fill", "k_chain2", "k_publish", "k_align_batch", "k_dp_batch")
+KERNELS = ("k_chain1", "k_filllist", "k_filldp_small", "k_filldp_wave", "k_fill", "k_chain2", "k_publish", "k_align_batch", "k_dp_batch")
 
 
 def kname(s):
@@ -38,7 +38,7 @@ def main():
     # The fill launches run twice per step (round 1, round 2) and round 2 is nearly empty on the bench data: an average over both says
     # little about either.  The dispatches of such a kernel are told apart by their order (round 1 first): `round1` holds the same figures
     # for the first of every pair.
-    TWICE = ("k_fill", "k_filllist", "k_filldp_small", "k_filldp_big")
+    TWICE = ("k_fill", "k_filllist", "k_filldp_small", "k_filldp_wave")
     for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_trace.csv"), recursive=True):
         by = {}
         for row in csv.DictReader(open(f)):
@@ -98,7 +98,7 @@ def main():
         doc["algorithmic_bytes_per_step"] = bench["roofline"].get("algorithmic_bytes_per_step", bench["roofline"].get("algorithmic_bytes_per_launch"))
         doc["launch_ms_bench_hip_events"] = bench.get("launch_ms")
     # one step of the main pass = chain1, [filllist, filldp, fill] (round 1), chain2, [filllist, filldp, fill] (round 2), publish: traffic of a step
-    main = [k for k in ("k_chain1", "k_filllist", "k_filldp_small", "k_filldp_big", "k_fill", "k_chain2", "k_publish") if k in kern and "hbm_bytes_per_dispatch_upper" in kern[k]]
+    main = [k for k in ("k_chain1", "k_filllist", "k_filldp_small", "k_filldp_wave", "k_fill", "k_chain2", "k_publish") if k in kern and "hbm_bytes_per_dispatch_upper" in kern[k]]
     steps = kern.get("k_chain1", {}).get("calls") or 1
     for k in main:
         mult = kern[k]["calls"] / steps                      # dispatches of this kernel per step
