@@ -554,9 +554,11 @@ static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_filldp_wave, 64, 0) != hipSuccess || pw < 1) pw = 4;
     // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU cap the persistent grids below what fits a CU, so that the launches of two
     // batches in flight can share the CUs instead of the later one waiting for the earlier one's waves to exit
-    { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0;
+    { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0,
+                       cw = getenv("LAMSA_HP_WJ_PER_CU") ? atoi(getenv("LAMSA_HP_WJ_PER_CU")) : 0;
       if (cf > 0 && cf < pf) pf = cf;
-      if (cc > 0 && cc < pc) pc = cc; }
+      if (cc > 0 && cc < pc) pc = cc;
+      if (cw > 0 && cw < pw) pw = cw; }
     Q.w_chain = cap_waves(h->n_cu * pc, Q.chain, h->n_cu); Q.w_fill = cap_waves(h->n_cu * pf, Q.fill, h->n_cu);
     Q.w_dp = std::min(h->n_cu * pd, Q.w_fill); Q.w_wj = cap_waves(h->n_cu * pw, Q.wj, h->n_cu);
     Q.bytes = std::max(std::max(Q.chain * (size_t)Q.w_chain, Q.fill * (size_t)Q.w_fill), Q.wj * (size_t)Q.w_wj);

@@ -30,7 +30,9 @@ HP_INL int wj_bucket_of(const lamsa_hp_para *P, int type, int qlen, int tlen)
     return WJ_NBUCKET - 1 - b;
 }
 
+#ifndef HP_WJ_LDS_WORDS
 #define HP_WJ_LDS_WORDS 2432                     // 9.5 KB: sixteen waves per CU, as the chaining kernels
+#endif
 
 struct WjOut { int score, qle, tle, reflen, readlen; };
 

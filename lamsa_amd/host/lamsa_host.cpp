@@ -942,12 +942,12 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                     // the lines of a read's seeds are consecutive and begin "<read name>_<seed>:" (split_seed, src/lamsa_aln.c:287): the first
                     // of them at or after a guess of where this part begins, then back over the lines of the same read before it.  A line of
                     // ANOTHER read whose name merely begins with "<name>_" ("r1_2_0:0" for the read "r1") is told apart by what follows the
-                    // key: digits and a colon.
+                    // key: digits, then a colon (or the end of the name).
                     const std::string key = "\n" + nm + "_";
                     auto is_seed_line = [&](const char *q) {       // q: just behind "<name>_"
                         const char *e = mapt.p + mapt.n, *d = q;
                         while (d < e && *d >= '0' && *d <= '9') ++d;
-                        return d > q && d < e && *d == ':';
+                        return d > q && d < e && (*d == ':' || *d == '\t' || *d == ' ');       // "<name>_<seed>:<offset>" as split_seed writes it; a mapper may cut the name at the colon
                     };
                     auto find_from = [&](size_t from) -> const char * {
                         while (from < mapt.n) {

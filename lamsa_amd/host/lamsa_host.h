@@ -95,7 +95,7 @@ struct Stats { long n_reads = 0, n_bases = 0, n_bad = 0; double kernel_ms = 0;
 void sam_header(std::string &o, const Index &ix, const std::string &pg);
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt);
 int run_seeding(const Options &opt, const lamsa_hp_para &P, long *pid = nullptr);   // pid: leave the mapper running and return its process id
-int run_index(const std::string &fasta, const std::string &gem_dir, bool with_gem);      // index.cpp
+int run_index(const std::string &fasta, const std::string &gem_dir, bool with_gem, bool from_pac = false);      // index.cpp
 int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::string &pg_line, Stats *stats);
 
 }  // namespace lamsa

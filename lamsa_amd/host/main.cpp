@@ -36,15 +36,16 @@ int main(int argc, char *argv[])
 {
     if (argc < 2) return usage();
     if (strcmp(argv[1], "index") == 0) {                  // lamsa index [--no-gem] [--gem-dir DIR] <ref.fa>   (src/lamsa_index.c:113)
-        std::string gem_dir, fasta; bool with_gem = true;
+        std::string gem_dir, fasta; bool with_gem = true, from_pac = false;
         for (int i = 2; i < argc; ++i) {
             if (strcmp(argv[i], "--no-gem") == 0) with_gem = false;
+            else if (strcmp(argv[i], "--from-pac") == 0) { from_pac = true; with_gem = false; }      // <ref>.pac / .ann exist: build <ref>.bwt / .sa only
             else if (strcmp(argv[i], "--gem-dir") == 0 && i + 1 < argc) gem_dir = argv[++i];
             else fasta = argv[i];
         }
-        if (fasta.empty()) { fprintf(stderr, "\nUsage:   lamsa index [--no-gem] [--gem-dir DIR] <ref.fa>\n\n"); return 1; }
+        if (fasta.empty()) { fprintf(stderr, "\nUsage:   lamsa index [--no-gem] [--gem-dir DIR] [--from-pac] <ref.fa>\n\n"); return 1; }
         if (gem_dir.empty()) { std::string self = argv[0]; const size_t sl = self.rfind('/'); gem_dir = (sl == std::string::npos ? std::string(".") : self.substr(0, sl)) + "/gem"; }
-        return lamsa::run_index(fasta, gem_dir, with_gem);
+        return lamsa::run_index(fasta, gem_dir, with_gem, from_pac);
     }
     if (strcmp(argv[1], "aln") != 0) { fprintf(stderr, "[main] unrecognized command '%s'\n", argv[1]); return 1; }
     std::string pg = std::string("@PG\tID:lamsa\tPN:lamsa\tVN:1.0.0\tCL:") + argv[0];

@@ -271,6 +271,16 @@ def test_index_files_identical_to_the_reference(cli, tmp_path):
     assert p.returncode == 0, p.stderr
     for ext in ("pac", "ann", "amb", "bwt", "sa"):
         assert open(small + "." + ext, "rb").read() == open(os.path.join(d, "expected." + ext), "rb").read(), ext
+    # the suffixes sorted in many small blocks by several threads, and from the .pac alone: the same bytes
+    many = str(tmp_path / "many.fa")
+    shutil.copy(ref, many)
+    p = subprocess.run([cli, "index", "--no-gem", many], capture_output=True, text=True, env=dict(os.environ, LAMSA_INDEX_BLOCK="3000", LAMSA_INDEX_THREADS="3"))
+    assert p.returncode == 0, p.stderr
+    os.remove(many); os.remove(many + ".bwt"); os.remove(many + ".sa")
+    p = subprocess.run([cli, "index", "--from-pac", many], capture_output=True, text=True, env=dict(os.environ, LAMSA_INDEX_BLOCK="70000", LAMSA_INDEX_THREADS="5"))
+    assert p.returncode == 0, p.stderr
+    for ext in (".bwt", ".sa"):
+        assert open(many + ext, "rb").read() == open(os.path.join(G.GOLD, "ref", "ref.fa" + ext), "rb").read(), ext
     # the index just built serves `lamsa aln` (default run, stage 4 on)
     os.makedirs(str(tmp_path / "s"))
     _, reads, args, _ = G.stage_scenario("c7_rescue", str(tmp_path / "s"))
@@ -281,6 +291,31 @@ def test_index_files_identical_to_the_reference(cli, tmp_path):
 
 
 REF_BIN = os.path.join(reflib.ROOT, "oracle", "_ref", "lamsa")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="the compiled reference (oracle/_ref/lamsa) is only built where /root/reference exists")
+def test_index_of_a_repeat_rich_text_against_the_reference_binary(cli, tmp_path):
+    """`lamsa index` block by block against the reference's own builder (BWT-SW, src/bwt_gen.c) on a fresh 6 Mbp text with planted repeat
+    families, long exact repeats and a run of one base (deep suffix comparisons): .bwt and .sa byte for byte.  (The same comparison on a
+    120 Mbp text -- 240 M suffixes -- is recorded in profiles/r04_index.txt.)"""
+    import sys
+    sys.path.insert(0, os.path.join(G.ROOT, "tools"))
+    import numpy as np
+    import simdata
+    rng = np.random.default_rng(77)
+    contigs = simdata.make_reference(rng, [2_000_000, 2_500_000, 1_500_000], [(300, 1500), (1000, 300), (6000, 40)])
+    contigs[1][100_000:130_000] = contigs[0][500_000:530_000]                    # a 30 kbp exact copy
+    contigs[2][200_000:205_000] = 0                                             # 5 000 x A
+    contigs[2][300_000:304_000] = np.tile(np.array([0, 3], np.uint8), 2000)     # (AT)n
+    for d in ("ours", "theirs"):
+        os.makedirs(str(tmp_path / d))
+        simdata.write_fasta(str(tmp_path / d / "ref.fa"), [("chr%d" % (i + 1), c) for i, c in enumerate(contigs)])
+    p = subprocess.run([cli, "index", "--no-gem", str(tmp_path / "ours" / "ref.fa")], capture_output=True, text=True, env=dict(os.environ, LAMSA_INDEX_BLOCK="2000000"))
+    assert p.returncode == 0, p.stderr
+    q = subprocess.run([REF_BIN, "index", str(tmp_path / "theirs" / "ref.fa")], capture_output=True, text=True, timeout=1500)
+    assert os.path.exists(str(tmp_path / "theirs" / "ref.fa.sa")), q.stderr[-2000:]
+    for ext in ("pac", "ann", "amb", "bwt", "sa"):
+        assert open(str(tmp_path / "ours" / "ref.fa.") + ext, "rb").read() == open(str(tmp_path / "theirs" / "ref.fa.") + ext, "rb").read(), ext
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="the compiled reference (oracle/_ref/lamsa) is only built where /root/reference exists")
