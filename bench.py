@@ -148,6 +148,9 @@ def main():
                     "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target duration of the CPU baseline sample (0: skip)")
     ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--default-run-reads", type=int, default=768, help="reads of the default-run check after the CPU baseline: `lamsa aln` WITHOUT -R 0 (stage 4, the BWT rescue, on) of the compiled "
+                    "reference and of the product binary on a smaller stand-in whose .bwt / .sa `lamsa index --from-pac` builds on the spot (0: skip)")
+    ap.add_argument("--default-run-ref-bp", type=int, default=100_000_000, help="size of that stand-in (the FM index of the 3.1 Gbp one takes a quarter of an hour to build)")
     ap.add_argument("--bare", action="store_true", help="profiling runs: only set-up, warm-up and the timed steps (no one-call / streamed / CPU legs afterwards)")
     ap.add_argument("--rehearse", action="store_true", help="development only: run the N > 1 code path with the gloo backend and every rank on GPU 0 "
                     "(a one-GPU box cannot run RCCL with two ranks); the driver never passes this")
@@ -356,6 +359,12 @@ def main():
                 cpu["reference_binary"] = reference_binary_baseline(B, ref, wl, cpu_threads, a.cpu_seconds)
             except Exception as e:                           # a reported extra, never a reason to lose the bench line
                 cpu["reference_binary"] = {"error": repr(e)[:200]}
+            if a.default_run_reads > 0 and isinstance(cpu.get("reference_binary"), dict):
+                try:                                         # the reference's DEFAULT run (stage 4 on) against the product's, on an index built here
+                    cpu["reference_binary"]["default_run"] = default_run_check(a.workload, wl, cpu_threads, a.default_run_reads, a.default_run_ref_bp)
+                    cpu["reference_binary"]["gpu_equals_reference_on_sample_default_run"] = cpu["reference_binary"]["default_run"].get("gpu_equals_reference")
+                except Exception as e:
+                    cpu["reference_binary"]["default_run"] = {"error": repr(e)[:300]}
         hits = np.diff(B.hit_off)
         out = {
             "metric": "aligned Gbase/s, %s vs GRCh37-sized stand-in; inputs resident in HBM when the timed region starts (upload excluded: see pcie_inclusive_*)" % wl["desc"], "value": round(gbase_per_s, 6), "unit": "Gbase/s",
@@ -442,6 +451,84 @@ def reference_binary_baseline(B, ref, wl, threads, seconds):
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=None):
+    """The reference's DEFAULT run -- no -R 0: stage 4, the BWT rescue of unaligned read parts (src/bwt_aln.c:398-409), searches the FM
+    index -- against the product binary's, on files: a stand-in of ref_bp bases with the bench's repeat families, its .bwt / .sa built here by
+    the product's own `lamsa index --from-pac`, n_reads simulated reads of the workload with their seed hits as GEM map text.  Returns the
+    per-read SAM comparison, both wall times, and what share of the product's chunk loop went to stage 4 (its own trace)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    import simbatch
+    import simfiles
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "lamsa")
+    exe = exe or os.path.join(ROOT, "lamsa_amd", "bin", "lamsa")
+    if not os.path.exists(ref_exe) or not os.path.exists(exe):
+        return {"error": "the compiled reference or the product binary is not on this machine"}
+    p = simbatch.PROFILES[wl["profile"]]
+    args = [] if wl["read_type"] == "default" else ["-T", wl["read_type"]]
+    for k, v in wl["over"].items():
+        args += [{"band_w": "-w", "SV_len_thd": "-V"}[k], str(v)]
+    d = keep or tempfile.mkdtemp(prefix="lamsa_dflt_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        t0 = time.perf_counter()
+        ref = simbatch.SimRef(ref_bp, n_contigs=12, seed=17, threads=min(threads, 32))
+        B = simbatch.SimBatch(ref, n_reads, wl["length"], wl["profile"], seed=23, threads=min(threads, 32))
+        simfiles.write_index(d + "/ref.fa", ref)
+        t1 = time.perf_counter()
+        q = subprocess.run([exe, "index", "--from-pac", d + "/ref.fa"], capture_output=True, text=True, timeout=1500, env=dict(os.environ, LAMSA_INDEX_THREADS=str(min(threads, 64))))
+        if q.returncode != 0:
+            return {"error": "lamsa index --from-pac failed: " + q.stderr[-300:]}
+        t_index = time.perf_counter() - t1
+        simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"], workers=min(threads, 32))
+        with open(d + "/reads.fa.seed.info", "w") as f:
+            for r in range(n_reads):
+                f.write("r%d %d %d %d\n" % (r, int(B.seed_all[r]), int(B.last_len[r]), int(B.read_off[r + 1] - B.read_off[r])))
+        t_setup = time.perf_counter() - t0
+        t2 = time.perf_counter()
+        q = subprocess.run([ref_exe, "aln"] + args + ["-t", str(threads), "-N", "-I", "-o", d + "/out.sam", d + "/ref.fa", d + "/reads.fa"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=1500)
+        t_ref = time.perf_counter() - t2
+        if q.returncode != 0:
+            return {"error": "reference exited with %d: %s" % (q.returncode, q.stderr[-300:])}
+        t3 = time.perf_counter()
+        g = subprocess.run([exe, "aln"] + args + ["-t", str(min(threads, 32)), "-N", "-I", "-o", d + "/out_gpu.sam", d + "/ref.fa", d + "/reads.fa"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=1500,
+                           env=dict(os.environ, LAMSA_TRACE="1"))
+        t_gpu = time.perf_counter() - t3
+        if g.returncode != 0:
+            return {"error": "product binary exited with %d: %s" % (g.returncode, " | ".join(l for l in g.stderr.splitlines() if "read " not in l)[-400:])}
+        same = sam_same_reads(d + "/out.sam", d + "/out_gpu.sam")
+        # the product's own account of its write stage: "[write] N reads: records + stage-4 plan A s, stage-4 DP batch (J jobs) B s, finish + rank + SAM C s"
+        plan = dp = rest = 0.0; jobs = 0
+        for m in re.finditer(r"\[write\] \d+ reads: records(?: \+ stage-4 plan)? ([0-9.]+) s, stage-4 DP batch \((\d+) jobs\) ([0-9.]+) s, finish \+ rank \+ SAM ([0-9.]+) s", g.stderr):
+            plan += float(m.group(1)); jobs += int(m.group(2)); dp += float(m.group(3)); rest += float(m.group(4))
+        n_rescued = sum(1 for line in open(d + "/out.sam") if not line.startswith("@"))
+        return {"workload": workload, "reads": n_reads, "ref_bp": int(ref.l_pac), "gpu_equals_reference": same, "sam_lines_reference": n_rescued,
+                "index_build_s": round(t_index, 1), "setup_s": round(t_setup, 1), "reference_wall_s": round(t_ref, 2), "reference_threads": threads, "product_wall_s": round(t_gpu, 2),
+                "product_stage4": {"dp_jobs": jobs, "plan_s": round(plan, 3), "dp_batch_s": round(dp, 3), "finish_rank_sam_s": round(rest, 3),
+                                   "share_of_product_wall": round((plan + dp) / max(t_gpu, 1e-6), 4)},
+                "command": "lamsa aln %s -N -I  (no -R: stage 4 on)" % " ".join(args)}
+    finally:
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def sam_same_reads(a, b):
+    def by_read(path):
+        recs, hdr = {}, []
+        for line in open(path):
+            if line.startswith("@"):
+                if not line.startswith("@PG"):
+                    hdr.append(line)
+                continue
+            recs.setdefault(line.split("\t", 1)[0], []).append(line)
+        return hdr, recs
+    h1, r1 = by_read(a); h2, r2 = by_read(b)
+    same = sum(1 for k in r1 if r2.get(k) == r1[k])
+    note = "" if (h1 == h2 and len(r1) == len(r2)) else " (headers or read sets differ: %d vs %d reads)" % (len(r1), len(r2))
+    return "%d/%d reads%s" % (same, len(r1), note)
 
 
 def compare_with_product(d, args, threads, n, exe=None):

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, 1) void k_dp_batch_lane(DpBatchArgs a, const ui
 // from the read bytes and the packed reference, the direction matrix in LDS where it fits): 8 = a junction's ksw_bi_extend(h0, h0), 9 = a
 // seed gap's ksw_global2(w), 10 / 11 = a line's head / tail extension (ksw_extend_r / ksw_extend_c with (w, h0), the rest of the query
 // clipped, the head's CIGAR turned round -- frag_check.c:640-648, :699-703).
-__global__ __launch_bounds__(64, 4) void k_dp_batch_wave(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
+__global__ __launch_bounds__(64, HP_WJ_WAVES_PER_SIMD) void k_dp_batch_wave(DpBatchArgs a, const uint8_t *pac, const int64_t *tk)
 {
     __shared__ int32_t lds[HP_WJ_LDS_WORDS];
     for (;;) {

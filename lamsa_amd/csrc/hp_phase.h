@@ -353,6 +353,13 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
         for (int b0 = 0; b0 < nfr; b0 += 64) { WAVE_FOR(l) { const int f = f0 + b0 + l; if (b0 + l < nfr) { for (int q = g_so[f]; q < g_so[f + 1]; ++q) g_fo[q - p0] = f; } } }
         wv::sync();
     }
+    long long *cand = (long long *)arena_alloc(r.cx, sizeof(long long) * 4 * (size_t)(n_cand + 64));       // what the first pass finds out about every candidate: 32 bytes each
+    if (!cand) { r.flip = false; return; }
+    int n_lb[LJ_NBUCKET], n_wb[WJ_NBUCKET];
+#pragma unroll
+    for (int b = 0; b < LJ_NBUCKET; ++b) n_lb[b] = 0;
+#pragma unroll
+    for (int b = 0; b < WJ_NBUCKET; ++b) n_wb[b] = 0;
     for (int c0 = 0; c0 < n_cand; c0 += 64) {
         // ty: 0 none, 1 / 2 junction / seed gap (WJ_BI / WJ_GLOBAL), 3 / 4 head / tail; qo: where the query begins in the strand-appropriate read
         wv::Lane<int> ty, qo, ql, tl, qrev; wv::Lane<long long> tk, sl;
@@ -418,18 +425,65 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
             if (type != 0 && !small) type |= 16;                                // bit 4: a job of the wave-per-job launch
             ty[l] = type; qo[l] = qoff; ql[l] = qlen; tl[l] = tlen; sl[l] = slot; tk[l] = k0; qrev[l] = rev;
         }
-        wv::Lane<int> has, big, tbl;
-        WAVE_FOR(l) { has[l] = ty[l] != 0 && !(ty[l] & 16); big[l] = (ty[l] & 16) != 0; tbl[l] = ty[l] ? tl[l] : 0; }
-        const unsigned long long m = wv::ballot(has), mw = wv::ballot(big);
-        if (m) {                                                                // ---- the lane jobs
-            const int cnt = __builtin_popcountll(m);
-            int base = 0;
-            if (wv::leader()) base = atomicAdd(&a.ctl->lj_n[round], cnt);
-            base = wv::uni(base);
-            if (base + cnt <= a.lj_cap) {                                       // (queue full: these stay with the fill)
+        // noted in the wave's slab; the queues are entered once per LINE (below): a reservation per 64 candidates made every wave wait for
+        // ~10 atomics on the same few counters, 8 192 waves at a time (the listing launch was 98 % waiting: profiles/r04_ont10k_pmc.json)
+        WAVE_FOR(l) {
+            const int c = c0 + l;
+            if (c < n_cand) { HP_G int32_t *cw = (HP_G int32_t *)cand + 8 * (size_t)c; cw[0] = ty[l]; cw[1] = qo[l]; cw[2] = ql[l]; cw[3] = tl[l] | (qrev[l] << 30); *(HP_G long long *)(cw + 4) = tk[l]; *(HP_G long long *)(cw + 6) = sl[l]; }
+        }
+#pragma unroll
+        for (int b = 0; b < LJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = ty[l] != 0 && !(ty[l] & 16) && lj_bucket_of(ty[l], ql[l]) == b; n_lb[b] += __builtin_popcountll(wv::ballot(inb)); }
+#pragma unroll
+        for (int b = 0; b < WJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = (ty[l] & 16) && wj_bucket_of(P, ty[l] & 15, ql[l], tl[l]) == b; n_wb[b] += __builtin_popcountll(wv::ballot(inb)); }
+    }
+    // ---- one reservation per queue for the whole line: lanes 0 .. LJ_NBUCKET - 1 the lane-job queues, the next WJ_NBUCKET the wave-job queues, then the two record arrays
+    int n_l = 0, n_w = 0;
+#pragma unroll
+    for (int b = 0; b < LJ_NBUCKET; ++b) n_l += n_lb[b];
+#pragma unroll
+    for (int b = 0; b < WJ_NBUCKET; ++b) n_w += n_wb[b];
+    if (n_l + n_w > 0) {
+        wv::Lane<int> got;
+        WAVE_FOR(l) {
+            int v = 0, add = 0; int32_t *ctr = nullptr;
+#pragma unroll
+            for (int b = 0; b < LJ_NBUCKET; ++b) if (l == b) { add = n_lb[b]; ctr = &a.ctl->lj_bucket_n[round][b]; }
+#pragma unroll
+            for (int b = 0; b < WJ_NBUCKET; ++b) if (l == LJ_NBUCKET + b) { add = n_wb[b]; ctr = &a.ctl->wj_bucket_n[round][b]; }
+            if (l == LJ_NBUCKET + WJ_NBUCKET) { add = n_l; ctr = &a.ctl->lj_n[round]; }
+            if (l == LJ_NBUCKET + WJ_NBUCKET + 1) { add = n_w; ctr = &a.ctl->wj_n[round]; }
+            if (ctr && add > 0) v = atomicAdd(ctr, add);
+            got[l] = v;
+        }
+        int base_l = wv::bcast(got, LJ_NBUCKET + WJ_NBUCKET), base_w = wv::bcast(got, LJ_NBUCKET + WJ_NBUCKET + 1);
+        // a queue or a record array that is full: the line's jobs of that launch stay with the fill (the counters have moved on: the launches
+        // clamp what they read to the capacities)
+        bool ok_l = n_l > 0 && base_l + n_l <= a.lj_cap, ok_w = n_w > 0 && base_w + n_w <= a.wj_cap;
+        int pos_lb[LJ_NBUCKET], pos_wb[WJ_NBUCKET];
+#pragma unroll
+        for (int b = 0; b < LJ_NBUCKET; ++b) { pos_lb[b] = wv::bcast(got, b); if (n_lb[b] > 0 && pos_lb[b] + n_lb[b] > a.lj_cap) ok_l = false; }
+#pragma unroll
+        for (int b = 0; b < WJ_NBUCKET; ++b) { pos_wb[b] = wv::bcast(got, LJ_NBUCKET + b); if (n_wb[b] > 0 && pos_wb[b] + n_wb[b] > a.wj_cap) ok_w = false; }
+        // (a reservation that does not fit leaves its queue slots marked empty: the DP launches skip them)
+#pragma unroll
+        for (int b = 0; b < LJ_NBUCKET; ++b) if (!ok_l && n_lb[b] > 0) { for (int k0 = 0; k0 < n_lb[b]; k0 += 64) { WAVE_FOR(l) { const int k = pos_lb[b] + k0 + l; if (k0 + l < n_lb[b] && k < a.lj_cap) a.lj_bucket[(size_t)b * a.lj_cap + k] = -1; } } }
+#pragma unroll
+        for (int b = 0; b < WJ_NBUCKET; ++b) if (!ok_w && n_wb[b] > 0) { for (int k0 = 0; k0 < n_wb[b]; k0 += 64) { WAVE_FOR(l) { const int k = pos_wb[b] + k0 + l; if (k0 + l < n_wb[b] && k < a.wj_cap) a.wj_bucket[(size_t)b * a.wj_cap + k] = -1; } } }
+        wv::sync();
+        for (int c0 = 0; c0 < n_cand && (ok_l || ok_w); c0 += 64) {
+            wv::Lane<int> ty, qo, ql, tl, qrev; wv::Lane<long long> tk, sl;
+            WAVE_FOR(l) {
+                const int c = c0 + l;
+                ty[l] = 0; qo[l] = 0; ql[l] = 0; tl[l] = 0; qrev[l] = 0; tk[l] = 0; sl[l] = 0;
+                if (c < n_cand) { const HP_G int32_t *cw = (const HP_G int32_t *)cand + 8 * (size_t)c; ty[l] = cw[0]; qo[l] = cw[1]; ql[l] = cw[2]; tl[l] = cw[3] & 0x3fffffff; qrev[l] = (cw[3] >> 30) & 1; tk[l] = *(const HP_G long long *)(cw + 4); sl[l] = *(const HP_G long long *)(cw + 6); }
+            }
+            wv::Lane<int> has, big, tbl;
+            WAVE_FOR(l) { has[l] = ok_l && ty[l] != 0 && !(ty[l] & 16); big[l] = ok_w && (ty[l] & 16) != 0; tbl[l] = (has[l] || big[l]) ? tl[l] : 0; }
+            const unsigned long long m = wv::ballot(has), mw = wv::ballot(big);
+            if (m) {                                                            // ---- the lane jobs
                 wv::Lane<int> at;
                 WAVE_FOR(l) {
-                    at[l] = base + __builtin_popcountll(m & ((1ull << l) - 1));
+                    at[l] = base_l + __builtin_popcountll(m & ((1ull << l) - 1));
                     if (has[l]) {
                         LjRec &J = a.ljobs[at[l]];
                         // the query in the read as stored: a '-' line reads the reverse complement, base j of it is the complement of base L-1-j
@@ -437,27 +491,21 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                         J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = (uint8_t)ql[l]; J.tlen = (uint16_t)tl[l]; J.type_comp = (int8_t)(ty[l] | (strand == 1 ? 0 : 16));
                     }
                 }
+                base_l += __builtin_popcountll(m);
+#pragma unroll
                 for (int b = 0; b < LJ_NBUCKET; ++b) {                          // into the queue of its kind and length class
                     wv::Lane<int> inb;
                     WAVE_FOR(l) inb[l] = has[l] && lj_bucket_of(ty[l], ql[l]) == b;
                     const unsigned long long mb = wv::ballot(inb);
                     if (!mb) continue;
-                    int bb = 0;
-                    if (wv::leader()) bb = atomicAdd(&a.ctl->lj_bucket_n[round][b], __builtin_popcountll(mb));
-                    bb = wv::uni(bb);
-                    WAVE_FOR(l) { if (inb[l]) a.lj_bucket[(size_t)b * a.lj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                    WAVE_FOR(l) { if (inb[l]) a.lj_bucket[(size_t)b * a.lj_cap + pos_lb[b] + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                    pos_lb[b] += __builtin_popcountll(mb);
                 }
-            } else { WAVE_FOR(l) { if (has[l]) tbl[l] = 0; } }
-        }
-        if (mw) {                                                               // ---- the wave jobs
-            const int cnt = __builtin_popcountll(mw);
-            int base = 0;
-            if (wv::leader()) base = atomicAdd(&a.ctl->wj_n[round], cnt);
-            base = wv::uni(base);
-            if (base + cnt <= a.wj_cap) {
+            }
+            if (mw) {                                                           // ---- the wave jobs
                 wv::Lane<int> at, bk;
                 WAVE_FOR(l) {
-                    at[l] = base + __builtin_popcountll(mw & ((1ull << l) - 1)); bk[l] = -1;
+                    at[l] = base_w + __builtin_popcountll(mw & ((1ull << l) - 1)); bk[l] = -1;
                     if (big[l]) {
                         const int type = ty[l] & 15;
                         WjRec &J = a.wjobs[at[l]];
@@ -470,19 +518,19 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                         bk[l] = wj_bucket_of(P, type, ql[l], tl[l]);
                     }
                 }
+                base_w += __builtin_popcountll(mw);
+#pragma unroll
                 for (int b = 0; b < WJ_NBUCKET; ++b) {
                     wv::Lane<int> inb;
                     WAVE_FOR(l) inb[l] = bk[l] == b;
                     const unsigned long long mb = wv::ballot(inb);
                     if (!mb) continue;
-                    int bb = 0;
-                    if (wv::leader()) bb = atomicAdd(&a.ctl->wj_bucket_n[round][b], __builtin_popcountll(mb));
-                    bb = wv::uni(bb);
-                    WAVE_FOR(l) { if (inb[l]) a.wj_bucket[(size_t)b * a.wj_cap + bb + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                    WAVE_FOR(l) { if (inb[l]) a.wj_bucket[(size_t)b * a.wj_cap + pos_wb[b] + __builtin_popcountll(mb & ((1ull << l) - 1))] = at[l]; }
+                    pos_wb[b] += __builtin_popcountll(mb);
                 }
-            } else { WAVE_FOR(l) { if (big[l]) tbl[l] = 0; } }
+            }
+            tb += wv::reduce_sum(tbl);
         }
-        tb += wv::reduce_sum(tbl);
     }
     r.flip = false;
     r.t_bases = tb;
@@ -493,7 +541,8 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
 HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int wave_slot, HP_L int32_t *lds, int qcap)
 {
     const lamsa_hp_para *P = &a.P;
-    const int cnt = a.ctl->lj_bucket_n[round][bucket] - off < 64 ? a.ctl->lj_bucket_n[round][bucket] - off : 64;
+    const int n_in = a.ctl->lj_bucket_n[round][bucket] < a.lj_cap ? a.ctl->lj_bucket_n[round][bucket] : a.lj_cap;
+    const int cnt = n_in - off < 64 ? n_in - off : 64;
     char *slab = a.slab + (size_t)wave_slot * a.slab_fill;
     cig_t *cbuf = (cig_t *)slab;                                               // per lane three CIGAR buffers
     uint8_t *zbuf = (uint8_t *)(slab + sizeof(cig_t) * 3 * HP_LJ_CIG * 64);     // the lane-interleaved direction matrices
@@ -503,7 +552,7 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
     wv::sync();
     WAVE_FOR(l) {
         nw[l] = 0; rdl[l] = -1; cel[l] = 0; slotl[l] = 0;
-        if (l < cnt) {
+        if (l < cnt && bq[l] >= 0) {
             const LjRec R = a.ljobs[bq[l]];
             LaneJob J;
             const int comp = (R.type_comp >> 4) & 1, type = R.type_comp & 15;
@@ -526,7 +575,7 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
     base = (unsigned long long)wv::uni64((long long)base);
     if ((int64_t)(base + (unsigned long long)total) > a.job_cap) return;       // arena full: these stay with the fill
     WAVE_FOR(l) {
-        if (l < cnt) {
+        if (l < cnt && bq[l] >= 0) {
             const cig_t *src = cbuf + (size_t)l * 3 * HP_LJ_CIG;
             int32_t *dst = a.job_base + base + pre[l];
             for (int k = 0; k < nw[l]; ++k) dst[k] = src[k];
@@ -542,8 +591,10 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
 HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot, HP_L int32_t *lds)
 {
     int b = 0;
-    for (; b < WJ_NBUCKET - 1; ++b) { const int nb = a.ctl->wj_bucket_n[round][b]; if (g < nb) break; g -= nb; }
-    const WjRec R = a.wjobs[a.wj_bucket[(size_t)b * a.wj_cap + g]];
+    for (; b < WJ_NBUCKET - 1; ++b) { const int nb = a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap; if (g < nb) break; g -= nb; }
+    const int ji = wv::uni(a.wj_bucket[(size_t)b * a.wj_cap + g]);
+    if (ji < 0) return;                                                        // (a slot of a reservation that did not fit)
+    const WjRec R = a.wjobs[ji];
     const int rd = wv::uni(R.rd), type = wv::uni(R.type_comp) & 15, comp = (wv::uni(R.type_comp) >> 4) & 1;
     const int qs = (wv::uni(R.type_comp) >> 5) & 1 ? -1 : 1, ts = (wv::uni(R.type_comp) >> 6) & 1 ? -1 : 1;
     const int qlen = wv::uni(R.qlen), tlen = wv::uni(R.tlen);

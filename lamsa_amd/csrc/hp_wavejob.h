@@ -5,10 +5,11 @@
 // gaps of that size (frag_extend :360-400 -> ksw_global2) and the two end extensions (frag_head_bound_fix :576-654 -> ksw_extend_r,
 // frag_tail_bound_fix :656-707 -> ksw_extend_c, up to the whole read long).  None of them depends on the line's growing CIGAR -- only
 // merge_cigar (:251), which joins their results, is sequential -- so the listing launch (phase_filllist, hp_phase.h) writes them as job
-// records with the geometry the fill would compute, and this launch runs them one per wavefront, costliest first, at the register and LDS
-// budget of a DP kernel (4 waves per SIMD: 128 VGPRs, 9.5 KB of LDS -- the direction matrix of a 100-row junction stays on the CU) instead of
-// the glue kernel's (8 waves per SIMD: 64 VGPRs, 0.5 KB).  The fill finds the CIGARs in the job arena (FLines::jt / gt / ht) and goes on
-// with merge_cigar; a job that was not listed, or whose buffers did not suffice, is run by the fill as before.
+// records with the geometry the fill would compute, and this launch runs them one per wavefront, costliest first: a launch that is all
+// instruction issue (VALU port 78 % busy) beside a fill launch that is all memory latency (wait 89 %), instead of one kernel that is both; the
+// direction matrix of the two-columns-per-lane routines lies in the wave's LDS where it fits (a junction of up to 80 rows).  The fill finds the
+// CIGARs in the job arena (FLines::jt / gt / ht) and goes on with merge_cigar; a job that was not listed, or whose buffers did not suffice, is
+// run by the fill as before.
 // The routines are those of hp_ksw.h: same recurrences, tie rules, band and z-drop logic, whatever launch calls them.
 #pragma once
 #include "hp_lanedp.h"
@@ -30,8 +31,11 @@ HP_INL int wj_bucket_of(const lamsa_hp_para *P, int type, int qlen, int tlen)
     return WJ_NBUCKET - 1 - b;
 }
 
+#ifndef HP_WJ_WAVES_PER_SIMD
+#define HP_WJ_WAVES_PER_SIMD 8          // measured (profiles/r04_overlap.txt, ont10k, ms of the launch alone / reads/s with two batches in flight): 4 waves per SIMD and 9.5 KB of LDS 66.3 / 317 k, 6 and 6.5 KB 63.4 / 326 k, 8 and 5 KB 64.7 / 339 k
+#endif
 #ifndef HP_WJ_LDS_WORDS
-#define HP_WJ_LDS_WORDS 2432                     // 9.5 KB: sixteen waves per CU, as the chaining kernels
+#define HP_WJ_LDS_WORDS HP_LDS_WORDS             // 5 KB: thirty-two waves per CU (the launch is bound by instruction issue; more waves beat more LDS, hp_align_api.hip)
 #endif
 
 struct WjOut { int score, qle, tle, reflen, readlen; };

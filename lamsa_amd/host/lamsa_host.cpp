@@ -605,13 +605,20 @@ void parse_stream(const int32_t *s, int n_words, int read_len, ReadResult &R)
     }
 }
 
+// a stable sort that allocates nothing for the handful of elements a read has (std::stable_sort asks for a buffer every time)
+template <class It, class Less> static inline void small_stable_sort(It b, It e, Less less)
+{
+    if (e - b > 24) { std::stable_sort(b, e, less); return; }
+    for (It i = b + (b != e); i < e; ++i) { auto v = *i; It j = i; while (j > b && less(v, *(j - 1))) { *j = *(j - 1); --j; } *j = v; }
+}
+
 // get_cov_f, src/lamsa_aln.c:639-651
 static float cov_fraction(const ReadResult &R, int read_len)
 {
     std::vector<std::pair<int, int>> reg;
     for (int st = 0; st < 3; ++st) for (const Line &ln : R.stage[st]) { if (ln.tol_score < 0) continue; for (const Rec &r : ln.rec) reg.push_back({r.reg_beg, r.reg_end}); }
     if (reg.empty()) return (float)(0.0 / read_len);
-    std::stable_sort(reg.begin(), reg.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    small_stable_sort(reg.begin(), reg.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
     int cov = 0; size_t cur = 0;
     for (size_t i = 1; i < reg.size(); ++i) {                              // aln_merg_reg with thd 0, :499
         if (reg[i].first - reg[cur].second - 1 < 0) { if (reg[i].second > reg[cur].second) reg[cur].second = reg[i].second; }
@@ -641,7 +648,7 @@ void rank_results(ReadResult &R, int read_len, const lamsa_hp_para &P)
             qua.push_back({st, (int)i, l.tol_score, l.line_score});
         }
     if (qua.empty()) return;
-    std::stable_sort(qua.begin(), qua.end(), [](const Q &x, const Q &y) { return x.a != y.a ? x.a > y.a : x.b > y.b; });   // res_comp :632 on glibc's stable qsort
+    small_stable_sort(qua.begin(), qua.end(), [](const Q &x, const Q &y) { return x.a != y.a ? x.a > y.a : x.b > y.b; });   // res_comp :632 on glibc's stable qsort
     auto L = [&](int i) -> Line & { return R.stage[qua[i].st][qua[i].li]; };
     std::vector<int> head;
     std::vector<std::pair<int, int>> reg;                                     // intervals of the accepted heads, in acceptance order
@@ -711,9 +718,26 @@ static inline void append_int(std::string &o, long long v)
     if (v < 0) buf[n++] = '-';
     while (n) o.push_back(buf[--n]);
 }
+// The CIGAR of a 10-kbp noisy read has ~1 500 operations, nearly all of one or two digits: they are formatted into a block of the string's
+// own storage through a pointer (no per-character capacity check), lengths below 100 from a table of digit pairs.
+static inline char *put_len(char *p, unsigned v)
+{
+    static const char D2[] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+    if (v < 10) { *p++ = (char)('0' + v); return p; }
+    if (v < 100) { p[0] = D2[2 * v]; p[1] = D2[2 * v + 1]; return p + 2; }
+    char buf[12]; int n = 0;
+    while (v >= 100) { const unsigned q = v / 100, r = v - 100 * q; buf[n++] = D2[2 * r + 1]; buf[n++] = D2[2 * r]; v = q; }
+    if (v >= 10) { buf[n++] = D2[2 * v + 1]; buf[n++] = D2[2 * v]; } else buf[n++] = (char)('0' + v);
+    while (n) *p++ = buf[--n];
+    return p;
+}
 static inline void append_cigar(std::string &o, const std::vector<int32_t> &cig, const char *ops)
 {
-    for (int32_t w : cig) { append_int(o, w >> 4); o.push_back(ops[w & 0xf]); }
+    const size_t k0 = o.size();
+    o.resize(k0 + 11 * cig.size());                          // at most ten digits and the operation
+    char *p = &o[k0];
+    for (int32_t w : cig) { p = put_len(p, (unsigned)(w >> 4)); *p++ = ops[w & 0xf]; }
+    o.resize((size_t)(p - o.data()));
 }
 
 void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index &ix, const Options &opt)
@@ -722,6 +746,7 @@ void write_sam(std::string &o, const ReadResult &R, const Read &rd, const Index 
     const int read_len = (int)rd.seq.size();
     const bool with_qual = rd.has_qual && opt.comm;
     int all = 0; bool prim = false;
+    if (o.capacity() - o.size() < 4 * (size_t)read_len + 4096) o.reserve(o.size() + std::max<size_t>(o.size() / 2, 8 * (size_t)read_len + 65536));      // grown in large steps, not per append
     for (int st = 0; st < 3; ++st)
         for (const Line &la : R.stage[st]) {
             if (la.merg_x != 1) continue;

@@ -156,10 +156,10 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
                 for (int b = 0; b < PH_NBUCKET; ++b)
                     for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filllist(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
                 int nw = 0;
-                for (int b = 0; b < WJ_NBUCKET; ++b) nw += ctl.wj_bucket_n[round][b];
+                for (int b = 0; b < WJ_NBUCKET; ++b) nw += ctl.wj_bucket_n[round][b] < p.wj_cap ? ctl.wj_bucket_n[round][b] : p.wj_cap;
                 for (int g = 0; g < nw; ++g) phase_wavejob(p, round, g, 0, lds_wj);
                 for (int b = 0; b < LJ_NBUCKET; ++b)
-                    for (int off = 0; off < ctl.lj_bucket_n[round][b]; off += 64) phase_filldp(p, round, b, off, 0, lds_lj, HP_LJ_QSMALL);
+                    for (int off = 0; off < (ctl.lj_bucket_n[round][b] < p.lj_cap ? ctl.lj_bucket_n[round][b] : p.lj_cap); off += 64) phase_filldp(p, round, b, off, 0, lds_lj, HP_LJ_QSMALL);
             }
             for (int b = 0; b < PH_NBUCKET; ++b)
                 for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_fill(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);

@@ -46,6 +46,16 @@ for n_sh, src in ((2, ["--hits", d + "/hits.bin"]), (2, [])):
     same = not any(rcs) and subprocess.run("cat %s/out.0.sam %s/out.1.sam | grep -v ^@PG | cmp - <(grep -v ^@PG %s/out.sam)" % (d, d, d), shell=True, executable="/bin/bash").returncode == 0
     print("%d shards %s, one after the other: rc %s, %s s wall each -> %.0f reads/s if they ran on %d GPUs; concatenated == unsharded SAM: %s" % (
         n_sh, " ".join(src) or "(GEM map text)", rcs, ", ".join("%.2f" % x for x in dts), n / max(dts), n_sh, same), flush=True)
+# Eight shards at once on the host alone (--parse-only makes no GPU call): what the host side of an 8-GPU node has to keep up with.  This box
+# grants one GPU's share of the cores (16), so every shard gets an eighth of it -- a lower bound for a node that brings 16 cores per GPU.
+for src, what in ((["--hits", d + "/hits.bin"], "hit stream"), ([], "GEM map text")):
+    per = max(1, min(threads, 32) // 8)
+    t = time.time()
+    ps = [subprocess.Popen([exe, "aln", "-N", "-T", "ont2d", "-R", "0", "-t", str(per), "--batch", batch, "--shard", "%d/8" % i, "--parse-only"] + src + [d + "/ref.fa", d + "/reads.fa"],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(8)]
+    rcs = [q.wait() for q in ps]
+    dt = time.time() - t
+    print("8 shards --parse-only at once (%s), %d threads each on %d cores: rc %s, %.2f s wall -> %.0f reads/s ingested in aggregate" % (what, per, threads, rcs, dt, n / dt), flush=True)
 # does the time to reserve the device buffers depend on a process that has just released its own?
 time.sleep(20)
 t = time.time()
