@@ -70,7 +70,7 @@ def count_mapped_bases(B, streams):
 
 
 LAUNCH_KEYS = ["retry", "chain1", "fill1", "chain2", "fill2", "publish", "drain_chain1", "drain_fill1", "drain_chain2", "drain_fill2", "lines_round1", "lines_round2", "dp1_within_fill1",
-               "list1_within_fill1", "wave_dp1_within_fill1", "wave_jobs", "wave_jobs_alg_MB", "lane_jobs", "cigars_ahead_MB"]
+               "list1_within_fill1", "wave_dp1_within_fill1", "wave_jobs", "wave_jobs_alg_MB", "lane_jobs", "cigars_ahead_MB", "wave_jobs_Mcells"]
 N_LAUNCH = len(LAUNCH_KEYS) + 1
 
 
@@ -311,6 +311,18 @@ def main():
                 "hbm_bytes_per_pair_eval": round(chain_traffic / max(pairs, 1), 2) if chain_traffic else None,
                 "valu_lane_slots_per_cell": round(valu_fill * 64.0 / max(cells, 1), 1) if valu_fill else None,
                 "valu_issue_frac": {k: v.get("valu_issue_frac") for k, v in prof.items() if isinstance(v, dict) and v.get("valu_issue_frac") is not None} or None}
+        # the compute-side ceiling of the DP launch (the path is max-plus DP, not bytes): how busy the two issue ports were (committed counter pass),
+        # what a cell cost in VALU lane-slots, and what the recurrence alone needs (~22 lane operations per cell -- substitution
+        # score 3, M 2, E 4, F 4, H and the direction nibble 6, the matrix store 3 -- before any cross-lane work of a row)
+        wave = prof.get("k_filldp_wave", {})
+        wv_ = wave.get("round1") or wave
+        wave_valu = (wave.get("per_dispatch") or {}).get("SQ_INSTS_VALU") or (wv_.get("per_dispatch") or {}).get("SQ_INSTS_VALU")
+        wave_cells = lm["wave_jobs_Mcells"] * 1e6
+        roof["compute"] = {"kernel": "k_filldp_wave", "valu_busy": wv_.get("valu_busy_frac"), "salu_busy": wv_.get("salu_busy_frac"),
+                           "lane_slots_per_cell": round(wave_valu * 64.0 / wave_cells, 1) if (wave_valu and wave_cells) else None,
+                           "lane_slots_per_cell_recurrence_only": 22, "dp_cells_per_launch": int(wave_cells),
+                           "gcups_of_the_launch": round(wave_cells / max(lm_seq["wave_dp1_within_fill1"] if lm_seq else lm["wave_dp1_within_fill1"], 1e-6) / 1e6, 1) if wave_cells else None,
+                           "source": prof.get("_source")}
         t_pcie = r_seq = float("nan")
         if not a.bare:
             # PCIe-inclusive rate of the one-call boundary (host buffers in, host results out), one untimed step; never `value`

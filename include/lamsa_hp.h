@@ -206,7 +206,8 @@ void  lamsa_hp_host_free(void *p);
  * pass consists of (chaining round 1, gap fill of its lines, chaining round 2, gap fill of its lines, result assembly); 7..10: how long each of the first four spent draining (first wave
  * that found the queue empty -> last wave done, i.e. time with idle wave slots); 11, 12: lines filled in round 1 / round 2; 13: of "gap fill, round 1"
  * the part before the fill launch proper (job listing + the two DP launches), 14: the listing, 15: the wave-per-job DP launch; 16: wave jobs listed,
- * 17: their algorithmic bytes (MB: sequences read, CIGARs written), 18: lane jobs listed, 19: MB of CIGARs computed ahead of the fill. */
+ * 17: their algorithmic bytes (MB: sequences read, CIGARs written), 18: lane jobs listed, 19: MB of CIGARs computed ahead of the fill, 20: DP cells the wave jobs
+ * updated (millions). */
 float lamsa_hp_last_kernel_ms(const lamsa_hp_handle *h, int which);
 
 /* Cap the per-wave scratch slab of the first pass at `bytes` (0 = size it from the batch, the default).  The slab

@@ -237,7 +237,7 @@ struct HostBuf {                  // page-locked host memory, mapped into the de
 // grid is running (a 0.6 GB copy took 10 ms beside it, five 0.5 MB ones 380 ms).
 struct OutDev {
     DevBuf buf; HostBuf host; int64_t stream_cap = 0; int n_cap = 0;
-    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256 + al256(16 * (size_t)n); }      // offsets, three int arrays, 16 words of launch accounting, four accounting words per read
+    static size_t hdr(int n) { return al256(8 * (size_t)n) + 3 * al256(4 * (size_t)n) + 256 + al256(16 * (size_t)n); }      // offsets, three int arrays, 32 words of launch accounting, four accounting words per read
     int ensure(int n, int64_t cap) { stream_cap = cap; n_cap = n; return buf.ensure(4 * (size_t)cap + 256) || host.ensure(hdr(n) + 256); }
     // device-visible addresses (kernel arguments)
     int64_t *off() const { return (int64_t *)host.dev; }
@@ -726,7 +726,7 @@ static int finish_main(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, lam
         hipEventElapsedTime(&h->kernel_ms[13], Ln.ep[0], Ln.ep[4]);                         // of "fill1" (kernel_ms[3]): listing + the two DP launches
         hipEventElapsedTime(&h->kernel_ms[14], Ln.ep[0], Ln.ep[5]);                         // ... the listing
         hipEventElapsedTime(&h->kernel_ms[15], Ln.ep[5], Ln.ep[6]);                         // ... the wave-per-job DP launch
-        h->kernel_ms[16] = (float)dg[12]; h->kernel_ms[17] = (float)((double)dg[13] * 1e-6); h->kernel_ms[18] = (float)dg[14]; h->kernel_ms[19] = (float)((double)dg[15] * 4e-6);   // wave jobs, their algorithmic MB, lane jobs, MB of CIGARs computed ahead
+        h->kernel_ms[16] = (float)dg[12]; h->kernel_ms[17] = (float)((double)dg[13] * 1e-6); h->kernel_ms[18] = (float)dg[14]; h->kernel_ms[19] = (float)((double)dg[15] * 4e-6); h->kernel_ms[20] = (float)((double)dg[16] * 1e-6);   // wave jobs, their algorithmic MB, lane jobs, MB of CIGARs computed ahead
 #ifdef HP_PROF
         prof_report(T, (const long long *)Ln.prof.p, n);
 #endif

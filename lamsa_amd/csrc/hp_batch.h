@@ -49,7 +49,7 @@ struct BatchOut {
     int32_t *read_status;        // [n_reads]
     int32_t *read_tbases;        // [n_reads] reference bases fetched (2-bit windows), or nullptr
     int32_t *read_work;          // [4 * n_reads] per read: DP cells updated, chaining edge classifications executed, seed-CIGAR words read, 0; or nullptr
-    unsigned long long *diag;    // 16 words of launch accounting (hp_phase.h), or nullptr
+    unsigned long long *diag;    // 32 words of launch accounting (hp_phase.h), or nullptr
 };
 
 struct AlignArgs {

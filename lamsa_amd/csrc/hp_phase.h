@@ -52,6 +52,7 @@ struct PhaseCtl {                // counters of one launch sequence, zeroed befo
     int32_t lj_n[2], lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (kind x query-length class; LJ_NBUCKET <= 24)
     int32_t wj_n[2], wj_bucket_n[2][WJ_NBUCKET];      // wave-per-job DP (hp_wavejob.h): jobs listed per round, and per cost class
     unsigned long long wj_bytes;                       // algorithmic bytes of the wave-per-job launches: query bases + 2-bit target bases read, CIGAR words + slots written
+    unsigned long long wj_cells;                       // DP cells they updated
     // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
     // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
     // draining, i.e. with idle wave slots
@@ -608,7 +609,7 @@ HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot,
     const lamsa_hp_para *P = &a.P;
     const bool ok = wj_run(cx, a.in.read_seq, a.ref.pac, type, comp, wv::uni64(R.qaddr), qs, qlen, wv::uni64(R.tk), ts, tlen,
                            P->band_w, type == WJ_BI ? 100 : P->seed_len * P->match, out, o);
-    if (cx.n_cells > 0 && wv::leader()) atomicAdd(&a.meta[rd].cells, (int)(cx.n_cells > 0x3fffffffLL ? 0x3fffffffLL : cx.n_cells));
+    if (cx.n_cells > 0 && wv::leader()) { atomicAdd(&a.meta[rd].cells, (int)(cx.n_cells > 0x3fffffffLL ? 0x3fffffffLL : cx.n_cells)); atomicAdd(&a.ctl->wj_cells, (unsigned long long)cx.n_cells); }
     if (!ok) return;                                                           // left to the fill, which runs the job itself and flags what there is to flag
     unsigned long long base = 0;
     if (wv::leader()) base = atomicAdd(&a.ctl->job_cursor, (unsigned long long)out.n);
@@ -716,7 +717,7 @@ HP_INL void publish_diag(const PhaseArgs &a)
         a.out.diag[8] = (unsigned long long)a.ctl->n_units[0]; a.out.diag[9] = (unsigned long long)a.ctl->n_units[1];
         a.out.diag[10] = a.ctl->fl_cursor; a.out.diag[11] = a.ctl->line_cursor;
         a.out.diag[12] = (unsigned long long)(a.ctl->wj_n[0] + a.ctl->wj_n[1]); a.out.diag[13] = a.ctl->wj_bytes; a.out.diag[14] = (unsigned long long)(a.ctl->lj_n[0] + a.ctl->lj_n[1]);
-        a.out.diag[15] = a.ctl->job_cursor;
+        a.out.diag[15] = a.ctl->job_cursor; a.out.diag[16] = a.ctl->wj_cells;
     }
 }
 
