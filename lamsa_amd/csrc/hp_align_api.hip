@@ -40,8 +40,8 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
 #define HP_CHAIN_WAVES_PER_SIMD 4
 #endif
 #ifndef HP_FILL_WAVES_PER_SIMD
-#define HP_FILL_WAVES_PER_SIMD 8
-#endif
+#define HP_FILL_WAVES_PER_SIMD 7          // round 4, the fill without its DPs (profiles/r04_overlap.txt; ms of k_fill, ont10k): 8 waves per SIMD (64 VGPRs) 44.6, 7 (72) 34.2, 6 (80) 34.7, 5 (96) 40.8, 4 (128) 41.3 --
+#endif                                    // with 64 registers the append loop of frags_merge reloads spilled values behind its own stores (loads and stores share vmcnt on gfx9: a reload waits for every store before it)
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;        // in device memory: scalar loads, no private copy of the argument block

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64, HP_WJ_WAVES_PER_SIMD) void k_dp_batch_wave(DpBa
         job = wv::uni(job);
         if (job >= a.n_jobs) break;
         Ctx cx;
-        cx.P = &a.P; cx.lds = (HP_L int32_t *)lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr;
+        cx.P = &a.P; cx.lds = (HP_L int32_t *)lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = nullptr;
         arena_init(cx.tmp, a.slab + (size_t)blockIdx.x * a.slab_per_wave, a.slab_per_wave);
         const int type = wv::uni(a.kind[job]) - 7, qlen = wv::uni(a.qlen[job]), tlen = wv::uni(a.tlen[job]);
         const bool back = type == WJ_HEAD;

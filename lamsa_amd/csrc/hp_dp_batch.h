@@ -21,7 +21,7 @@ HP_FN void dp_run_job(const DpBatchArgs &a, int job, int wave_slot, HP_L int32_t
 {
     Ctx cx;
     cx.P = &a.P;
-    cx.status = 0; cx.n_cells = 0; cx.prof = nullptr; cx.lds = lds; cx.lds_words = HP_LDS_WORDS;
+    cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = nullptr; cx.lds = lds; cx.lds_words = HP_LDS_WORDS;
     arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_per_wave, a.slab_per_wave);
     const int ql = a.qlen[job], tl = a.tlen[job];
     Seq q = seq_fwd(a.seq + a.q_off[job]), t = seq_fwd(a.seq + a.t_off[job]);

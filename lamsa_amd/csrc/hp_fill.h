@@ -463,7 +463,13 @@ HP_INL void junction_geo(const ReadCtx &r, const FLines &F, int f1, int f2, JGeo
     G.cls = G.s_qlen > 0 ? 1 : 2;
 }
 
-struct MergeSrc { const cig_t *p; int n, first, last, reflen, readlen; };       // p == nullptr: a one-element CIGAR, the element in `first`
+// p == nullptr: a one-element CIGAR, the element in `first`; ls: the CIGAR's words staged in the wave's LDS (or nullptr -- NOT tested: `staged` says)
+struct MergeSrc { const cig_t *p; int n, first, last, reflen, readlen; const HP_L int32_t *ls; bool staged; };
+// Short CIGARs of a 64-step block of frags_merge are staged in the wave's LDS when the block's plan is made (all of them requested at once, one
+// step per lane): an append then copies from LDS instead of waiting ~2 us for its own load, 300 times per line one after the other.  Per step
+// FM_SW words of its seed CIGAR and FM_JW of its junction's; longer ones are loaded when their turn comes, as before.  The staging lives in the
+// DP rows' part of the LDS; a general routine that may run a DP with LDS rows invalidates it for the rest of the block.
+enum { FM_SW = 8, FM_JW = 10, FM_W = FM_SW + FM_JW };      // 64 * 18 = 1152 words = the rows' part of HP_LDS_WORDS
 
 // merge_cigar (:251-328) with _push_cigar (frag_check.h:158-184) for the common cases; `tail` = the record's last CIGAR element (valid when n > 0).
 // It works on the record's running state held in registers (frags_merge): the length of the record's CIGAR, its reference and read
@@ -508,7 +514,8 @@ HP_INL bool merge_fast_loc(ReadCtx &r, Rec &res, MergeLoc &m, int &tail, bool &o
     const int mm = S.n - j;
     if (n1 + mm > cap) ovf = true;
     else if (mm > 0) {
-        if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
+        if (S.staged) { WAVE_FOR(l) { if (l < mm) dst[n1 + l] = S.ls[j + l]; } }
+        else if (S.p) { const HP_G cig_t *src = (const HP_G cig_t *)S.p; for (int b0 = 0; b0 < mm; b0 += 64) { WAVE_FOR(l) { const int i = b0 + l; if (i < mm) dst[n1 + i] = src[j + i]; } } }
         else dst[n1] = S.first;
         m.n = n1 + mm; tail = S.last;
     }
@@ -534,8 +541,13 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
     const cig_t *const seed_cigs = (const cig_t *)wv::uni64((long long)r.cig); const cig_t *const job_cigs = (const cig_t *)wv::uni64((long long)F.jarena);
     const int seed_len = wv::uni(P->seed_len);
     int tail = ml.n > 0 ? (int)res_c[ml.n - 1] : 0;
+    HP_L int32_t *const stg = cx.lds;
+    const bool stage = cx.lds_words >= 64 * FM_W;
     for (int t0 = 0; t0 < nfr && ok; t0 += 64) {
         HP_T0(tg64_);
+        bool staged_ok = stage;                      // the block's staged CIGARs are intact
+        const int epoch0 = cx.lds_epoch;             // (a boundary repair's DP may have been large enough to use the LDS rows: checked after each)
+        wv::sync();                                  // (the previous block's are no longer read)
         // ---- 64 steps, one per lane: the fragment's seed CIGAR and the junction to the next fragment
         WAVE_FOR(l) {
             const int t = t0 + l;
@@ -550,6 +562,13 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                     const int64_t co = r.h_cig_off[s]; const int cn = r.h_cig_n[s];
                     v[1] = (int)(co & 0xffffffffll); v[2] = (int)(co >> 32); v[3] = cn; v[6] = P->seed_len + r.h_len_dif[s]; v[7] = r.h_chr[s];
                     if (cn > 0) { v[4] = r.cig[co]; v[5] = r.cig[co + cn - 1]; }
+                    if (stage && cn > 0 && cn <= FM_SW) {
+                        int w[FM_SW];
+#pragma unroll
+                        for (int k = 0; k < FM_SW; ++k) w[k] = k < cn ? (int)r.cig[co + k] : 0;
+#pragma unroll
+                        for (int k = 0; k < FM_SW; ++k) stg[l * FM_W + k] = w[k];
+                    }
                 }
                 if (t < nfr - 1) {
                     const int f2 = strand == 1 ? f - 1 : f + 1;
@@ -558,7 +577,16 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                     if (G.cls == 2) { v[8] = G.tl > 0 ? 1 : 0; v[10] = 1; v[11] = v[12] = (G.tl << 4) | C_D; v[13] = G.tl; v[14] = 0; }       // 1: deletion of the bases between the seeds, 0: nothing
                     else if (G.cls == 1) {
                         const int32_t *jt = F.jt ? F.jt + 4 * (f < f2 ? f : f2) : nullptr;
-                        if (jt && jt[3] && F.jarena) { v[8] = 2; v[9] = jt[0]; v[10] = jt[1]; v[13] = jt[2]; v[14] = G.s_qlen; if (jt[1] > 0) { v[11] = F.jarena[jt[0]]; v[12] = F.jarena[jt[0] + jt[1] - 1]; } }   // 2: computed ahead
+                        if (jt && jt[3] && F.jarena) {                                  // 2: computed ahead
+                            v[8] = 2; v[9] = jt[0]; v[10] = jt[1]; v[13] = jt[2]; v[14] = G.s_qlen; if (jt[1] > 0) { v[11] = F.jarena[jt[0]]; v[12] = F.jarena[jt[0] + jt[1] - 1]; }
+                            if (stage && jt[1] > 0 && jt[1] <= FM_JW) {
+                                int w[FM_JW];
+#pragma unroll
+                                for (int k = 0; k < FM_JW; ++k) w[k] = k < jt[1] ? (int)F.jarena[jt[0] + k] : 0;
+#pragma unroll
+                                for (int k = 0; k < FM_JW; ++k) stg[l * FM_W + FM_SW + k] = w[k];
+                            }
+                        }
                     }
                 }
             }
@@ -573,15 +601,27 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
             const int t = t0 + q, f = strand == 1 ? f0 + nfr - 1 - t : f0 + t;
             // frag_extend, :332-410
             if (wv::bcast(V[0], q)) {
+#if defined(HP_PROF) && defined(HP_PROF_FILL)
+                const long long tpa_ = wv::clock();
+#endif
                 MergeSrc S;
                 S.p = seed_cigs + (((int64_t)wv::bcast(V[2], q) << 32) | (unsigned)wv::bcast(V[1], q)); S.n = wv::bcast(V[3], q); S.first = wv::bcast(V[4], q); S.last = wv::bcast(V[5], q);
                 S.reflen = wv::bcast(V[6], q); S.readlen = seed_len;
+                if (cx.lds_epoch != epoch0) staged_ok = false;
+                S.ls = stg + q * FM_W; S.staged = staged_ok && S.n <= FM_SW;
                 cs_ += S.n;
+#if defined(HP_PROF) && defined(HP_PROF_FILL)
+                const long long tpb_ = wv::clock();
+#endif
                 ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[7], q), S, res_c, res_cap);
+#if defined(HP_PROF) && defined(HP_PROF_FILL)
+                if (cx.prof) { cx.prof[13] += tpb_ - tpa_; cx.prof[11] += wv::clock() - tpb_; }
+#endif
             } else {
                 mloc_out(ml, res);
                 wv::sync();
                 HP_T0(tfm_);
+                staged_ok = false;                   // (its DPs may use the LDS rows)
                 ok = frag_extend_multi(r, F, f, res);
                 HP_TADD_FILL(cx, 20, tfm_);
                 wv::sync();
@@ -595,16 +635,25 @@ HP_NOINL bool frags_merge(ReadCtx &r, const FLines &F, int f0, int nfr, int stra
                 mloc_out(ml, res);
                 wv::sync();
                 HP_T0(tsm_);
+                staged_ok = false;
                 ok = split_mapping(r, F, f, strand == 1 ? f - 1 : f + 1, res);
                 HP_TADD_FILL(cx, 18, tsm_);
                 wv::sync();
                 mloc_in(ml, res);
                 tail = ml.n > 0 ? (int)res_c[ml.n - 1] : 0;
             } else if (kind != 0) {
+#if defined(HP_PROF) && defined(HP_PROF_FILL)
+                const long long tpc_ = wv::clock();
+#endif
                 MergeSrc S;
                 S.p = kind == 2 ? job_cigs + wv::bcast(V[9], q) : nullptr; S.n = wv::bcast(V[10], q); S.first = wv::bcast(V[11], q); S.last = wv::bcast(V[12], q);
                 S.reflen = wv::bcast(V[13], q); S.readlen = wv::bcast(V[14], q);
+                if (cx.lds_epoch != epoch0) staged_ok = false;
+                S.ls = stg + q * FM_W + FM_SW; S.staged = staged_ok && kind == 2 && S.n <= FM_JW;
                 ok = merge_fast_loc(r, res, ml, tail, ovf, wv::bcast(V[15], q), S, res_c, res_cap);
+#if defined(HP_PROF) && defined(HP_PROF_FILL)
+                if (cx.prof) cx.prof[12] += wv::clock() - tpc_;
+#endif
             }
         }
     }

@@ -381,6 +381,7 @@ HP_NOINL ExtRes ksw_extend_wide(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
 HP_NOINL int ksw_global_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
                             int o_del, int e_del, int o_ins, int e_ins, int w, CigV *out)
 {
+    ++cx.lds_epoch;                                                         // the rows live in LDS
     long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     HP_T0(tg0_);
     qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w);            // wave-uniform: keep them in scalar registers
@@ -945,6 +946,7 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
     // the matrix in LDS when the wave's share holds it (every byte of a row is written, 0xF = a cell outside the row's band); else in the
     // slab with the band limits of every row beside it
     const bool zl = (size_t)zs * (size_t)tlen <= z_cap_pk(cx);
+    if (zl) ++cx.lds_epoch;
     uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1);
     int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
     if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
@@ -1435,6 +1437,7 @@ HP_NOINL int ksw_global_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int o_del,
     const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
     const size_t mark = arena_mark(cx.tmp);
     const bool zl = (size_t)zs * (size_t)tlen <= z_cap_pk(cx);            // the matrix in LDS when the wave's share holds it
+    if (out && zl) ++cx.lds_epoch;
     uint8_t *z = (out && !zl) ? (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1) : nullptr;
     if (out && !zl && !z) { arena_release(cx.tmp, mark); return 0; }
     HP_L uint8_t *LZ = (HP_L uint8_t *)cx.lds;
@@ -1572,6 +1575,7 @@ HP_INL int ksw_global(Ctx &cx, int qlen, Seq q, int tlen, Seq t,
 
 HP_NOINL ExtRes ksw_extend_lds(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
 {
+    ++cx.lds_epoch;                                                         // the rows live in LDS
     long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
     ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
     HP_T0(te0_);

@@ -601,7 +601,7 @@ HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot,
     const int qlen = wv::uni(R.qlen), tlen = wv::uni(R.tlen);
     if (*(volatile int32_t *)&a.meta[rd].status & ST_DEAD) return;
     Ctx cx;
-    cx.P = &a.P; cx.lds = lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
+    cx.P = &a.P; cx.lds = lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
     arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_wj, a.slab_wj);
     CigV out;
     if (!cig_alloc(cx, out, qlen + tlen + 64)) return;

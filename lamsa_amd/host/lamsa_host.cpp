@@ -900,7 +900,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
 {
     const double t_begin = now_s();
     double parse_s = 0, submit_s = 0, wait_s = 0, sam_s = 0;
-    long n_mapped_chunks = 0;                                // chunks whose SAM text went out through a mapping of the output file
+    long n_mapped_chunks = 0;                                // chunks whose SAM text the threads wrote side by side
     // Every way out of this function before the map has been read to its end -- an index that does not load, a map that does not match
     // the reads, a failed submit -- must not leave the mapper started by run_seeding running (and writing, on -t cores): it is told to
     // stop and waited for, and its exit status reported.
@@ -1284,34 +1284,31 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
                 write_sam(o, R, B.reads[(size_t)r], ix, opt);
             }
         });
-        // The chunk's text (15 KB per 10-kbp read) goes out in input order.  Into a regular file the threads copy their parts side by side through
-        // a mapping of the file's new end (one thread's write() of 250 MB per chunk was the slowest stage of the loop once the hits came from a
-        // binary stream); a pipe or a terminal takes them one after the other.
+        // The chunk's text (15 KB per 10-kbp read) goes out in input order.  Into a regular file every thread writes its own part at its own
+        // offset (pwrite: one thread's write() of 250 MB per chunk was the slowest stage of the loop once the hits came from a binary stream;
+        // a mapping of the file's new end, round 3's way, pays a page fault per 4 KB and was slower still: profiles/r04_cli_bench.txt); a pipe
+        // or a terminal takes the parts one after the other.
         bool mapped_out = false;
         {
             size_t total = 0; for (const std::string &x : sams) total += x.size();
             struct stat st; const int fd = fileno(out);
             static const size_t map_min = getenv("LAMSA_MAP_OUT_MIN") ? (size_t)atol(getenv("LAMSA_MAP_OUT_MIN")) : ((size_t)8 << 20);      // (tests lower it)
-            // only a descriptor open for reading AND writing can be mapped shared and writable (main.cpp opens -o that way; a shell's `>` is
-            // write-only and takes the fwrite path); the new end is allocated, not just declared: a store into a hole of a full disk is a SIGBUS
-            if (threads > 1 && total >= map_min && fd >= 0 && (fcntl(fd, F_GETFL) & O_ACCMODE) == O_RDWR && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fflush(out) == 0) {
+            if (threads > 1 && total >= map_min && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(fcntl(fd, F_GETFL) & O_APPEND) && fflush(out) == 0) {
                 const off_t base = lseek(fd, 0, SEEK_CUR);
-                const long pg = sysconf(_SC_PAGESIZE);
-                if (base >= 0 && pg > 0 && posix_fallocate(fd, base, (off_t)total) == 0) {
-                    const off_t m0 = base / pg * pg;
-                    void *m = mmap(nullptr, (size_t)(base - m0) + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
-                    if (m != MAP_FAILED) {
-                        char *dst = (char *)m + (base - m0);
-                        std::vector<size_t> at((size_t)threads + 1, 0);
-                        for (int t = 0; t < threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + sams[(size_t)t].size();
-                        std::vector<std::thread> th;
-                        for (int t = 0; t < threads; ++t) if (!sams[(size_t)t].empty()) th.emplace_back([&, t]() { memcpy(dst + at[(size_t)t], sams[(size_t)t].data(), sams[(size_t)t].size()); });
-                        for (auto &x : th) x.join();
-                        munmap(m, (size_t)(base - m0) + total);
-                        mapped_out = lseek(fd, base + (off_t)total, SEEK_SET) == base + (off_t)total;
-                        if (!mapped_out) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
-                        ++n_mapped_chunks;
-                    } else if (ftruncate(fd, base) != 0) { fprintf(stderr, "[lamsa_aln] cannot restore the output file's length\n"); return 2; }
+                if (base >= 0) {
+                    std::vector<size_t> at((size_t)threads + 1, 0);
+                    for (int t = 0; t < threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + sams[(size_t)t].size();
+                    std::atomic<int> werr(0);
+                    std::vector<std::thread> th;
+                    for (int t = 0; t < threads; ++t) if (!sams[(size_t)t].empty()) th.emplace_back([&, t]() {
+                        const char *p = sams[(size_t)t].data(); size_t left = sams[(size_t)t].size(); off_t o = base + (off_t)at[(size_t)t];
+                        while (left) { const ssize_t k = pwrite(fd, p, left, o); if (k <= 0) { if (k < 0 && errno == EINTR) continue; werr = errno ? errno : EIO; return; } p += k; left -= (size_t)k; o += k; }
+                    });
+                    for (auto &x : th) x.join();
+                    if (werr.load()) { fprintf(stderr, "[lamsa_aln] cannot write the output file: %s\n", strerror(werr.load())); return 2; }
+                    mapped_out = lseek(fd, base + (off_t)total, SEEK_SET) == base + (off_t)total;
+                    if (!mapped_out) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
+                    ++n_mapped_chunks;
                 }
             }
         }
@@ -1387,7 +1384,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     if (reserver.joinable()) reserver.join();
     for (lamsa_hp_handle *hh : hs) lamsa_hp_destroy(hh);
     if (h_dp) lamsa_hp_destroy(h_dp);
-    if (trace) fprintf(stderr, "[write] %ld chunks written through a mapping of the output file\n", n_mapped_chunks);
+    if (trace) fprintf(stderr, "[write] %ld chunks written by all threads side by side (pwrite)\n", n_mapped_chunks);
     if (stats) { stats->n_reads = n_reads; stats->n_bases = n_bases; stats->n_bad = n_bad; stats->kernel_ms = kernel_ms;
                  stats->wall_s = now_s() - t_begin; stats->load_s = load_s; stats->parse_s = parse_s; stats->submit_s = submit_s; stats->wait_s = wait_s; stats->sam_s = sam_s; stats->reserve_s = reserve_s; }
     return ret;

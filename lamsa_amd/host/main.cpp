@@ -97,10 +97,7 @@ int main(int argc, char *argv[])
                   /* fall through */
         case 'S': opt.supp_soft = 1; break;
         case 'C': opt.comm = 1; break;
-        case 'o': {     // read-write: the chunk loop writes SAM text through a mapping of the file's new end, and a write-only descriptor cannot be mapped
-                  const int ofd = open(optarg, O_RDWR | O_CREAT | O_TRUNC, 0666);
-                  out = ofd >= 0 ? fdopen(ofd, "w+") : nullptr;
-                  if (!out) { if (ofd >= 0) close(ofd); fprintf(stderr, "[lamsa_aln] Can not open output file: %s.\n", optarg); return 1; } break; }
+        case 'o': out = fopen(optarg, "w"); if (!out) { fprintf(stderr, "[lamsa_aln] Can not open output file: %s.\n", optarg); return 1; } break;
         case 'N': opt.no_seed_aln = 1; break;
         case 'I': break;                                            // seed info is recomputed from the read lengths either way
         case 1000: opt.device = atoi(optarg); break;

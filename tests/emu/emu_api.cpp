@@ -185,7 +185,7 @@ extern "C" int emu_split_indel_map(const lamsa_hp_para *P, const uint8_t *read, 
 {
     std::vector<char> slab((size_t)64 << 20);
     static thread_local int32_t lds[HP_BOTH_LDS_WORDS];
-    Ctx cx; cx.P = P; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr; cx.lds = lds; cx.lds_words = HP_LDS_WORDS;
+    Ctx cx; cx.P = P; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = nullptr; cx.lds = lds; cx.lds_words = HP_LDS_WORDS;
     arena_init(cx.tmp, slab.data(), slab.size());
     CigV out; cig_bind(out, cig, cig_cap);
     *ret = split_indel_map(cx, out, read, read_len, ref, ref_len, ref_offset);
@@ -206,7 +206,7 @@ extern "C" int emu_wave_job(const lamsa_hp_para *P, int n, const uint8_t *seq, c
     std::vector<char> slab(slab_bytes);
     static thread_local int32_t lds_wj[HP_WJ_LDS_WORDS];
     for (int i = 0; i < n; ++i) {
-        Ctx cx; cx.P = P; cx.lds = lds_wj; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.prof = nullptr;
+        Ctx cx; cx.P = P; cx.lds = lds_wj; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = nullptr;
         arena_init(cx.tmp, slab.data(), slab.size());
         const bool back = type == WJ_HEAD;
         CigV out; cig_bind(out, cig + cig_off[i], (int)(cig_off[i + 1] - cig_off[i]));

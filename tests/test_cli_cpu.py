@@ -57,23 +57,26 @@ def test_error_paths(cli, tmp_path):
     assert seeds[0].endswith("_0:0") and len(seeds[1]) == 50 and seeds[2].endswith("_1:100")
 
 
-def test_output_file_written_through_a_mapping_by_all_threads(cli, tmp_path):
-    """-o FILE: the SAM text of a chunk is copied into a mapping of the file's new end by the threads side by side (chunks of 8 MB and
-    more; LAMSA_MAP_OUT_MIN lowers the limit); the file is the same as the text written to a pipe, header and chunk order included."""
+def test_output_file_written_by_all_threads_side_by_side(cli, tmp_path):
+    """A regular output file (-o FILE, or stdout redirected into one): the SAM text of a chunk is written by the threads side by side, each at
+    its own offset (chunks of 8 MB and more; LAMSA_MAP_OUT_MIN lowers the limit); the file is the same as the text written to a pipe, header
+    and chunk order included -- and the parallel path really ran."""
     ref, reads, args, want = G.stage_scenario("c2_pacbio", str(tmp_path))
     out = str(tmp_path / "out.sam")
     for limit, t in (("1", "3"), ("1", "5"), ("100000000", "3")):
         p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", t, "--batch", "7", "-o", out] + args + [ref, reads], capture_output=True, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN=limit, LAMSA_TRACE="1"))
         assert p.returncode == 0, p.stderr[-2000:]
         assert G.strip_pg(open(out).read()) == G.strip_pg(want), (limit, t)
-        # the mapped path really ran (a write-only descriptor cannot be mapped: -o is opened read-write), and only when the chunk is large enough
-        mapped = int(re.search(r"\[write\] (\d+) chunks written through a mapping", p.stderr).group(1))
-        assert (mapped > 0) == (limit == "1"), (limit, t, mapped)
-    # a write-only descriptor (a shell's `>`) takes the fwrite path and writes the same text
-    with open(out, "w") as fo:
+        n_par = int(re.search(r"\[write\] (\d+) chunks written by all threads side by side", p.stderr).group(1))
+        assert (n_par > 0) == (limit == "1"), (limit, t, n_par)
+    with open(out, "w") as fo:                          # a shell's `>`
         p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", "3", "--batch", "7"] + args + [ref, reads], stdout=fo, stderr=subprocess.PIPE, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN="1", LAMSA_TRACE="1"))
-    assert p.returncode == 0 and "[write] 0 chunks written through a mapping" in p.stderr, p.stderr[-2000:]
+    assert p.returncode == 0 and "[write] 0 chunks written" not in p.stderr, p.stderr[-2000:]
     assert G.strip_pg(open(out).read()) == G.strip_pg(want)
+    with open(out, "a") as fo:                          # `>>`: an append-mode descriptor ignores offsets: one after the other
+        p = subprocess.run([cli, "aln", "-N", "-R", "0", "-t", "3", "--batch", "7"] + args + [ref, reads], stdout=fo, stderr=subprocess.PIPE, text=True, env=dict(os.environ, LAMSA_MAP_OUT_MIN="1", LAMSA_TRACE="1"))
+    assert p.returncode == 0 and "[write] 0 chunks written" in p.stderr, p.stderr[-2000:]
+    assert G.strip_pg(open(out).read()) == G.strip_pg(want) + G.strip_pg(want)
 
 
 def test_seed_cigars_in_words_when_an_element_does_not_fit_a_byte(cli, tmp_path):
