@@ -133,15 +133,23 @@ __global__ __launch_bounds__(64, HP_WJ_WAVES_PER_SIMD) void k_filldp_wave(const 
 {
     __shared__ int32_t lds[HP_WJ_LDS_WORDS];
     const PhaseArgs &a = *ap;
-    int n = 0;
-    for (int b = 0; b < WJ_NBUCKET; ++b) n += a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap;
-    n = wv::uni(n);
+    int n = 0, n_big = 0;
+    for (int b = 0; b < WJ_NBUCKET; ++b) { const int k = a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap; if (b < WJ_NBIG) n_big += k; else n += k; }
+    n = wv::uni(n); n_big = wv::uni(n_big);
+    if ((int)blockIdx.x < a.n_wjb)                      // this wave owns a big slab: the jobs that need one first (they are the costliest)
+        for (;;) {
+            int g = 0;
+            if (wv::leader()) g = atomicAdd(&a.ctl->q_head[8], 1);
+            g = wv::uni(g);
+            if (g >= n_big) break;
+            phase_wavejob(a, round, g, true, blockIdx.x, (HP_L int32_t *)lds);
+        }
     for (;;) {
         int g = 0;
         if (wv::leader()) g = atomicAdd(&a.ctl->q_head[7], 1);
         g = wv::uni(g);
         if (g >= n) break;
-        phase_wavejob(a, round, g, blockIdx.x, (HP_L int32_t *)lds);
+        phase_wavejob(a, round, g, false, blockIdx.x, (HP_L int32_t *)lds);
     }
 }
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
@@ -532,29 +540,33 @@ static int64_t main_stream_cap(int n, int64_t n_bases) { return 1024 + (int64_t)
 // scratch of a wave of each kind of launch (all launches of a batch share one allocation, one after the other): the chaining launches keep
 // per-hit arrays, the listing / lane-DP / fill launches result and CIGAR buffers and the small DPs the fill still runs itself, the
 // wave-per-job launch the direction matrix of the longest end extension
-struct SlabPlan { size_t chain, fill, wj; int w_chain, w_fill, w_dp, w_wj; size_t bytes; };
+struct SlabPlan { size_t chain, fill, wj, wjb, wjb_off; int w_chain, w_fill, w_dp, w_wj, n_wjb; size_t bytes; };
 // shared: another batch's launches are in flight on the handle's other stream.  The launches are persistent grids; at full size the earlier
 // batch's grid owns every wave slot and the later one only gets what its tail leaves.  The DP launch is bound by instruction issue (VALU port
 // 78 % busy, profiles/r04_ont10k_pmc.json) and the chaining / fill launches by memory latency (wait 74-89 %, VALU 26-38 %): with every grid
 // capped at half a CU's slots the launches of the two batches run side by side on the same CUs, one filling the issue slots the other leaves
-// idle -- measured 339 k reads/s against 317 k with full grids (profiles/r04_overlap.txt).  A batch that runs alone gets the whole CU.
+// idle -- measured 357 k reads/s against 345 k with full grids (profiles/r04_overlap.txt).  A batch that runs alone gets the whole CU.
 static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared = false)
 {
     SlabPlan Q;
-    Q.chain = slab_bytes_for(h->para, max_L, max_H, 1);
-    Q.wj = Q.chain;
-    // the fill without the big direction matrix: 256 KiB + 128 B per base, and what a lane-DP group needs
-    Q.fill = al256(((size_t)256 << 10) + 128 * (size_t)max_L + sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64);
-    if (g_nowave) Q.fill = std::max(Q.fill, Q.chain);                    // (diagnostics: the fill runs every DP itself)
-    if (h->scratch_limit) { Q.chain = std::min(Q.chain, al256(h->scratch_limit)); Q.fill = std::min(Q.fill, al256(h->scratch_limit)); Q.wj = std::min(Q.wj, al256(h->scratch_limit)); }
+    const lamsa_hp_para &P = h->para;
+    // chaining: per-hit arrays, line sets, fragments.  Listing / lane DP / fill: result and CIGAR buffers, the small DPs the fill still runs
+    // itself, a lane-DP group's buffers.  Wave jobs: an ordinary slab takes the junctions and the end extensions of a few thousand rows; the
+    // direction matrix of the longest end extension (the whole read long) lives in one of the big slabs that only the first waves own.
+    Q.chain = al256(((size_t)256 << 10) + 128 * (size_t)max_L + 424 * (size_t)max_H);
+    Q.fill = al256(((size_t)256 << 10) + 128 * (size_t)max_L + sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QSMALL * HP_LJ_TSMALL * 64 + 64);
+    Q.wj = (size_t)1 << 20;
+    Q.wjb = al256((size_t)wj_need(&P, WJ_HEAD, max_L, max_L + 2 * P.hash_step + 64) + ((size_t)64 << 10));
+    if (Q.wjb < Q.wj) Q.wjb = Q.wj;
+    if (g_nowave) Q.fill = std::max(Q.fill, slab_bytes_for(P, max_L, max_H, 1));            // (diagnostics: the fill runs every DP itself)
+    if (h->scratch_limit) { const size_t lim = al256(h->scratch_limit); Q.chain = std::min(Q.chain, lim); Q.fill = std::min(Q.fill, lim); Q.wj = std::min(Q.wj, lim); Q.wjb = std::min(Q.wjb, lim); }
     int pc = 0, pf = 0, pd = 0, pw = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_filldp_wave, 64, 0) != hipSuccess || pw < 1) pw = 4;
-    // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU cap the persistent grids below what fits a CU, so that the launches of two
-    // batches in flight can share the CUs instead of the later one waiting for the earlier one's waves to exit
     if (shared && !g_noshare) { pc = std::min(pc, 8); pf = std::min(pf, 16); pw = std::min(pw, 16); }
+    // diagnostic: LAMSA_HP_FILL_PER_CU / LAMSA_HP_CHAIN_PER_CU / LAMSA_HP_WJ_PER_CU set the grids' waves per CU
     { static const int cf = getenv("LAMSA_HP_FILL_PER_CU") ? atoi(getenv("LAMSA_HP_FILL_PER_CU")) : 0, cc = getenv("LAMSA_HP_CHAIN_PER_CU") ? atoi(getenv("LAMSA_HP_CHAIN_PER_CU")) : 0,
                        cw = getenv("LAMSA_HP_WJ_PER_CU") ? atoi(getenv("LAMSA_HP_WJ_PER_CU")) : 0;
       if (cf > 0 && cf < pf) pf = cf;
@@ -562,7 +574,11 @@ static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared 
       if (cw > 0 && cw < pw) pw = cw; }
     Q.w_chain = cap_waves(h->n_cu * pc, Q.chain, h->n_cu); Q.w_fill = cap_waves(h->n_cu * pf, Q.fill, h->n_cu);
     Q.w_dp = std::min(h->n_cu * pd, Q.w_fill); Q.w_wj = cap_waves(h->n_cu * pw, Q.wj, h->n_cu);
-    Q.bytes = std::max(std::max(Q.chain * (size_t)Q.w_chain, Q.fill * (size_t)Q.w_fill), Q.wj * (size_t)Q.w_wj);
+    // big slabs: 12 GB of them, at most one per wave of the launch and at least one per CU's worth of waves where that fits
+    { const size_t budget_big = (size_t)12 << 30; size_t nb = budget_big / Q.wjb; if (nb < 1) nb = 1; Q.n_wjb = (int)std::min<size_t>(nb, (size_t)Q.w_wj); }
+    Q.wjb_off = al256(Q.wj * (size_t)Q.w_wj);
+    const size_t wj_bytes = Q.wjb_off + Q.wjb * (size_t)Q.n_wjb;
+    Q.bytes = std::max(std::max(Q.chain * (size_t)Q.w_chain, Q.fill * (size_t)Q.w_fill), wj_bytes);
     return Q;
 }
 
@@ -585,7 +601,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.in = T.in;
     a.out.read_out_off = O.off(); a.out.read_out_len = O.len(n); a.out.read_status = O.st(n); a.out.read_tbases = O.tb(n); a.out.read_work = O.work(n); a.out.stream = O.stream(n);
     a.out.stream_cap = O.stream_cap; a.out.cursor = (unsigned long long *)((char *)Ln.misc.p + 64); a.out.diag = O.diag(n);
-    a.slab = (char *)Ln.slab.p; a.slab_per_wave = Q.chain; a.slab_fill = Q.fill; a.slab_wj = Q.wj; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
+    a.slab = (char *)Ln.slab.p; a.slab_per_wave = Q.chain; a.slab_fill = Q.fill; a.slab_wj = Q.wj; a.slab_wjb = Q.wjb; a.wjb_off = Q.wjb_off; a.n_wjb = Q.n_wjb; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
     a.order = T.d_order; a.n_reads = n; a.prof = nullptr;
 #ifdef HP_PROF
     if (Ln.prof.ensure(sizeof(long long) * 64 * ((size_t)n + 1))) { h->err = "hipMalloc(prof)"; return LAMSA_HP_ENOMEM; }
@@ -622,7 +638,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
     if (list) {
-        HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 12, s), LAMSA_HP_EKERNEL);          // the three queue heads of the listing and DP launches
+        HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 16, s), LAMSA_HP_EKERNEL);          // the four queue heads of the listing and DP launches
         hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 1);
         if (!g_nowave) hipLaunchKernelGGL(k_filldp_wave, dim3(w_wj), dim3(64), 0, s, da, 1);
         if (!g_nolane) hipLaunchKernelGGL(k_filldp_small, dim3(w_dp), dim3(64), 0, s, da, 1);

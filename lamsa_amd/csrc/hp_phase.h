@@ -45,7 +45,7 @@ struct UnitRec {                 // one line to fill
 enum { PH_NBUCKET = 8, PH_REG_WORDS = 10 };
 
 struct PhaseCtl {                // counters of one launch sequence, zeroed before chain1
-    int32_t q_head[8];           // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish
+    int32_t q_head[12];          // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish, 5 listing, 6 lane DP, 7 wave DP, 8 wave DP (jobs that need a big slab)
     int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
     int32_t bucket_n[2][PH_NBUCKET];
     unsigned long long fl_cursor, line_cursor, job_cursor;
@@ -81,6 +81,7 @@ struct PhaseArgs {
     struct LjRec *ljobs; int32_t *lj_bucket; int32_t lj_cap;     // [lj_cap] job records and [LJ_NBUCKET][lj_cap] queues of job indices of the round being filled
     WjRec *wjobs; int32_t *wj_bucket; int32_t wj_cap;            // the same for the wave-per-job launch: [wj_cap] records, [WJ_NBUCKET][wj_cap] queues; wj_cap 0: no such launch
     size_t slab_fill, slab_wj;                                   // scratch of a wave of the listing / lane-DP / fill launches and of the wave-per-job launch (slab_per_wave: the chaining launches)
+    size_t slab_wjb, wjb_off; int32_t n_wjb;                     // the first n_wjb waves of the wave-per-job launch also own a big slab of slab_wjb bytes (at slab + wjb_off): they take the jobs that need one
     PhaseCtl *ctl;
 };
 
@@ -435,7 +436,9 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
 #pragma unroll
         for (int b = 0; b < LJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = ty[l] != 0 && !(ty[l] & 16) && lj_bucket_of(ty[l], ql[l]) == b; n_lb[b] += __builtin_popcountll(wv::ballot(inb)); }
 #pragma unroll
-        for (int b = 0; b < WJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = (ty[l] & 16) && wj_bucket_of(P, ty[l] & 15, ql[l], tl[l]) == b; n_wb[b] += __builtin_popcountll(wv::ballot(inb)); }
+        { wv::Lane<int> wb; WAVE_FOR(l) wb[l] = (ty[l] & 16) ? wj_bucket_of(P, ty[l] & 15, ql[l], tl[l], wj_need(P, ty[l] & 15, ql[l], tl[l]) > (long long)a.slab_wj) : -1;
+#pragma unroll
+          for (int b = 0; b < WJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = wb[l] == b; n_wb[b] += __builtin_popcountll(wv::ballot(inb)); } }
     }
     // ---- one reservation per queue for the whole line: lanes 0 .. LJ_NBUCKET - 1 the lane-job queues, the next WJ_NBUCKET the wave-job queues, then the two record arrays
     int n_l = 0, n_w = 0;
@@ -516,7 +519,7 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
                         J.qaddr = strand == 1 ? rbase + qo[l] : rbase + (r.L - 1 - qo[l]);
                         J.tk = tk[l]; J.slot = sl[l]; J.rd = rd; J.qlen = ql[l]; J.tlen = tl[l];
                         J.type_comp = type | (comp << 4) | ((back ^ comp) << 5) | (back << 6);
-                        bk[l] = wj_bucket_of(P, type, ql[l], tl[l]);
+                        bk[l] = wj_bucket_of(P, type, ql[l], tl[l], wj_need(P, type, ql[l], tl[l]) > (long long)a.slab_wj);
                     }
                 }
                 base_w += __builtin_popcountll(mw);
@@ -547,7 +550,7 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
     char *slab = a.slab + (size_t)wave_slot * a.slab_fill;
     cig_t *cbuf = (cig_t *)slab;                                               // per lane three CIGAR buffers
     uint8_t *zbuf = (uint8_t *)(slab + sizeof(cig_t) * 3 * HP_LJ_CIG * 64);     // the lane-interleaved direction matrices
-    if (sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QCAP * HP_LJ_TCAP * 64 + 64 > a.slab_fill) return;
+    if (sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)qcap * HP_LJ_TSMALL * 64 + 64 > a.slab_fill) return;
     const int32_t *bq = a.lj_bucket + (size_t)bucket * a.lj_cap + off;
     wv::Lane<int> nw, rdl, cel; wv::Lane<long long> slotl;
     wv::sync();
@@ -588,11 +591,12 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
     wv::sync();
 }
 
-// job `g` of the round's wave-job queues, costliest class first (hp_wavejob.h)
-HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot, HP_L int32_t *lds)
+// job `g` of the round's wave-job queues b0 .. b1 - 1, costliest class first (hp_wavejob.h); big: the jobs that need a big slab (this wave owns one)
+HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, bool big, int wave_slot, HP_L int32_t *lds)
 {
-    int b = 0;
-    for (; b < WJ_NBUCKET - 1; ++b) { const int nb = a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap; if (g < nb) break; g -= nb; }
+    const int b1 = big ? WJ_NBIG : WJ_NBUCKET;
+    int b = big ? 0 : WJ_NBIG;
+    for (; b < b1 - 1; ++b) { const int nb = a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap; if (g < nb) break; g -= nb; }
     const int ji = wv::uni(a.wj_bucket[(size_t)b * a.wj_cap + g]);
     if (ji < 0) return;                                                        // (a slot of a reservation that did not fit)
     const WjRec R = a.wjobs[ji];
@@ -602,7 +606,8 @@ HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, int wave_slot,
     if (*(volatile int32_t *)&a.meta[rd].status & ST_DEAD) return;
     Ctx cx;
     cx.P = &a.P; cx.lds = lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
-    arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_wj, a.slab_wj);
+    if (big) arena_init(cx.tmp, a.slab + a.wjb_off + (size_t)wave_slot * a.slab_wjb, a.slab_wjb);
+    else arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_wj, a.slab_wj);
     CigV out;
     if (!cig_alloc(cx, out, qlen + tlen + 64)) return;
     WjOut o;

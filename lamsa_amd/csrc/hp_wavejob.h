@@ -19,16 +19,33 @@ namespace hp {
 enum { WJ_BI = 1, WJ_GLOBAL = 2, WJ_HEAD = 3, WJ_TAIL = 4 };
 // type_comp: type | complement << 4 (a '-' line reads the reverse complement of the read) | query walked backwards << 5 | target walked backwards << 6
 struct WjRec { int64_t qaddr, tk, slot; int32_t rd, qlen, tlen, type_comp; };
-enum { WJ_NBUCKET = 12 };            // cost classes (powers of two of query length x band), costliest first
+// Queues of the wave jobs, costliest first: WJ_NBIG classes of jobs whose scratch (above all the direction matrix of a long end extension)
+// does not fit a wave's ordinary slab -- only the waves that own a big slab take those (the first n_wjb waves of the launch: a few hundred
+// MB-sized slabs instead of one per wave, which is what capped the 20-kbp workload at 4 096 waves and 17 MB each) -- then WJ_NSMALL cost
+// classes (powers of two of query length x band) that every wave takes.
+enum { WJ_NBIG = 4, WJ_NSMALL = 12, WJ_NBUCKET = WJ_NBIG + WJ_NSMALL };
 
-HP_INL int wj_bucket_of(const lamsa_hp_para *P, int type, int qlen, int tlen)
+// what a job can ask of its slab at most: the staged sequences, the CIGARs of ksw_bi_extend (left, right, result, the global fallback's), the
+// band limits of every row, HBM rows of the widest routine, and the direction matrix -- a row of it is the band's columns, or 64 / 128 / 256
+// bytes of the register routines (hp_ksw.h)
+HP_HD long long wj_need(const lamsa_hp_para *P, int type, int qlen, int tlen)
+{
+    const int d = qlen > tlen ? qlen - tlen : tlen - qlen;
+    const int w = type == WJ_BI && d + 3 > P->band_w ? d + 3 : P->band_w;
+    long long ncol = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    if (ncol < 256) ncol = 256;
+    return ((long long)64 << 10) + 40ll * ((long long)qlen + tlen) + 16ll * qlen + ncol * ((long long)tlen + 16);
+}
+
+HP_INL int wj_bucket_of(const lamsa_hp_para *P, int type, int qlen, int tlen, bool big)
 {
     const int band = 2 * P->band_w + 1, cols = qlen < band ? qlen : band;
     // rows: a junction's target; an end extension stops by z-drop somewhere along the query
     const long long cost = (long long)(type == WJ_HEAD || type == WJ_TAIL ? qlen : tlen) * (cols > 0 ? cols : 1);
     int b = 0;
-    for (long long c = cost >> 11; c > 0 && b < WJ_NBUCKET - 1; c >>= 1) ++b;
-    return WJ_NBUCKET - 1 - b;
+    if (big) { for (long long c = cost >> 20; c > 0 && b < WJ_NBIG - 1; c >>= 1) ++b; return WJ_NBIG - 1 - b; }
+    for (long long c = cost >> 11; c > 0 && b < WJ_NSMALL - 1; c >>= 1) ++b;
+    return WJ_NBIG + WJ_NSMALL - 1 - b;
 }
 
 #ifndef HP_WJ_WAVES_PER_SIMD

@@ -10,6 +10,7 @@ int g_emu_gaptab_cap = 1 << 30;        // tests: reads with more seed slots than
 #define HP_GAPTAB_CAP_RT(cap) (g_emu_gaptab_cap < (cap) ? g_emu_gaptab_cap : (cap))
 int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than this take the wave-wide routine (hp_gaps.h)
 #define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
+int g_emu_wj_small = 0;                // tests: the ordinary slab of a wave job in bytes (0: as large as a big one), so that small inputs have jobs that need a big slab
 int g_emu_wave_jobs = 1;               // tests: 0 = no wave-per-job launch (hp_wavejob.h): the fill runs the junctions beyond a lane job and the end extensions itself
 int g_emu_pk = 1;                      // tests: 0 = extensions of 63 .. 254 query bases take the int32 register sets instead of the packed int16 routine (hp_ksw.h)
 #define HP_PK_RT g_emu_pk
@@ -96,6 +97,7 @@ extern "C" void emu_set_phased(int on) { g_emu_phased = on; }
 extern "C" void emu_set_cl_cap(int cap) { g_emu_cl_cap = cap > 0 ? cap : (cap < 0 ? 0 : 1 << 30); }      // < 0: no clusters at all (the whole-read HBM paths)
 extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab_cap > 0 ? tab_cap : (tab_cap < 0 ? 0 : 1 << 30); g_emu_gap_mcap = mcap > 0 ? mcap : (mcap < 0 ? 0 : 1 << 30); }
 extern "C" void emu_set_wave_jobs(int on) { g_emu_wave_jobs = on; }
+extern "C" void emu_set_wj_small(int bytes) { g_emu_wj_small = bytes; }
 extern "C" void emu_set_pk(int on) { g_emu_pk = on; }
 extern "C" long long emu_stat(int i) { return g_emu_stat[i & 31]; }
 extern "C" void emu_dplog_on(int on) { g_emu_dplog_on = on; g_emu_dplog.clear(); }
@@ -126,7 +128,7 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
     if (scale == 1 && g_emu_phased) {
         // the product's main pass: chain1 -> fill -> chain2 -> fill -> publish, every phase over the whole batch before the next starts
         PhaseArgs p;
-        p.P = a.P; p.ref = a.ref; p.in = a.in; p.out = a.out; p.slab = slab.data(); p.slab_per_wave = slab_bytes; p.slab_fill = slab_bytes; p.slab_wj = slab_bytes;
+        p.P = a.P; p.ref = a.ref; p.in = a.in; p.out = a.out; p.slab = slab.data(); p.slab_per_wave = slab_bytes; p.slab_fill = slab_bytes; p.slab_wj = g_emu_wj_small > 0 ? (size_t)g_emu_wj_small : slab_bytes; p.slab_wjb = slab_bytes; p.wjb_off = 0; p.n_wjb = 1;
         p.sort_pb = a.sort_pb; p.sort_cb = a.sort_cb; p.order = nullptr; p.n_reads = B->n_reads; p.prof = nullptr;
         const int n = B->n_reads;
         const int64_t n_hits = n ? B->hit_off[B->seed_off[n]] : 0, n_bases = n ? B->read_off[n] : 0;
@@ -155,9 +157,10 @@ extern "C" int emu_align_batch(const lamsa_hp_para *P, const lamsa_hp_ref *ref, 
             if (g_emu_lane_dp || g_emu_wave_jobs) {
                 for (int b = 0; b < PH_NBUCKET; ++b)
                     for (int i = 0; i < ctl.bucket_n[round][b]; ++i) phase_filllist(p, round, bq[((size_t)round * PH_NBUCKET + b) * p.unit_cap + i], 0, lds);
-                int nw = 0;
-                for (int b = 0; b < WJ_NBUCKET; ++b) nw += ctl.wj_bucket_n[round][b] < p.wj_cap ? ctl.wj_bucket_n[round][b] : p.wj_cap;
-                for (int g = 0; g < nw; ++g) phase_wavejob(p, round, g, 0, lds_wj);
+                int nw = 0, nwb = 0;
+                for (int b = 0; b < WJ_NBUCKET; ++b) { const int k = ctl.wj_bucket_n[round][b] < p.wj_cap ? ctl.wj_bucket_n[round][b] : p.wj_cap; if (b < WJ_NBIG) nwb += k; else nw += k; }
+                for (int g = 0; g < nwb; ++g) { phase_wavejob(p, round, g, true, 0, lds_wj); ++g_emu_stat[23]; }      // the jobs that need a big slab
+                for (int g = 0; g < nw; ++g) phase_wavejob(p, round, g, false, 0, lds_wj);
                 for (int b = 0; b < LJ_NBUCKET; ++b)
                     for (int off = 0; off < (ctl.lj_bucket_n[round][b] < p.lj_cap ? ctl.lj_bucket_n[round][b] : p.lj_cap); off += 64) phase_filldp(p, round, b, off, 0, lds_lj, HP_LJ_QSMALL);
             }
