@@ -465,7 +465,7 @@ def reference_binary_baseline(B, ref, wl, threads, seconds):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=None):
+def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=None, prebuilt=None):
     """The reference's DEFAULT run -- no -R 0: stage 4, the BWT rescue of unaligned read parts (src/bwt_aln.c:398-409), searches the FM
     index -- against the product binary's, on files: a stand-in of ref_bp bases with the bench's repeat families, its .bwt / .sa built here by
     the product's own `lamsa index --from-pac`, n_reads simulated reads of the workload with their seed hits as GEM map text.  Returns the
@@ -487,14 +487,17 @@ def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=Non
     d = keep or tempfile.mkdtemp(prefix="lamsa_dflt_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
         t0 = time.perf_counter()
-        ref = simbatch.SimRef(ref_bp, n_contigs=12, seed=17, threads=min(threads, 32))
+        if prebuilt:                                        # (tools/default_run.py: one stand-in and one index for every workload)
+            ref, t_index = prebuilt
+        else:
+            ref = simbatch.SimRef(ref_bp, n_contigs=12, seed=17, threads=min(threads, 32))
+            simfiles.write_index(d + "/ref.fa", ref)
+            t1 = time.perf_counter()
+            q = subprocess.run([exe, "index", "--from-pac", d + "/ref.fa"], capture_output=True, text=True, timeout=1500, env=dict(os.environ, LAMSA_INDEX_THREADS=str(min(threads, 64))))
+            if q.returncode != 0:
+                return {"error": "lamsa index --from-pac failed: " + q.stderr[-300:]}
+            t_index = time.perf_counter() - t1
         B = simbatch.SimBatch(ref, n_reads, wl["length"], wl["profile"], seed=23, threads=min(threads, 32))
-        simfiles.write_index(d + "/ref.fa", ref)
-        t1 = time.perf_counter()
-        q = subprocess.run([exe, "index", "--from-pac", d + "/ref.fa"], capture_output=True, text=True, timeout=1500, env=dict(os.environ, LAMSA_INDEX_THREADS=str(min(threads, 64))))
-        if q.returncode != 0:
-            return {"error": "lamsa index --from-pac failed: " + q.stderr[-300:]}
-        t_index = time.perf_counter() - t1
         simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"], workers=min(threads, 32))
         with open(d + "/reads.fa.seed.info", "w") as f:
             for r in range(n_reads):

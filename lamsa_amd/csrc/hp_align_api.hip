@@ -136,20 +136,14 @@ __global__ __launch_bounds__(64, HP_WJ_WAVES_PER_SIMD) void k_filldp_wave(const 
     int n = 0, n_big = 0;
     for (int b = 0; b < WJ_NBUCKET; ++b) { const int k = a.ctl->wj_bucket_n[round][b] < a.wj_cap ? a.ctl->wj_bucket_n[round][b] : a.wj_cap; if (b < WJ_NBIG) n_big += k; else n += k; }
     n = wv::uni(n); n_big = wv::uni(n_big);
-    if ((int)blockIdx.x < a.n_wjb)                      // this wave owns a big slab: the jobs that need one first (they are the costliest)
-        for (;;) {
-            int g = 0;
-            if (wv::leader()) g = atomicAdd(&a.ctl->q_head[8], 1);
-            g = wv::uni(g);
-            if (g >= n_big) break;
-            phase_wavejob(a, round, g, true, blockIdx.x, (HP_L int32_t *)lds);
-        }
+    bool own_big = (int)blockIdx.x < a.n_wjb;           // this wave owns a big slab: the jobs that need one first (they are the costliest)
     for (;;) {
         int g = 0;
-        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[7], 1);
+        const bool big = own_big;
+        if (wv::leader()) g = atomicAdd(&a.ctl->q_head[big ? 8 : 7], 1);
         g = wv::uni(g);
-        if (g >= n) break;
-        phase_wavejob(a, round, g, false, blockIdx.x, (HP_L int32_t *)lds);
+        if (g >= (big ? n_big : n)) { if (!big) break; own_big = false; continue; }
+        phase_wavejob(a, round, g, big, blockIdx.x, (HP_L int32_t *)lds);
     }
 }
 __global__ __launch_bounds__(64) void k_publish(const PhaseArgs *ap)
@@ -555,8 +549,9 @@ static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared 
     // direction matrix of the longest end extension (the whole read long) lives in one of the big slabs that only the first waves own.
     Q.chain = al256(((size_t)256 << 10) + 128 * (size_t)max_L + 424 * (size_t)max_H);
     Q.fill = al256(((size_t)256 << 10) + 128 * (size_t)max_L + sizeof(cig_t) * 3 * HP_LJ_CIG * 64 + (size_t)HP_LJ_QSMALL * HP_LJ_TSMALL * 64 + 64);
-    Q.wj = (size_t)1 << 20;
-    Q.wjb = al256((size_t)wj_need(&P, WJ_HEAD, max_L, max_L + 2 * P.hash_step + 64) + ((size_t)64 << 10));
+    { static const int kb = getenv("LAMSA_HP_WJ_SLAB_KB") ? atoi(getenv("LAMSA_HP_WJ_SLAB_KB")) : 0;    // diagnostic
+      Q.wj = ((size_t)(kb > 0 ? kb : 1024) << 10) + 33 * 256; }
+    Q.wjb = al256((size_t)wj_need(&P, WJ_HEAD, max_L, max_L + 2 * P.hash_step + 64) + ((size_t)64 << 10)) + 33 * 256;
     if (Q.wjb < Q.wj) Q.wjb = Q.wj;
     if (g_nowave) Q.fill = std::max(Q.fill, slab_bytes_for(P, max_L, max_H, 1));            // (diagnostics: the fill runs every DP itself)
     if (h->scratch_limit) { const size_t lim = al256(h->scratch_limit); Q.chain = std::min(Q.chain, lim); Q.fill = std::min(Q.fill, lim); Q.wj = std::min(Q.wj, lim); Q.wjb = std::min(Q.wjb, lim); }

@@ -44,19 +44,24 @@ struct UnitRec {                 // one line to fill
 
 enum { PH_NBUCKET = 8, PH_REG_WORDS = 10 };
 
-struct PhaseCtl {                // counters of one launch sequence, zeroed before chain1
-    int32_t q_head[12];          // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish, 5 listing, 6 lane DP, 7 wave DP, 8 wave DP (jobs that need a big slab)
-    int32_t n_units[2];          // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
+// Laid out by 128-byte lines: a line that thousands of waves update with atomics must not also hold words the same waves READ once per
+// job -- every such read then queues behind the atomics in the one L2 channel that owns the line.  (Round 4: wj_bytes / wj_cells shared a
+// line with half of wj_bucket_n and the wave-per-job launch took 151 ms instead of 64.)
+struct alignas(128) PhaseCtl {   // counters of one launch sequence, zeroed before chain1
+    alignas(128) int32_t q_head[12];   // queue heads: 0 chain1, 1 fill(round 1), 2 chain2, 3 fill(round 2), 4 publish, 5 listing, 6 lane DP, 7 wave DP, 8 wave DP (jobs that need a big slab)
+    alignas(128) int32_t n_units[2];   // fill units reserved by chain1 / chain2 (may exceed unit_cap: the excess is flagged, not stored)
     int32_t bucket_n[2][PH_NBUCKET];
-    unsigned long long fl_cursor, line_cursor, job_cursor;
-    int32_t lj_n[2], lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (kind x query-length class; LJ_NBUCKET <= 24)
-    int32_t wj_n[2], wj_bucket_n[2][WJ_NBUCKET];      // wave-per-job DP (hp_wavejob.h): jobs listed per round, and per cost class
-    unsigned long long wj_bytes;                       // algorithmic bytes of the wave-per-job launches: query bases + 2-bit target bases read, CIGAR words + slots written
-    unsigned long long wj_cells;                       // DP cells they updated
+    alignas(128) unsigned long long fl_cursor;
+    alignas(128) unsigned long long line_cursor;
+    alignas(128) unsigned long long job_cursor;
+    alignas(128) int32_t lj_n[2]; int32_t lj_bucket_n[2][24];   // lane-per-job DP: jobs listed per round, and per queue (kind x query-length class; LJ_NBUCKET <= 24)
+    alignas(128) int32_t wj_n[2]; int32_t wj_bucket_n[2][WJ_NBUCKET];      // wave-per-job DP (hp_wavejob.h): jobs listed per round, and per cost class
+    alignas(128) unsigned long long wj_bytes;          // algorithmic bytes of the wave-per-job launches: query bases + 2-bit target bases read, CIGAR words + slots written
+    alignas(128) unsigned long long wj_cells;          // DP cells they updated
     // when the first and the last wave of each of the four long launches found its queue empty (wall clock, 100 MHz; the first
     // one stored complemented so that zero-initialised words work with atomicMax): last - first is the time a launch spends
     // draining, i.e. with idle wave slots
-    unsigned long long t_first_inv[4], t_last[4];
+    alignas(128) unsigned long long t_first_inv[4], t_last[4];
 };
 
 struct LjRec;
@@ -435,7 +440,6 @@ HP_NOINL void phase_filllist(const PhaseArgs &a, int round, int u, int wave_slot
         }
 #pragma unroll
         for (int b = 0; b < LJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = ty[l] != 0 && !(ty[l] & 16) && lj_bucket_of(ty[l], ql[l]) == b; n_lb[b] += __builtin_popcountll(wv::ballot(inb)); }
-#pragma unroll
         { wv::Lane<int> wb; WAVE_FOR(l) wb[l] = (ty[l] & 16) ? wj_bucket_of(P, ty[l] & 15, ql[l], tl[l], wj_need(P, ty[l] & 15, ql[l], tl[l]) > (long long)a.slab_wj) : -1;
 #pragma unroll
           for (int b = 0; b < WJ_NBUCKET; ++b) { wv::Lane<int> inb; WAVE_FOR(l) inb[l] = wb[l] == b; n_wb[b] += __builtin_popcountll(wv::ballot(inb)); } }
@@ -592,7 +596,12 @@ HP_INL void phase_filldp(const PhaseArgs &a, int round, int bucket, int off, int
 }
 
 // job `g` of the round's wave-job queues b0 .. b1 - 1, costliest class first (hp_wavejob.h); big: the jobs that need a big slab (this wave owns one)
-HP_NOINL void phase_wavejob(const PhaseArgs &a, int round, int g, bool big, int wave_slot, HP_L int32_t *lds)
+#ifdef HP_WJ_NOINL
+HP_NOINL
+#else
+HP_INL
+#endif
+void phase_wavejob(const PhaseArgs &a, int round, int g, bool big, int wave_slot, HP_L int32_t *lds)
 {
     const int b1 = big ? WJ_NBIG : WJ_NBUCKET;
     int b = big ? 0 : WJ_NBIG;
