@@ -143,6 +143,7 @@ def main():
                     "and one batch holds at most 2^31 seed CIGAR words (~ 125 k reads of this kind)")
     ap.add_argument("--ref-bp", type=int, default=3_100_000_000, help="size of the reference stand-in")
     ap.add_argument("--threads", type=int, default=0, help="host threads for input generation and the CPU baseline (0 = every core of the box, os.cpu_count())")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="diagnostic: delay between the first two queued steps of a run")
     ap.add_argument("--sequential", action="store_true", help="wait for every step before starting the next (default: consecutive steps are queued two deep)")
     ap.add_argument("--stream-chunks", type=int, default=16, help="chunks pushed through the streaming boundary for the PCIe-inclusive rate, after the timed region (0: skip; "
                     "profiles use 0 so that every k_align_batch dispatch of the run is a resident-batch step)")
@@ -218,6 +219,8 @@ def main():
                 note()
             return ms, raw
         h.start_uploaded()
+        if a.stagger_ms > 0:
+            time.sleep(a.stagger_ms / 1000.0)           # diagnostic: the second batch enters the pipeline this much later than the first
         for _ in range(k - 1):
             h.start_uploaded()
             raw = h.finish_uploaded(fetch=True, raw=True)

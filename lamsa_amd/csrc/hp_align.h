@@ -108,7 +108,7 @@ HP_NOINL void fill_round(ReadCtx &r, FLines &F, OutBuf &o, Regs *G, int reg_cap,
 // ---- one read's view of the batch (hp_batch.h) and its scratch ----
 HP_INL void read_bind(ReadCtx &r, const lamsa_hp_para &P, const RefView &ref, const BatchIn &in, int rd, char *slab, size_t slab_bytes, HP_L int32_t *lds, long long *prof, int lds_words = HP_BOTH_LDS_WORDS)
 {
-    r.cx.P = &P; r.cx.status = 0; r.cx.n_cells = 0; r.cx.lds_epoch = 0; r.n_pairs = 0; r.cx.lds = lds; r.cx.lds_words = lds_words; r.cx.prof = prof ? prof + (size_t)rd * 64 : nullptr;
+    r.cx.P = &P; r.cx.status = 0; r.cx.n_cells = 0; r.cx.lds_epoch = 0; r.cx.prof_dp = nullptr; r.n_pairs = 0; r.cx.lds = lds; r.cx.lds_words = lds_words; r.cx.prof = prof ? prof + (size_t)rd * 64 : nullptr;
     arena_init(r.cx.tmp, slab, slab_bytes);
     r.ref = ref;
     r.L = (int)(in.read_off[rd + 1] - in.read_off[rd]);

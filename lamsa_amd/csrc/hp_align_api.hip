@@ -42,9 +42,17 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
 #ifndef HP_FILL_WAVES_PER_SIMD
 #define HP_FILL_WAVES_PER_SIMD 7          // round 4, the fill without its DPs (profiles/r04_overlap.txt; ms of k_fill, ont10k): 8 waves per SIMD (64 VGPRs) 44.6, 7 (72) 34.2, 6 (80) 34.7, 5 (96) 40.8, 4 (128) 41.3 --
 #endif                                    // with 64 registers the append loop of frags_merge reloads spilled values behind its own stores (loads and stores share vmcnt on gfx9: a reload waits for every store before it)
+// The chaining, listing and fill launches wait on memory most of the time (74-89 % of wave cycles) and issue little; the DP launches saturate
+// the vector port.  When the launches of two batches share a CU the arbiter would otherwise hand out issue slots evenly and stretch every
+// dependent step of the latency-bound waves: they run at raised priority, the DP waves take the slots they leave.
+#ifndef HP_PRIO
+#define HP_PRIO 3
+#endif
+#define HP_LATENCY_PRIO() __builtin_amdgcn_s_setprio(HP_PRIO)
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;        // in device memory: scalar loads, no private copy of the argument block
+    HP_LATENCY_PRIO();
     __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];      // the hit sort's blocks (hp_sort.h), then the node state of one cluster at a time (hp_cluster.h)
     for (;;) {
         int u = 0;
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const Ph
 __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain2(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;
+    HP_LATENCY_PRIO();
     __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];
     for (;;) {
         int u = 0;
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain2(const Ph
 __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
+    HP_LATENCY_PRIO();
     __shared__ int32_t lds[HP_LDS_WORDS];            // this wave's DP rows, query window and direction matrix (hp_ksw.h)
     int n = 0;
     for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const Phase
 __global__ __launch_bounds__(64, HP_LIST_WAVES_PER_SIMD) void k_filllist(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
+    HP_LATENCY_PRIO();
     int n = 0;
     for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
     n = wv::uni(n);
@@ -502,6 +513,13 @@ static void prof_report(Slot &T, const long long *d_prof, int n)
           fprintf(stderr, "[HP_PROF] query <= 62: ksw_extend %lld Mcyc %lld calls, ksw_global %lld Mcyc %lld calls\n", sum[60] / 1000000, sum[61], sum[62] / 1000000, sum[63]);
           const char *bn[] = {"[bi_extend total]", "[bi_extend after left ext]", "17-32", "33-64", "65-128", "129-256", "257-512", ">512"};
           for (int k = 0; k < 2; ++k) fprintf(stderr, "[HP_PROF] ksw_extend qlen %-8s %8lld Mcyc %10lld calls\n", bn[k], sum[48 + 2 * k] / 1000000, sum[49 + 2 * k]); }
+        {   // the wave-per-job launch's ksw_extend calls by routine (second half of the buffer)
+            std::vector<long long> pd((size_t)n * 64);
+            hipMemcpy(pd.data(), d_prof + ((size_t)n + 1) * 64, sizeof(long long) * pd.size(), hipMemcpyDeviceToHost);
+            long long sd[64] = {0}; for (int r = 0; r < n; ++r) for (int k = 0; k < 64; ++k) sd[k] += pd[(size_t)r * 64 + k];
+            const char *cn[] = {"one set, q <= 62", "packed, one set", "packed, two sets", "band 1 set", "band 2 sets", "band 4 sets", "int32 sets", "LDS / HBM rows"};
+            for (int c = 0; c < 8; ++c) fprintf(stderr, "[HP_PROF] wave jobs, ksw_extend %-18s %8lld Mcyc %10lld Mcells %9lld calls %10lld rows\n", cn[c], sd[4 * c] / 1000000, sd[4 * c + 1] / 1000000, sd[4 * c + 2], sd[4 * c + 3]);
+        }
         for (int q = 0; q < 8 && q < n; ++q) { int r = idx[q]; fprintf(stderr, "[HP_PROF] read %d L=%d:", r, T.h_len[r]); for (int k = 0; k < 11; ++k) fprintf(stderr, " %lld", pr[(size_t)r * 64 + k] / 1000000); fprintf(stderr, " | o_l %lld H %lld | targets %lld trips %lld init_Mcyc %lld\n", pr[(size_t)r * 64 + 14], pr[(size_t)r * 64 + 15], pr[(size_t)r * 64 + 11], pr[(size_t)r * 64 + 12], pr[(size_t)r * 64 + 13] / 1000000); }
     }
 }
@@ -599,9 +617,9 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     a.slab = (char *)Ln.slab.p; a.slab_per_wave = Q.chain; a.slab_fill = Q.fill; a.slab_wj = Q.wj; a.slab_wjb = Q.wjb; a.wjb_off = Q.wjb_off; a.n_wjb = Q.n_wjb; a.sort_pb = T.sort_pb; a.sort_cb = T.sort_cb;
     a.order = T.d_order; a.n_reads = n; a.prof = nullptr;
 #ifdef HP_PROF
-    if (Ln.prof.ensure(sizeof(long long) * 64 * ((size_t)n + 1))) { h->err = "hipMalloc(prof)"; return LAMSA_HP_ENOMEM; }
+    if (Ln.prof.ensure(sizeof(long long) * 64 * 2 * ((size_t)n + 1))) { h->err = "hipMalloc(prof)"; return LAMSA_HP_ENOMEM; }
     a.prof = (long long *)Ln.prof.p;
-    HIPCHK(h, hipMemsetAsync(Ln.prof.p, 0, sizeof(long long) * 64 * ((size_t)n + 1), Ln.cs), LAMSA_HP_EKERNEL);
+    HIPCHK(h, hipMemsetAsync(Ln.prof.p, 0, sizeof(long long) * 64 * 2 * ((size_t)n + 1), Ln.cs), LAMSA_HP_EKERNEL);
 #endif
     a.g_nd = (NodeS *)(d + o_nd); a.g_nseed = (int32_t *)(d + o_ns); a.g_sidx = (int32_t *)(d + o_sx); a.meta = (RdMeta *)(d + o_meta);
     a.units = (UnitRec *)(d + o_un); a.unit_cap = unit_cap; a.bucket_q = (int32_t *)(d + o_bq);

@@ -51,6 +51,7 @@ struct Ctx {
     int status;               // ST_* bits for the unit (read / job) being processed
     long long n_cells;        // DP cells updated (accounting: GCUPS)
     long long *prof;          // per-read cycle counters of diagnostic builds (-DHP_PROF), else nullptr
+    long long *prof_dp = nullptr;   // -DHP_PROF, wave-per-job launch only: per-routine cycle / cell counters of ksw_extend (else nullptr)
     int lds_epoch;            // bumped by every DP routine that writes the rows' part of the LDS (hp_ksw.h): what a caller parked there (frags_merge's staged CIGARs) is gone
 };
 // -DHP_PROF_FILL: slots 16 .. 23 time parts of frags_merge (hp_fill.h) instead of parts of the chaining (hp_chain.h, hp_gaps.h)

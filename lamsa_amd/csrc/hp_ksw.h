@@ -908,277 +908,14 @@ HP_NOINL ExtRes ksw_extend_regn(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     return er;
 }
 
-// ksw_extend_core with TWO columns per lane, scores as int16 pairs (packed math, wave.h pk::): column j of the reference's eh[] array is
-// half (j & 1) of lane ((j >> 1) & 63) of register set (j >> 7).  Everything a row does per register set -- the F scan, the reductions,
-// the ballots of the band logic, the store of the direction cells -- serves 128 columns instead of 64, and a cell costs half a packed
-// instruction where it cost a whole one: a row of a 100-base junction is ~200 instructions instead of ~400 (ksw_extend_regn<2>).  The
-// fill kernel is bound by instruction issue (VALU 68 %, scalar 60 % busy: profiles/r03_fill_issue.txt), so that is time.
-// Comparisons become sign bits of differences; every quantity is a sum of a few scores and penalties, and ksw_extend() only sends a job
-// here when none of them can leave +-16 000 (pk_extend_ok).  Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg.
-// The direction matrix is a nibble per cell in the wave's HBM slab, two cells per byte, a row = 64 * NS bytes indexed by the column.
+// Scores as int16 pairs (packed math, wave.h pk::): two cells per instruction.  Comparisons become sign bits of differences; every quantity
+// is a sum of a few scores and penalties, and a job only goes to a packed routine (ksw_extend_band, ksw_global_pk) when none of them can
+// leave the int16 range (pkb_extend_ok, pk_global_ok); the int32 register sets and the LDS rows stand behind them.
 #define HP_PK_QMAX(ns) (128 * (ns) - 2)
 #ifndef HP_PK_RT
-#define HP_PK_RT 1                          // the tests' CPU build switches the routine off to reach the int32 register sets behind it
+#define HP_PK_RT 1                          // the tests' CPU build switches the packed routines off to reach the int32 register sets behind them
 #endif
 #define HP_PK_IDENT (-16000)
-HP_INL bool pk_extend_ok(const lamsa_hp_para *P, int qlen, int h0)
-{
-    const int mx = P->match > P->mis ? P->match : P->mis;
-    const int pen = (P->ins_ext_o > P->del_ext_o ? P->ins_ext_o : P->del_ext_o) + (P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e);
-    const int ext = P->ins_ext_e > P->del_ext_e ? P->ins_ext_e : P->del_ext_e;
-    return mx > 0 && mx < 256 && pen >= 0 && pen < 4000 && P->ins_ext_e >= 0 && P->del_ext_e >= 0 && P->ins_ext_o >= 0 && P->del_ext_o >= 0 &&
-           (long long)h0 + (long long)qlen * mx < 15000 && (long long)(qlen + 2) * ext < 8000;
-}
-template <int NS>
-HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, CigV *out)
-{
-    long long cells_ = 0;                                                  // in a register: a counter in cx would be a memory round trip per row
-    ExtRes er; er.score = 0; er.qle = 0; er.tle = 0;
-    HP_T0(te0_);
-    qlen = wv::uni(qlen); tlen = wv::uni(tlen); w = wv::uni(w); h0 = wv::uni(h0);
-    const lamsa_hp_para *P = cx.P;
-    const int o_ins = wv::uni(P->ins_ext_o), e_ins = wv::uni(P->ins_ext_e), o_del = wv::uni(P->del_ext_o), e_del = wv::uni(P->del_ext_e);
-    const int end_bonus = wv::uni(P->end_bonus), zdrop = wv::uni(P->zdrop);
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    const int zs = 64 * NS;                                                // bytes of a row of the direction matrix
-    const size_t mark = arena_mark(cx.tmp);
-    // the matrix in LDS when the wave's share holds it (every byte of a row is written, 0xF = a cell outside the row's band); else in the
-    // slab with the band limits of every row beside it
-    const bool zl = (size_t)zs * (size_t)tlen <= z_cap_pk(cx);
-    if (zl) ++cx.lds_epoch;
-    uint8_t *z = zl ? nullptr : (uint8_t *)arena_alloc(cx, (size_t)zs * tlen + 1);
-    int32_t *rowb = zl ? nullptr : (int32_t *)arena_alloc(cx, sizeof(int32_t) * 2 * ((size_t)tlen + 1));
-    if (!zl && (!z || !rowb)) { arena_release(cx.tmp, mark); return er; }
-#ifdef HP_PROF
-    if (!zl && cx.prof) { cx.prof[52] += (long long)zs * tlen; cx.prof[53] += 1; }
-#endif
-    HP_L uint8_t *LZ = (HP_L uint8_t *)cx.lds;
-    HP_G uint8_t *gz = (HP_G uint8_t *)wv::uni64((long long)z);
-    HP_G int32_t *growb = (HP_G int32_t *)wv::uni64((long long)rowb);
-    const int sc_match = wv::uni(P->match), sc_mis = -wv::uni(P->mis);
-    const HP_G uint8_t *gq = (const HP_G uint8_t *)wv::uni64((long long)q.p); const int qs = wv::uni(q.stride);
-    const HP_G uint8_t *gt = (const HP_G uint8_t *)wv::uni64((long long)t.p); const int ts = wv::uni(t.stride);
-    const int h1v = h0 > oe_ins ? h0 - oe_ins : 0;
-    // packed constants (both halves the same value)
-    const int OEI = pk::rep(oe_ins), OED = pk::rep(oe_del), EI = pk::rep(e_ins), ED = pk::rep(e_del);
-    const int DSC = pk::rep(sc_match - sc_mis), MIS = pk::rep(sc_mis), IDENT = pk::rep(HP_PK_IDENT);
-    wv::Lane<int> Hs[NS], Es[NS], qoh[NS], qN[NS], hcur[NS], jp0, jep0, tl;
-    WAVE_FOR(l) { jp0[l] = pk::pack(2 * l, 2 * l + 1); jep0[l] = pk::pack(2 * l * e_ins, (2 * l + 1) * e_ins); tl[l] = 4; }
-#pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        WAVE_FOR(l) {                                                      // first row, :692-694
-            int hv[2], oh = 0, nn = 0;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int j = 128 * c + 2 * l + b;
-                hv[b] = j == 0 ? h0 : (j == 1 ? h1v : ((j <= qlen && h1v - (j - 2) * e_ins > e_ins) ? h1v - (j - 1) * e_ins : 0));
-                const int code = j < qlen ? (int)gq[(long)j * qs] : 4;
-                if (code < 4) oh |= 1 << (code + 16 * b); else nn |= (int)(0xffffu << (16 * b));
-            }
-            Hs[c][l] = pk::pack(hv[0], hv[1]); Es[c][l] = 0;
-            qoh[c][l] = oh; qN[c][l] = nn;                                 // the query base of a column as one bit of four; N (and beyond the query): score -1
-        }
-    }
-    int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1;
-    int beg = 0, end = qlen;
-    bool stop_rows = false;
-    for (int ib = 0; ib < tlen && !stop_rows; ib += 64) {
-        { WAVE_FOR(l) { const int ii = ib + l; tl[l] = ii < tlen ? gt[(long)ii * ts] : 4; } }
-        const int ti_first = wv::bcast(tl, 0);
-        const int ie = ib + 64 < tlen ? ib + 64 : tlen;
-        for (int i = ib; i < ie; ++i) {
-            const int ti = i == ib ? ti_first : wv::bcast(tl, i & 63);
-            if (beg < i - w) beg = i - w;                                  // :718-720
-            if (end > i + w + 1) end = i + w + 1;
-            if (end > qlen) end = qlen;
-            cells_ += end > beg ? end - beg : 0;
-            if (!zl) { WAVE_FOR(l) { if (l < 2) growb[2 * i + l] = l ? end : beg; } }
-            int h1_init;
-            if (beg == 0) { h1_init = h0 - (o_del + e_del * (i + 1)); if (h1_init < 0) h1_init = 0; }
-            else h1_init = 0;
-            const int tsh = ti & 3, tN = ti > 3 ? -1 : 0;                   // a target N scores -1 against everything
-            const int BEG = pk::rep(beg), END = pk::rep(end), FB = pk::rep(beg * e_ins), H1 = pk::rep(h1_init);
-            int carry = HP_PK_IDENT;                                       // maximum of the scan keys of the sets below
-            wv::Lane<int> inb[NS];
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                wv::Lane<int> key, klo, tI, M;
-                WAVE_FOR(l) {
-                    const int jp = pk::add(jp0[l], pk::rep(128 * c));
-                    inb[c][l] = pk::neg_mask(pk::sub(jp, END)) & ~pk::neg_mask(pk::sub(jp, BEG));      // beg <= j < end, per half
-                    const int eq = (qoh[c][l] >> tsh) & 0x00010001;
-                    const int S = pk::add(pk::mul(eq, DSC), MIS) | qN[c][l] | tN;                       // HP_SUB(ti, qb)
-                    const int hm = Hs[c][l];
-                    const int m = pk::mul(pk::add(hm, S), pk::min_u(hm, 0x00010001));                   // hm ? hm + S : 0   (:737; hm is never negative)
-                    const int t1 = pk::max(pk::sub(m, OEI), 0);
-                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
-                    const int k = pk::sel(inb[c][l], pk::add(t1, jep), IDENT);
-                    M[l] = m; tI[l] = t1;
-                    klo[l] = pk::lo(k);
-                    const int kh = pk::hi(k);
-                    key[l] = klo[l] > kh ? klo[l] : kh;
-                }
-                // F along the row: an exclusive prefix maximum over the columns = the scan over the lanes' maxima, the second column of a
-                // lane topped up with the first, every set with the maximum of the sets before it
-                const int top = wv::scan_max_excl_top(key, HP_PK_IDENT);
-                WAVE_FOR(l) {
-                    const int jep = pk::add(jep0[l], pk::rep(128 * c * e_ins));
-                    const int s0 = key[l] > carry ? key[l] : carry, s1 = s0 > klo[l] ? s0 : klo[l];
-                    const int pre = pk::pack(s0, s1);
-                    int f = pk::max(pk::add(pk::sub(pre, jep), EI), pk::sub(FB, jep));                   // F(i,beg) = 0 carried along the row
-                    const int m = M[l];
-                    int ee = Es[c][l];
-                    const int m1 = pk::neg_mask(pk::sub(ee, m));                                        // M > E
-                    int h = pk::max(m, ee);                                                             // ties: E over M   :738-739
-                    const int m2 = pk::neg_mask(pk::sub(f, h));                                         // h > F
-                    int d = pk::sel(m2, ~m1 & 0x00010001, 0x00020002);                                  //       F over both :740-741
-                    h = pk::max(h, f);
-                    const int tD = pk::max(pk::sub(m, OED), 0);
-                    ee = pk::sub(ee, ED);
-                    d |= pk::neg_mask(pk::sub(tD, ee)) & 0x00040004;                                    // E extends, :745-750
-                    ee = pk::max(ee, tD);
-                    f = pk::sub(f, EI);
-                    d |= pk::neg_mask(pk::sub(tI[l], f)) & 0x00080008;                                  // F extends, :751-755
-                    const int in = inb[c][l];
-                    Es[c][l] = pk::sel(in, ee, Es[c][l]);
-                    hcur[c][l] = pk::sel(in, h, -1);
-                    if (zl) { const int dn = pk::sel(in, d, 0x000f000f); LZ[i * zs + 64 * c + l] = (uint8_t)((dn | (dn >> 12)) & 0xff); }
-                    else if (in) gz[(long)i * zs + 64 * c + l] = (uint8_t)((d | (d >> 12)) & 0xff);
-                }
-                carry = top > carry ? top : carry;
-            }
-            // row maximum, last j among equals (:743-744)
-            int mrow = 0, mj = -1;
-            {
-                wv::Lane<int> hm;
-                WAVE_FOR(l) {
-                    int v = -1;
-#pragma unroll
-                    for (int c = 0; c < NS; ++c) { const int a = pk::lo(hcur[c][l]), b = pk::hi(hcur[c][l]); v = a > v ? a : v; v = b > v ? b : v; }
-                    hm[l] = v;
-                }
-                const int hmax = wv::reduce_max(hm);
-                if (hmax >= 0) {
-                    mrow = hmax;
-                    bool got = false;
-#pragma unroll
-                    for (int c = NS - 1; c >= 0; --c) {
-                        if (got) continue;
-                        wv::Lane<int> e0, e1;
-                        WAVE_FOR(l) { e0[l] = pk::lo(hcur[c][l]) == hmax; e1[l] = pk::hi(hcur[c][l]) == hmax; }
-                        const unsigned long long b0 = wv::ballot(e0), b1 = wv::ballot(e1);
-                        if (b0 | b1) {
-                            const int j0 = b0 ? 2 * (63 - __builtin_clzll(b0)) : -1, j1 = b1 ? 2 * (63 - __builtin_clzll(b1)) + 1 : -1;
-                            mj = 128 * c + (j0 > j1 ? j0 : j1); got = true;
-                        }
-                    }
-                }
-            }
-            int h_last = h1_init;                                          // H(i,end-1), or the first-column value when the row is empty
-            if (beg < end) {
-#pragma unroll
-                for (int c = 0; c < NS; ++c) if (((end - 1) >> 7) == c) { const int v = wv::bcast(hcur[c], ((end - 1) >> 1) & 63); h_last = ((end - 1) & 1) ? pk::hi(v) : pk::lo(v); }
-            }
-            // eh[j+1].h = H(i,j): the row one column up, across halves, lanes and sets; columns the row did not compute arrive as -1
-            unsigned long long nz0[NS], nz1[NS];
-#pragma unroll
-            for (int c = NS - 1; c >= 0; --c) {
-                const int below = c > 0 ? wv::bcast(hcur[c > 0 ? c - 1 : 0], 63) : -1;
-                wv::Lane<int> dn = hcur[c];
-                wv::shr1(dn, below);
-                wv::Lane<int> z0, z1;
-                WAVE_FOR(l) {
-                    const int hsh = pk::shift_up(hcur[c][l], dn[l]);
-                    const int in = inb[c][l];
-                    int hs = Hs[c][l], es = Es[c][l];
-                    if (beg < end) {
-                        const int upd = ~pk::neg_mask(hsh);                // beg < j <= end
-                        hs = pk::sel(upd, hsh, hs);
-                        hs = pk::sel(in & ~upd, H1, hs);                   // j == beg
-                        es &= ~(upd & ~in);                                // eh[end].e = 0, :758
-                        const int live = (hs | es) & (in | upd);
-                        z0[l] = (live & 0xffff) != 0; z1[l] = ((unsigned)live >> 16) != 0;
-                    } else {                                               // the row is empty: eh[end].h = h1, eh[end].e = 0 (:758)
-                        const int jp = pk::add(jp0[l], pk::rep(128 * c));
-                        const int at = ~(pk::neg_mask(pk::sub(jp, END)) | pk::neg_mask(pk::sub(END, jp)));      // j == end
-                        hs = pk::sel(at, H1, hs); es &= ~at;
-                        const int live = (hs | es) & at;
-                        z0[l] = (live & 0xffff) != 0; z1[l] = ((unsigned)live >> 16) != 0;
-                    }
-                    Hs[c][l] = hs; Es[c][l] = es;
-                }
-                nz0[c] = wv::ballot(z0); nz1[c] = wv::ballot(z1);          // eh[j] not zero, for j in [beg, end]: even columns, odd columns
-            }
-            const int jj = beg < end ? end : beg;                          // loop variable j after the row
-            if (jj == qlen) {                                              // :759-762
-                max_ie = gscore > h_last ? max_ie : i;
-                gscore = gscore > h_last ? gscore : h_last;
-            }
-            if (mrow == 0) { stop_rows = true; break; }                    // :763
-            if (mrow > max) { max = mrow; max_i = i; max_j = mj; }
-            else if (zdrop > 0) {                                          // :767-773
-                if (i - max_i > mj - max_j) { if (max - mrow - ((i - max_i) - (mj - max_j)) * e_del > zdrop) { stop_rows = true; break; } }
-                else { if (max - mrow - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) { stop_rows = true; break; } }
-            }
-            // shrink the band for the next row, :775-778
-            if constexpr (NS == 1) {
-                // One register set: the ballots hold eh[j] != 0 for j in [beg, end] only, so "the first one below end" is the first one once
-                // index `end` is set aside, and "the last one from there on" is the last one of all -- no range masks.
-                const unsigned long long e_bit = 1ull << ((end >> 1) & 63);
-                const bool end_nz = ((end & 1) ? nz1[0] : nz0[0]) & e_bit;
-                const unsigned long long l0 = (end & 1) ? nz0[0] : nz0[0] & ~e_bit, l1 = (end & 1) ? nz1[0] & ~e_bit : nz1[0];
-                int nb, jl;
-                if (l0 | l1) {
-                    const int a0 = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b0 = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
-                    nb = a0 < b0 ? a0 : b0;
-                    const int a1 = nz0[0] ? 2 * (63 - __builtin_clzll(nz0[0])) : -1, b1 = nz1[0] ? 2 * (63 - __builtin_clzll(nz1[0])) + 1 : -1;
-                    jl = a1 > b1 ? a1 : b1;
-                } else { nb = end; jl = end_nz ? end : end - 1; }
-                beg = nb;
-                end = jl + 2 < qlen ? jl + 2 : qlen;
-            } else
-            {
-                // several sets: the same two facts set by set (the ballots hold eh[j] != 0 for j in [beg, end] only)
-                const int e_set = end >> 7;
-                const unsigned long long e_bit = 1ull << ((end >> 1) & 63);
-                bool end_nz = false;
-                int nb = end, jl = -1;
-                bool got = false;
-#pragma unroll
-                for (int c = 0; c < NS; ++c) {
-                    unsigned long long l0 = nz0[c], l1 = nz1[c];
-                    if (c == e_set) { if (end & 1) { end_nz = l1 & e_bit; l1 &= ~e_bit; } else { end_nz = l0 & e_bit; l0 &= ~e_bit; } }
-                    if (!got && (l0 | l1)) {
-                        const int a0 = l0 ? 2 * __builtin_ctzll(l0) : 1 << 20, b0 = l1 ? 2 * __builtin_ctzll(l1) + 1 : 1 << 20;
-                        nb = 128 * c + (a0 < b0 ? a0 : b0); got = true;
-                    }
-                }
-                if (got) {
-                    bool gl = false;
-#pragma unroll
-                    for (int c = NS - 1; c >= 0; --c) {
-                        if (!gl && (nz0[c] | nz1[c])) {
-                            const int a1 = nz0[c] ? 2 * (63 - __builtin_clzll(nz0[c])) : -1, b1 = nz1[c] ? 2 * (63 - __builtin_clzll(nz1[c])) + 1 : -1;
-                            jl = 128 * c + (a1 > b1 ? a1 : b1); gl = true;
-                        }
-                    }
-                } else jl = end_nz ? end : end - 1;
-                beg = nb;
-                end = jl + 2 < qlen ? jl + 2 : qlen;
-            }
-        }
-    }
-    int i, k;
-    if (gscore <= 0 || gscore <= max - end_bonus) { i = max_i; k = max_j; }   // :785-789
-    else { i = max_ie; k = qlen - 1; }
-    er.qle = k + 1; er.tle = i + 1; er.score = max;
-    if (out) { wv::sync(); HP_T0(tb0_); dp_backtrack(cx, zl ? LZ : nullptr, z, rowb, n_col, w, i, k, *out, zs); HP_TADD(cx, 28, tb0_); }
-    cx.n_cells += cells_;                                                  // accounting: DP cell updates (bench.py: GCUPS), once per call
-    arena_release(cx.tmp, mark);
-    HP_TADD(cx, 26, te0_);
-    return er;
-}
 
 // ksw_extend_core for LONG queries -- the end extensions of a line, up to the whole read (frag_head_bound_fix / frag_tail_bound_fix,
 // src/frag_check.c:576-707) -- with the row's live WINDOW in registers, int16 pairs, 2 * NS consecutive columns per lane.
@@ -1192,10 +929,16 @@ HP_NOINL ExtRes ksw_extend_pk(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, 
 // then one exclusive prefix maximum over the lanes' totals, in two halves because the window wraps round the wave), the row maximum
 // (one reduction of (H << 16 | column) keys: "last column among equals" is the larger key, :743-744), the one-column shift of H (inside
 // a lane but for one wave rotation), the first and last non-zero cell (:775-778: a ballot over the lanes, then two lanes' bit patterns).
-// Same recurrences, tie rules, band and z-drop logic as ksw_extend_pk; scores are bounded as there (pkb_extend_ok), the scan's keys use
+// Same recurrences, tie rules, band and z-drop logic as ksw_extend_reg; scores are bounded (pkb_extend_ok), the scan's keys use
 // columns relative to the row's first one.  The direction matrix is a nibble per cell in the wave's slab, a row = 64 * NS bytes indexed by
 // the slot, with the band limits of every row beside it.
-HP_INL int pkb_sets(int w) { return 2 * w + 3 + 18 <= 128 ? 1 : (2 * w + 3 + 36 <= 256 ? 2 : (2 * w + 3 + 72 <= 512 ? 4 : 0)); }      // window >= band + 2 + the eight lanes being refilled + one lane of slack
+// sets for a query of qlen columns under band w: the window holds the band + 2 + the eight lanes being refilled + one lane of slack -- or the
+// whole query, and then never moves
+HP_INL int pkb_sets_q(int qlen, int w)
+{
+    for (int ns = 1; ns <= 4; ns *= 2) if (2 * w + 3 + 18 * ns <= 128 * ns || qlen + 3 <= 128 * ns) return ns;
+    return 0;
+}
 HP_INL bool pkb_extend_ok(const lamsa_hp_para *P, int qlen, int h0, int ns)
 {
     const int mx = P->match > P->mis ? P->match : P->mis;
@@ -1413,7 +1156,7 @@ HP_NOINL ExtRes ksw_extend_band(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
     return er;
 }
 
-// ksw_global2 with two columns per lane, scores as int16 pairs: the layout and the row of ksw_extend_pk without the row maximum and the
+// ksw_global2 with two columns per lane, scores as int16 pairs: the layout of round 3's extension routine (column j = half j & 1 of lane (j >> 1) & 63 of register set j >> 7) without the row maximum and the
 // band logic.  MINUS_INF becomes -12 000 and the scan's identity -24 000: every cell is MINUS_INF or zero plus a sum of scores and
 // penalties that pk_global_ok keeps below 4 000 in size, so the three classes never meet and every comparison of the reference -- all
 // between sums of the same terms -- comes out as it does in 32 bits.
@@ -1763,18 +1506,24 @@ HP_INL int ksw_extend(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w, int h0, 
     }
     const long long cells0_ = cx.n_cells; (void)cells0_;
     ExtRes er;
+    int cls_ = 0; (void)cls_;          // diagnostic: which routine ran
+    HP_T0(tcls_);
     if (qlen <= HP_REG_QMAX) er = ksw_extend_reg(cx, qlen, q, tlen, t, w, h0, out);
-    else if (HP_PK_RT && qlen <= HP_PK_QMAX(2) && pk_extend_ok(cx.P, qlen, h0))
-        { HP_STAT(16); er = qlen <= HP_PK_QMAX(1) ? ksw_extend_pk<1>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_pk<2>(cx, qlen, q, tlen, t, w, h0, out); }
-    else if (HP_PK_RT && qlen > HP_PK_QMAX(2) && pkb_extend_ok(cx.P, qlen, h0, pkb_sets(w))) {
+    else if (HP_PK_RT && pkb_extend_ok(cx.P, qlen, h0, pkb_sets_q(qlen, w))) {
+        // every longer query: the window routine.  (Round 3's lane-per-column-pair routine for 63 .. 254 bases, ksw_extend_pk, cost more per row
+        // for half the columns -- 5.8 k wave cycles against 4.8 k -- and is gone: profiles/r04_dp_routines.txt.)
         HP_STAT(22);
-        const int ns = pkb_sets(w);
+        const int ns = pkb_sets_q(qlen, w);
+        cls_ = ns == 1 ? 3 : (ns == 2 ? 4 : 5);
         er = ns == 1 ? ksw_extend_band<1>(cx, qlen, q, tlen, t, w, h0, out) : (ns == 2 ? ksw_extend_band<2>(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_band<4>(cx, qlen, q, tlen, t, w, h0, out));
     }
-    else if (qlen <= HP_REGN_QMAX(2)) { HP_STAT(17); er = ksw_extend_regn<2>(cx, qlen, q, tlen, t, w, h0, out); }
-    else if (qlen <= HP_REGN_QMAX(3) && HP_REGN_SETS >= 3) { HP_STAT(17); er = ksw_extend_regn<3>(cx, qlen, q, tlen, t, w, h0, out); }
-    else if (qlen <= HP_REGN_QMAX(4) && HP_REGN_SETS >= 4) { HP_STAT(17); er = ksw_extend_regn<4>(cx, qlen, q, tlen, t, w, h0, out); }
-    else er = 2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out);
+    else if (qlen <= HP_REGN_QMAX(2)) { HP_STAT(17); cls_ = 6; er = ksw_extend_regn<2>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (qlen <= HP_REGN_QMAX(3) && HP_REGN_SETS >= 3) { HP_STAT(17); cls_ = 6; er = ksw_extend_regn<3>(cx, qlen, q, tlen, t, w, h0, out); }
+    else if (qlen <= HP_REGN_QMAX(4) && HP_REGN_SETS >= 4) { HP_STAT(17); cls_ = 6; er = ksw_extend_regn<4>(cx, qlen, q, tlen, t, w, h0, out); }
+    else { cls_ = 7; er = 2 * w + 4 + 64 <= HP_LDS_CELLS ? ksw_extend_lds(cx, qlen, q, tlen, t, w, h0, out) : ksw_extend_wide(cx, qlen, q, tlen, t, w, h0, out); }
+#ifdef HP_PROF
+    if (cx.prof_dp) { cx.prof_dp[4 * cls_] += wv::clock() - tcls_; cx.prof_dp[4 * cls_ + 1] += cx.n_cells - cells0_; cx.prof_dp[4 * cls_ + 2] += 1; cx.prof_dp[4 * cls_ + 3] += er.tle; }
+#endif
     HP_DPLOG(0, qlen, tlen, w, cx.n_cells - cells0_);
     if (qle) *qle = er.qle;
     if (tle) *tle = er.tle;

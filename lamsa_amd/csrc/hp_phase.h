@@ -615,6 +615,7 @@ void phase_wavejob(const PhaseArgs &a, int round, int g, bool big, int wave_slot
     if (*(volatile int32_t *)&a.meta[rd].status & ST_DEAD) return;
     Ctx cx;
     cx.P = &a.P; cx.lds = lds; cx.lds_words = HP_WJ_LDS_WORDS; cx.status = 0; cx.n_cells = 0; cx.lds_epoch = 0; cx.prof = a.prof ? a.prof + (size_t)rd * 64 : nullptr;
+    cx.prof_dp = a.prof ? a.prof + ((size_t)a.n_reads + 1 + rd) * 64 : nullptr;          // (the second half of the diagnostic buffer)
     if (big) arena_init(cx.tmp, a.slab + a.wjb_off + (size_t)wave_slot * a.slab_wjb, a.slab_wjb);
     else arena_init(cx.tmp, a.slab + (size_t)wave_slot * a.slab_wj, a.slab_wj);
     CigV out;

@@ -84,10 +84,10 @@ def test_emulated_extension_with_the_row_in_register_sets(rt):
     jobs = _mid_jobs(77 + len(rt), ERR[rt])
     for kind, w, h0 in ((1, lp.band_w, 50), (1, 5, 30), (1, 40, 7), (1, 70, 200), (1, 130, 90), (2, 0, 100), (2, 0, 12)):
         want = reflib.oracle_dp(jobs, lp, kind, w, h0)
-        for pk in (True, False):              # two columns per lane as int16 pairs (ksw_extend_pk<1 | 2>), then the int32 sets behind it
+        for pk in (True, False):              # the window of int16 pairs (ksw_extend_band<1 | 2>: the whole query fits it), then the int32 sets behind it
             st = []
             assert goldenlib.same_dp(want, reflib.emu_dp(jobs, P, kind, w, h0, pk=pk, stats=st), kind) == [], (kind, w, h0, pk)
-            assert (st[0] > 0 and st[1] == 0) if pk else (st[0] == 0 and st[1] > 0), st
+            assert (st[4] > 0 and st[1] == 0) if pk else (st[4] == 0 and st[1] > 0), st
     for w in (lp.band_w, 3, 40):              # ksw_global2 on the same jobs: ksw_global_pk<1 | 2>, then the LDS rows behind it
         want = reflib.oracle_dp(jobs, lp, 0, w, 0)
         for pk in (True, False):
@@ -97,14 +97,16 @@ def test_emulated_extension_with_the_row_in_register_sets(rt):
 
 
 def test_emulated_packed_extension_refuses_scores_beyond_int16():
-    """A start score that would take a cell past the int16 range sends the job to the int32 register sets (pk_extend_ok, hp_ksw.h)."""
+    """A start score that would take a cell past the int16 range sends the job to the int32 register sets (pkb_extend_ok, hp_ksw.h)."""
     lp, P = reflib.lo_para("ont2d"), hp_para_like("ont2d")
     jobs = _mid_jobs(5, ERR["ont2d"])[:40]
-    for h0, packed in ((14000, True), (14950, False), (30000, False), (1 << 20, False)):
+    mx = max(P.match, P.mis)
+    qmax = max(len(q) for q, _ in jobs)
+    for h0, packed in ((14000, True), (22990 - qmax * mx, True), (23000, False), (30000, False), (1 << 20, False)):
         st = []
         got = reflib.emu_dp(jobs, P, 1, lp.band_w, h0, stats=st)
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 1, lp.band_w, h0), got, 1) == [], h0
-        assert (st[0] > 0 and st[1] == 0) if packed else (st[0] == 0 and st[1] > 0), (h0, st)
+        assert (st[4] > 0 and st[1] == 0) if packed else (st[4] == 0 and st[1] > 0), (h0, st)
 
 
 def test_emulated_kernels_edge_cases():

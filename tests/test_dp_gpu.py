@@ -52,12 +52,12 @@ def test_hip_extension_with_the_row_in_register_sets(handles, rt):
 
 
 def test_hip_packed_extension_refuses_scores_beyond_int16(handles):
-    """Start scores around and beyond what the int16 pairs of ksw_extend_pk can hold (pk_extend_ok, hp_ksw.h): the jobs beyond it take the
+    """Start scores around and beyond what the int16 pairs of ksw_extend_band can hold (pkb_extend_ok, hp_ksw.h): the jobs beyond it take the
     int32 register sets -- same results as the oracle either way."""
     import test_dp_cpu
     lp = reflib.lo_para("ont2d")
     jobs = test_dp_cpu._mid_jobs(5, ERR["ont2d"])[:40]
-    for h0 in (14000, 14950, 30000, 1 << 20):
+    for h0 in (14000, 14950, 21500, 22400, 22990, 23000, 30000, 1 << 20):
         got = handles["ont2d"].dp_batch(jobs, 1, lp.band_w, h0)
         assert goldenlib.same_dp(reflib.oracle_dp(jobs, lp, 1, lp.band_w, h0), got, 1) == [], h0
 

@@ -12,13 +12,13 @@ except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
 }
-SEQ=--sequential
-run seq A=1
+V=$PWD/lamsa_amd/lib/var
 SEQ=
-run default A=1
-run full LAMSA_HP_FULL_GRIDS=1
-run c8_f14_w16 LAMSA_HP_CHAIN_PER_CU=8 LAMSA_HP_FILL_PER_CU=14 LAMSA_HP_WJ_PER_CU=16
-run c8_f20_w16 LAMSA_HP_CHAIN_PER_CU=8 LAMSA_HP_FILL_PER_CU=20 LAMSA_HP_WJ_PER_CU=16
-run c8_f12_w16 LAMSA_HP_CHAIN_PER_CU=8 LAMSA_HP_FILL_PER_CU=12 LAMSA_HP_WJ_PER_CU=16
-run c10_f16_w12 LAMSA_HP_CHAIN_PER_CU=10 LAMSA_HP_FILL_PER_CU=16 LAMSA_HP_WJ_PER_CU=12
-run c8_f16_w12 LAMSA_HP_CHAIN_PER_CU=8 LAMSA_HP_FILL_PER_CU=16 LAMSA_HP_WJ_PER_CU=12
+run prio0 LAMSA_HP_LIB=$V/liblamsa_hp_prio0.so
+run prio3 LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so
+run prio3_full LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so LAMSA_HP_FULL_GRIDS=1
+run prio3_c8_f16_w32 LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so LAMSA_HP_WJ_PER_CU=32
+run prio3_c12_f16_w8 LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so LAMSA_HP_CHAIN_PER_CU=12 LAMSA_HP_WJ_PER_CU=8
+run prio3_c8_f8_w16 LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so LAMSA_HP_FILL_PER_CU=8
+SEQ=--sequential
+run prio3_seq LAMSA_HP_LIB=$V/liblamsa_hp_prio3.so
