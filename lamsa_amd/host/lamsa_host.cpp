@@ -581,14 +581,15 @@ static void merge_batches(Batch &B, std::vector<Batch> &parts, int threads)
 // ------------------------------------------------------------------ result stream -> records
 void parse_stream(const int32_t *s, int n_words, int read_len, ReadResult &R)
 {
-    for (int st = 0; st < 3; ++st) R.stage[st].clear();
+    // (R may hold an earlier read's result: its lines, records and CIGAR vectors are reused, not freed and allocated again)
+    R.stage[2].clear();
     R.status = n_words > 0 ? s[0] : LAMSA_HP_ST_OVERFLOW;
-    if (n_words < 3 || R.status != 0) return;
+    if (n_words < 3 || R.status != 0) { R.stage[0].clear(); R.stage[1].clear(); return; }
     int i = 3;
     for (int st = 0; st < 2; ++st) {
         R.stage[st].resize((size_t)s[1 + st]);
         for (Line &ln : R.stage[st]) {
-            ln.line_score = s[i]; ln.tol_score = s[i + 1]; ln.tol_NM = s[i + 2];
+            ln.line_score = s[i]; ln.tol_score = s[i + 1]; ln.tol_NM = s[i + 2]; ln.merg_x = ln.merg_y = 0; ln.mapQ = 0; ln.xa.clear();
             const int n_res = s[i + 3]; i += 4;
             ln.rec.resize((size_t)n_res);
             for (Rec &r : ln.rec) {
@@ -1079,6 +1080,12 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             if (ch.cig_elem == 4) { hb.h_cig_off = (const int32_t *)take(4 * nh); hb.cig = (const int32_t *)take(4 * nc); hb.cig8 = nullptr; }
             else { hb.h_cig_off = nullptr; hb.cig = nullptr; hb.cig8 = (const uint8_t *)take(nc); }
             if ((size_t)(a - (hitsf.p + hitsf.pos + sizeof ch)) != (size_t)ch.bytes) { fprintf(stderr, "[lamsa_read_seq] damaged hit stream\n"); c->ret = 1; eof = true; return c; }
+            {   // The chunk's pages of the mapping, touched by all threads now: a page of a file mapping costs a fault the first time it is read, and the
+                // upload (one thread's copy into the runtime's page-locked staging buffers) otherwise pays 230 000 of them per chunk, one after the other.
+                const char *p0 = hitsf.p + hitsf.pos; const size_t np = (sizeof ch + (size_t)ch.bytes + 4095) / 4096;
+                static std::atomic<unsigned> sink(0);
+                parallel_blocks((int)np, threads, [&](int, int b0, int b1) { unsigned v = 0; for (int k = b0; k < b1; ++k) v += (unsigned char)p0[(size_t)k * 4096]; sink += v; });
+            }
             hitsf.pos += sizeof ch + (size_t)ch.bytes;
             if (fx.spans()) {                               // only where the records lie: they are parsed by all threads (prepare)
                 c->rspan.resize(n);
@@ -1222,13 +1229,21 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     // Everything after the GPU for one chunk: result streams -> records, stage (4) (rescue.h: plan on the host threads,
     // one DP batch on the GPU through the second handle, finish on the host threads), MAPQ / XA, SAM text in input order.
     // It runs as a task of its own beside the next collect; `res` stays valid until the collect after that.
+    // The SAM text of a chunk, a part per thread, and the records it is made from: kept from chunk to chunk (one write_chunk runs at a time), so
+    // their pages are touched and their vectors allocated once.  Two sets of text buffers: while the parts of chunk i are being written into the
+    // file (pwrite, every thread its own part at its own offset) the text of chunk i + 1 is made in the other set.
+    std::vector<std::string> sams_set[2] = {std::vector<std::string>((size_t)threads), std::vector<std::string>((size_t)threads)};
+    std::future<int> file_write[2];
+    int sams_turn = 0;
+    off_t out_at = -1;                                        // where the next chunk goes in the output file (-1: not a regular file, or not asked yet)
+    std::vector<ReadResult> RR;
     auto write_chunk = [&](Chunk *ck, lamsa_hp_result res) -> int {
         const double t1 = now_s();
         Batch &B = ck->B;
         const int n = (int)B.reads.size();
         const uint8_t *codes = ck->mapped ? ck->hb.read_seq : B.read_seq.data();
         const int64_t *roff = ck->mapped ? ck->hb.read_off : B.read_off.data();
-        std::vector<ReadResult> RR((size_t)n);
+        if (RR.size() < (size_t)n) RR.resize((size_t)n);
         std::vector<RescuePlan> plans(rescue ? (size_t)n : 0);
         std::vector<RescueJobs> tj((size_t)threads);
         std::vector<int> t_first((size_t)threads, 0), t_last((size_t)threads, 0);
@@ -1267,7 +1282,10 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
             n_rescue_jobs += dj.n_jobs;
         }
         const double t3 = now_s();
-        std::vector<std::string> sams((size_t)threads);
+        const int turn = sams_turn; sams_turn ^= 1;
+        if (file_write[turn].valid()) { const int e = file_write[turn].get(); if (e) return e; }          // the write that still reads this set
+        std::vector<std::string> &sams = sams_set[turn];
+        for (std::string &x : sams) x.clear();
         parallel_blocks(n, threads, [&](int t, int, int) {
             std::string &o = sams[(size_t)t];
             DpResults dp; dp.score = dpo.score; dp.qle = dpo.qle; dp.tle = dpo.tle; dp.cig_off = dpo.cig_off; dp.cigar = dpo.cigar; dp.base = base[(size_t)t];
@@ -1288,35 +1306,44 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
         // offset (pwrite: one thread's write() of 250 MB per chunk was the slowest stage of the loop once the hits came from a binary stream;
         // a mapping of the file's new end, round 3's way, pays a page fault per 4 KB and was slower still: profiles/r04_cli_bench.txt); a pipe
         // or a terminal takes the parts one after the other.
+        const double t4 = now_s();
         bool mapped_out = false;
         {
             size_t total = 0; for (const std::string &x : sams) total += x.size();
             struct stat st; const int fd = fileno(out);
             static const size_t map_min = getenv("LAMSA_MAP_OUT_MIN") ? (size_t)atol(getenv("LAMSA_MAP_OUT_MIN")) : ((size_t)8 << 20);      // (tests lower it)
-            if (threads > 1 && total >= map_min && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(fcntl(fd, F_GETFL) & O_APPEND) && fflush(out) == 0) {
-                const off_t base = lseek(fd, 0, SEEK_CUR);
-                if (base >= 0) {
-                    std::vector<size_t> at((size_t)threads + 1, 0);
-                    for (int t = 0; t < threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + sams[(size_t)t].size();
-                    std::atomic<int> werr(0);
-                    std::vector<std::thread> th;
-                    for (int t = 0; t < threads; ++t) if (!sams[(size_t)t].empty()) th.emplace_back([&, t]() {
-                        const char *p = sams[(size_t)t].data(); size_t left = sams[(size_t)t].size(); off_t o = base + (off_t)at[(size_t)t];
-                        while (left) { const ssize_t k = pwrite(fd, p, left, o); if (k <= 0) { if (k < 0 && errno == EINTR) continue; werr = errno ? errno : EIO; return; } p += k; left -= (size_t)k; o += k; }
+            if (threads > 1 && total >= map_min && fd >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(fcntl(fd, F_GETFL) & O_APPEND)) {
+                if (out_at < 0 && fflush(out) == 0) out_at = lseek(fd, 0, SEEK_CUR);
+                if (out_at >= 0) {
+                    const off_t base = out_at;
+                    out_at += (off_t)total;
+                    // (the stream's own position follows: whatever is written through `out` later -- a small chunk, nothing else today -- lands behind this one)
+                    if (fflush(out) != 0 || lseek(fd, out_at, SEEK_SET) != out_at) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
+                    file_write[turn] = std::async(std::launch::async, [&sams, fd, base, threads]() -> int {
+                        std::vector<size_t> at((size_t)threads + 1, 0);
+                        for (int t = 0; t < threads; ++t) at[(size_t)t + 1] = at[(size_t)t] + sams[(size_t)t].size();
+                        std::atomic<int> werr(0);
+                        std::vector<std::thread> th;
+                        for (int t = 0; t < threads; ++t) if (!sams[(size_t)t].empty()) th.emplace_back([&, t]() {
+                            const char *p = sams[(size_t)t].data(); size_t left = sams[(size_t)t].size(); off_t o = base + (off_t)at[(size_t)t];
+                            while (left) { const ssize_t k = pwrite(fd, p, left, o); if (k <= 0) { if (k < 0 && errno == EINTR) continue; werr = errno ? errno : EIO; return; } p += k; left -= (size_t)k; o += k; }
+                        });
+                        for (auto &x : th) x.join();
+                        if (werr.load()) { fprintf(stderr, "[lamsa_aln] cannot write the output file: %s\n", strerror(werr.load())); return 2; }
+                        return 0;
                     });
-                    for (auto &x : th) x.join();
-                    if (werr.load()) { fprintf(stderr, "[lamsa_aln] cannot write the output file: %s\n", strerror(werr.load())); return 2; }
-                    mapped_out = lseek(fd, base + (off_t)total, SEEK_SET) == base + (off_t)total;
-                    if (!mapped_out) { fprintf(stderr, "[lamsa_aln] cannot position the output file\n"); return 2; }
+                    mapped_out = true;
                     ++n_mapped_chunks;
                 }
             }
         }
+        if (!mapped_out) for (int k = 0; k < 2; ++k) if (file_write[k].valid()) { const int e = file_write[k].get(); if (e) return e; }     // (text through `out` goes behind what is still being written)
+        if (!mapped_out) out_at = -1;                           // (asked again after this chunk has gone through the stream)
         for (int t = 0; t < threads; ++t) { if (!mapped_out) fwrite(sams[(size_t)t].data(), 1, sams[(size_t)t].size(), out); n_bad += bad_of[(size_t)t]; }
         for (const Read &q : B.reads) n_bases += (long)q.seq.size();
         n_reads += (long)B.reads.size();
         sam_s += now_s() - t1;
-        if (trace) fprintf(stderr, "[write] %d reads: records%s %.3f s, stage-4 DP batch (%ld jobs) %.3f s, finish + rank + SAM %.3f s\n", n, rescue ? " + stage-4 plan" : "", t2 - t1, (long)base[(size_t)threads], t3 - t2, now_s() - t3);
+        if (trace) fprintf(stderr, "[write] %d reads: records%s %.3f s, stage-4 DP batch (%ld jobs) %.3f s, finish + rank + SAM text %.3f s, write started in %.3f s (it runs beside the next chunk's text)\n", n, rescue ? " + stage-4 plan" : "", t2 - t1, (long)base[(size_t)threads], t3 - t2, t4 - t3, now_s() - t4);
         return 0;
     };
     std::future<int> writer;                                 // the write_chunk task of the chunk collected last
@@ -1377,6 +1404,7 @@ int run_aln(const Options &opt, const lamsa_hp_para &P, FILE *out, const std::st
     }
     if (writer.valid()) { const int e = writer.get(); if (e && !ret) ret = e; }
     for (auto &f : dev_writer) if (f.valid()) f.get();
+    for (auto &f : file_write) if (f.valid()) { const int e = f.get(); if (e && !ret) ret = e; }
     stop_workers();
     if (next.valid()) next.wait();                       // the reader threads must be done before the files are closed
     if (scanned.valid()) scanned.wait();

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the product binary end to end on files (run on the GPU box): simulated reads + hits written as the files
 `lamsa aln -N` reads (FASTA, GEM map text, .pac/.ann), then `lamsa_amd/bin/lamsa aln -N ...` on them, page cache warm.
-Prints the binary's own stage accounting and reads/s.  usage: tools/cli_bench.py [n_reads] [read_len] [ref_bp] [reads per chunk]"""
+Prints the binary's own stage accounting and reads/s.  usage: tools/cli_bench.py [n_reads] [read_len] [ref_bp] [reads per chunk] [threads]"""
 import os
 import subprocess
 import sys
@@ -16,7 +16,7 @@ import simfiles   # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 ref_bp = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000_000
-threads = os.cpu_count() or 8
+threads = int(sys.argv[5]) if len(sys.argv) > 5 else (os.cpu_count() or 8)      # (-t of the runs is min(threads, 32); a one-GPU box grants 16 cores)
 d = tempfile.mkdtemp(prefix="clib_", dir=os.environ.get("TMPDIR", "/tmp"))
 t = time.time(); ref = simbatch.SimRef(ref_bp, n_contigs=24, seed=5, threads=min(threads, 16))
 B = simbatch.SimBatch(ref, n, L, "ont2d", seed=31, threads=min(threads, 16))
@@ -30,6 +30,10 @@ for rep, extra in enumerate((["--parse-only"], ["--save-hits", d + "/hits.bin"],
     dt = time.time() - t
     print("run %d %s: rc %d, %.2f s wall -> %.0f reads/s end to end" % (rep, " ".join(extra), p.returncode, dt, n / dt))
     print("\n".join(l for l in p.stderr.splitlines() if "wall" in l or "Mapping done" in l or "failed" in l), flush=True)
+    if rep == 4:                # once more with the stage trace of every chunk
+        q = subprocess.run([os.path.join(ROOT, "lamsa_amd", "bin", "lamsa"), "aln", "-N", "-T", "ont2d", "-R", "0", "-t", str(min(threads, 32)), "--batch", batch, "-o", d + "/out.sam"] + extra + [d + "/ref.fa", d + "/reads.fa"],
+                           capture_output=True, text=True, env=dict(os.environ, LAMSA_TRACE="1"))
+        print("\n".join(l for l in q.stderr.splitlines() if l.startswith("[write]") or l.startswith("[prepare]")), flush=True)
 # --shard i/N: every shard is a process with its own parser (meant to run one per GPU; here one after the other on this GPU, since two
 # processes sharing one GPU time-slice its persistent grids and its memory: measured 5-10x slower, see profiles/r03_cli_bench.txt);
 # their outputs concatenated are out.sam
