@@ -42,45 +42,48 @@ __global__ __launch_bounds__(64, HP_WAVES_PER_SIMD) void k_align_batch(AlignArgs
 #ifndef HP_FILL_WAVES_PER_SIMD
 #define HP_FILL_WAVES_PER_SIMD 7          // round 4, the fill without its DPs (profiles/r04_overlap.txt; ms of k_fill, ont10k): 8 waves per SIMD (64 VGPRs) 44.6, 7 (72) 34.2, 6 (80) 34.7, 5 (96) 40.8, 4 (128) 41.3 --
 #endif                                    // with 64 registers the append loop of frags_merge reloads spilled values behind its own stores (loads and stores share vmcnt on gfx9: a reload waits for every store before it)
-// The chaining, listing and fill launches wait on memory most of the time (74-89 % of wave cycles) and issue little; the DP launches saturate
-// the vector port.  When the launches of two batches share a CU the arbiter would otherwise hand out issue slots evenly and stretch every
-// dependent step of the latency-bound waves: they run at raised priority, the DP waves take the slots they leave.
-#ifndef HP_PRIO
-#define HP_PRIO 3
-#endif
-#define HP_LATENCY_PRIO() __builtin_amdgcn_s_setprio(HP_PRIO)
-__global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain1(const PhaseArgs *ap)
+// The chaining kernels in three shapes, chosen per batch (chain_shape): waves per SIMD against LDS words per wave.  A cluster of up to LDS / 5
+// hits runs out of LDS (hp_cluster.h), a larger one through the HBM scan; the line sets and the gap tables are bounded by the LDS likewise.
+// Measured (profiles/r04_chain_lds.txt, ms of k_chain1, one step at a time): 10-kbp ONT reads (400 seeds) 70 / 81 / 103 at 4 / 3 / 2 waves,
+// 20-kbp PacBio reads (800 seeds: the cluster at the read's true locus no longer fits 486 hits) 130 / 83 / 106.
+template <int WORDS, int WPS>
+__global__ __launch_bounds__(64, WPS) void k_chain1(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;        // in device memory: scalar loads, no private copy of the argument block
-    HP_LATENCY_PRIO();
-    __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];      // the hit sort's blocks (hp_sort.h), then the node state of one cluster at a time (hp_cluster.h)
+    __shared__ int32_t lds[WORDS];   // the hit sort's blocks (hp_sort.h), then the node state of one cluster at a time (hp_cluster.h)
     for (;;) {
         int u = 0;
         if (wv::leader()) u = atomicAdd(&a.ctl->q_head[0], 1);
         u = wv::uni(u);
         if (u >= a.n_reads) break;
-        phase_chain1(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, HP_CHAIN_LDS_WORDS);
+        phase_chain1(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, WORDS);
     }
     drain_stamp(a, 0);
 }
-__global__ __launch_bounds__(64, HP_CHAIN_WAVES_PER_SIMD) void k_chain2(const PhaseArgs *ap)
+template <int WORDS, int WPS>
+__global__ __launch_bounds__(64, WPS) void k_chain2(const PhaseArgs *ap)
 {
     const PhaseArgs &a = *ap;
-    HP_LATENCY_PRIO();
-    __shared__ int32_t lds[HP_CHAIN_LDS_WORDS];
+    __shared__ int32_t lds[WORDS];
     for (;;) {
         int u = 0;
         if (wv::leader()) u = atomicAdd(&a.ctl->q_head[2], 1);
         u = wv::uni(u);
         if (u >= a.n_reads) break;
-        phase_chain2(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, HP_CHAIN_LDS_WORDS);
+        phase_chain2(a, a.order ? a.order[u] : u, blockIdx.x, (HP_L int32_t *)lds, WORDS);
     }
     drain_stamp(a, 2);
 }
+typedef void (*ChainKernel)(const PhaseArgs *);
+struct ChainShape { ChainKernel k1, k2; int lds_words, waves_per_simd; };
+static const ChainShape g_chain_shapes[3] = {
+    {k_chain1<HP_CHAIN_LDS_WORDS, HP_CHAIN_WAVES_PER_SIMD>, k_chain2<HP_CHAIN_LDS_WORDS, HP_CHAIN_WAVES_PER_SIMD>, HP_CHAIN_LDS_WORDS, HP_CHAIN_WAVES_PER_SIMD},
+    {k_chain1<3392, 3>, k_chain2<3392, 3>, 3392, 3},
+    {k_chain1<5120, 2>, k_chain2<5120, 2>, 5120, 2},
+};
 __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
-    HP_LATENCY_PRIO();
     __shared__ int32_t lds[HP_LDS_WORDS];            // this wave's DP rows, query window and direction matrix (hp_ksw.h)
     int n = 0;
     for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
@@ -106,7 +109,6 @@ __global__ __launch_bounds__(64, HP_FILL_WAVES_PER_SIMD) void k_fill(const Phase
 __global__ __launch_bounds__(64, HP_LIST_WAVES_PER_SIMD) void k_filllist(const PhaseArgs *ap, int round)
 {
     const PhaseArgs &a = *ap;
-    HP_LATENCY_PRIO();
     int n = 0;
     for (int b = 0; b < PH_NBUCKET; ++b) n += a.ctl->bucket_n[round][b];
     n = wv::uni(n);
@@ -552,15 +554,27 @@ static int64_t main_stream_cap(int n, int64_t n_bases) { return 1024 + (int64_t)
 // scratch of a wave of each kind of launch (all launches of a batch share one allocation, one after the other): the chaining launches keep
 // per-hit arrays, the listing / lane-DP / fill launches result and CIGAR buffers and the small DPs the fill still runs itself, the
 // wave-per-job launch the direction matrix of the longest end extension
-struct SlabPlan { size_t chain, fill, wj, wjb, wjb_off; int w_chain, w_fill, w_dp, w_wj, n_wjb; size_t bytes; };
+struct SlabPlan { size_t chain, fill, wj, wjb, wjb_off; int w_chain, w_fill, w_dp, w_wj, n_wjb, shape; size_t bytes; };
 // shared: another batch's launches are in flight on the handle's other stream.  The launches are persistent grids; at full size the earlier
 // batch's grid owns every wave slot and the later one only gets what its tail leaves.  The DP launch is bound by instruction issue (VALU port
 // 78 % busy, profiles/r04_ont10k_pmc.json) and the chaining / fill launches by memory latency (wait 74-89 %, VALU 26-38 %): with every grid
 // capped at half a CU's slots the launches of the two batches run side by side on the same CUs, one filling the issue slots the other leaves
 // idle -- measured 357 k reads/s against 345 k with full grids (profiles/r04_overlap.txt).  A batch that runs alone gets the whole CU.
-static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared = false)
+// which shape of the chaining kernels suits the batch: the hits at a read's true locus are at most one per seed -- about two in three of
+// the seeds of a noisy read have one -- and that cluster should run out of LDS (LDS words / 5 hits)
+static int chain_shape(const lamsa_hp_para &P, int64_t n_reads, int64_t n_bases)
+{
+    static const int force = getenv("LAMSA_HP_CHAIN_SHAPE") ? atoi(getenv("LAMSA_HP_CHAIN_SHAPE")) : -1;          // diagnostic
+    if (force >= 0 && force < 3) return force;
+    const int64_t mean_L = n_reads > 0 ? n_bases / n_reads : 0, ss = P.seed_step > 0 ? P.seed_step : 1;
+    const int64_t est = mean_L / ss * 2 / 3;
+    for (int k = 0; k < 2; ++k) if (est <= g_chain_shapes[k].lds_words / 5) return k;
+    return 2;
+}
+static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared = false, int shape = 0)
 {
     SlabPlan Q;
+    Q.shape = shape;
     const lamsa_hp_para &P = h->para;
     // chaining: per-hit arrays, line sets, fragments.  Listing / lane DP / fill: result and CIGAR buffers, the small DPs the fill still runs
     // itself, a lane-DP group's buffers.  Wave jobs: an ordinary slab takes the junctions and the end extensions of a few thousand rows; the
@@ -574,7 +588,7 @@ static SlabPlan slab_plan(lamsa_hp_handle *h, int max_L, int max_H, bool shared 
     if (g_nowave) Q.fill = std::max(Q.fill, slab_bytes_for(P, max_L, max_H, 1));            // (diagnostics: the fill runs every DP itself)
     if (h->scratch_limit) { const size_t lim = al256(h->scratch_limit); Q.chain = std::min(Q.chain, lim); Q.fill = std::min(Q.fill, lim); Q.wj = std::min(Q.wj, lim); Q.wjb = std::min(Q.wjb, lim); }
     int pc = 0, pf = 0, pd = 0, pw = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_chain1, 64, 0) != hipSuccess || pc < 1) pc = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, g_chain_shapes[shape].k1, 64, 0) != hipSuccess || pc < 1) pc = 4 * g_chain_shapes[shape].waves_per_simd;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pf, k_fill, 64, 0) != hipSuccess || pf < 1) pf = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pd, k_filldp_small, 64, 0) != hipSuccess || pd < 1) pd = 4;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pw, k_filldp_wave, 64, 0) != hipSuccess || pw < 1) pw = 4;
@@ -600,7 +614,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
 {
     const int n = T.n_reads;
     const int64_t n_hits = T.n_hits;
-    const SlabPlan Q = slab_plan(h, T.max_L, T.max_H, S->n_fifo + S->n_res > 0);
+    const SlabPlan Q = slab_plan(h, T.max_L, T.max_H, S->n_fifo + S->n_res > 0, chain_shape(h->para, T.n_reads, T.n_bases));
     const int w_chain = Q.w_chain, w_fill = Q.w_fill, w_dp = Q.w_dp, w_wj = Q.w_wj;
     const PhasedLayout Y = phased_layout(n, n_hits, T.n_bases, O.stream_cap);
     const int unit_cap = Y.unit_cap, lj_cap = Y.lj_cap; const int64_t fl_cap = Y.fl_cap, line_cap = Y.line_cap, job_cap = Y.job_cap;
@@ -636,7 +650,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipMemcpyAsync(d + o_args, Ln.args_host.p, sizeof a, hipMemcpyHostToDevice, s), LAMSA_HP_EKERNEL);
     const PhaseArgs *da = (const PhaseArgs *)(d + o_args);
     HIPCHK(h, hipEventRecord(e0, s), LAMSA_HP_EKERNEL);
-    hipLaunchKernelGGL(k_chain1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
+    hipLaunchKernelGGL(g_chain_shapes[Q.shape].k1, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[0], s), LAMSA_HP_EKERNEL);
     if (list) {
         hipLaunchKernelGGL(k_filllist, dim3(w_fill), dim3(64), 0, s, da, 0);
@@ -648,7 +662,7 @@ static int launch_phased(lamsa_hp_handle *h, AlignState *S, Slot &T, Slot &Ln, O
     HIPCHK(h, hipEventRecord(Ln.ep[4], s), LAMSA_HP_EKERNEL);
     hipLaunchKernelGGL(k_fill, dim3(w_fill), dim3(64), 0, s, da, 0);
     HIPCHK(h, hipEventRecord(Ln.ep[1], s), LAMSA_HP_EKERNEL);
-    hipLaunchKernelGGL(k_chain2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
+    hipLaunchKernelGGL(g_chain_shapes[Q.shape].k2, dim3(std::min(w_chain, n)), dim3(64), 0, s, da);
     HIPCHK(h, hipEventRecord(Ln.ep[2], s), LAMSA_HP_EKERNEL);
     if (list) {
         HIPCHK(h, hipMemsetAsync(&((PhaseCtl *)(d + o_ctl))->q_head[5], 0, 16, s), LAMSA_HP_EKERNEL);          // the four queue heads of the listing and DP launches
@@ -914,7 +928,7 @@ extern "C" int lamsa_hp_reserve(lamsa_hp_handle *h, int32_t n_reads, int64_t n_b
     HIPCHK(h, hipSetDevice(h->device), LAMSA_HP_ENODEV);
     AlignState *S = state_of(h);
     if (S->n_fifo || S->n_res) { h->err = "batches are in flight"; return LAMSA_HP_EINVAL; }
-    const SlabPlan Q = slab_plan(h, max_read_len, max_hits_per_read);
+    const SlabPlan Q = slab_plan(h, max_read_len, max_hits_per_read, false, chain_shape(h->para, n_reads, n_bases));
     const int64_t cap = main_stream_cap(n_reads, n_bases);
     const PhasedLayout Y = phased_layout(n_reads, n_hits, n_bases, cap);
     // the packed input of a batch (upload_into): every array plus its 256-byte alignment, both CIGAR forms' staging included
