@@ -308,8 +308,8 @@ def main():
                 "launch_ms_one_step_at_a_time": {k: round(v, 3) for k, v in lm_seq.items()} if lm_seq else None,
                 "bytes_per_read": round(step_bytes / a.reads, 1), "terms": parts,
                 # the compute side: DP cell updates and chaining edge classifications actually executed
-                "dp_cells_per_step": cells, "gcups": round(cells * a.steps * world / dt / 1e9, 3), "gcups_within_fill_launches": round(cells / max(fill_ms, 1e-6) / 1e6, 3),
-                "pair_evals_per_step": pairs, "pair_evals_per_s": round(pairs * a.steps * world / dt, 1), "pair_evals_per_s_within_chain_launches": round(pairs / max(lm["chain1"] + lm["chain2"], 1e-6) * 1e3, 1),
+                "dp_cells_per_step": cells, "gcups": round(cells * a.steps * world / dt / 1e9, 3), "gcups_within_fill_launches": round(cells / max((lm_seq["fill1"] + lm_seq["fill2"]) if lm_seq else fill_ms, 1e-6) / 1e6, 3),      # (launch durations one step at a time when measured)
+                "pair_evals_per_step": pairs, "pair_evals_per_s": round(pairs * a.steps * world / dt, 1), "pair_evals_per_s_within_chain_launches": round(pairs / max((lm_seq or lm)["chain1"] + (lm_seq or lm)["chain2"], 1e-6) * 1e3, 1),
                 # per unit of work, from the committed counter passes of this workload (None without one)
                 "hbm_bytes_per_pair_eval": round(chain_traffic / max(pairs, 1), 2) if chain_traffic else None,
                 "valu_lane_slots_per_cell": round(valu_fill * 64.0 / max(cells, 1), 1) if valu_fill else None,
