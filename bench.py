@@ -468,11 +468,13 @@ def reference_binary_baseline(B, ref, wl, threads, seconds):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=None, prebuilt=None):
+def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=None, prebuilt=None, unseeded=None):
     """The reference's DEFAULT run -- no -R 0: stage 4, the BWT rescue of unaligned read parts (src/bwt_aln.c:398-409), searches the FM
     index -- against the product binary's, on files: a stand-in of ref_bp bases with the bench's repeat families, its .bwt / .sa built here by
     the product's own `lamsa index --from-pac`, n_reads simulated reads of the workload with their seed hits as GEM map text.  Returns the
-    per-read SAM comparison, both wall times, and what share of the product's chunk loop went to stage 4 (its own trace)."""
+    per-read SAM comparison, both wall times, and what share of the product's chunk loop went to stage 4 (its own trace).  unseeded = (share
+    of the reads, share of a read's seeds): those reads get a stretch without any seed hit -- on fully seeded simulated reads stage 4 finds
+    nothing to do."""
     import re
     import shutil
     import subprocess
@@ -501,7 +503,7 @@ def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=Non
                 return {"error": "lamsa index --from-pac failed: " + q.stderr[-300:]}
             t_index = time.perf_counter() - t1
         B = simbatch.SimBatch(ref, n_reads, wl["length"], wl["profile"], seed=23, threads=min(threads, 32))
-        simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"], workers=min(threads, 32))
+        simfiles.write_reads(d + "/reads.fa", B, seed_len=50, seed_step=p["seed_step"], workers=min(threads, 32), unseeded=unseeded)
         with open(d + "/reads.fa.seed.info", "w") as f:
             for r in range(n_reads):
                 f.write("r%d %d %d %d\n" % (r, int(B.seed_all[r]), int(B.last_len[r]), int(B.read_off[r + 1] - B.read_off[r])))
@@ -520,10 +522,10 @@ def default_run_check(workload, wl, threads, n_reads, ref_bp, exe=None, keep=Non
         same = sam_same_reads(d + "/out.sam", d + "/out_gpu.sam")
         # the product's own account of its write stage: "[write] N reads: records + stage-4 plan A s, stage-4 DP batch (J jobs) B s, finish + rank + SAM C s"
         plan = dp = rest = 0.0; jobs = 0
-        for m in re.finditer(r"\[write\] \d+ reads: records(?: \+ stage-4 plan)? ([0-9.]+) s, stage-4 DP batch \((\d+) jobs\) ([0-9.]+) s, finish \+ rank \+ SAM ([0-9.]+) s", g.stderr):
+        for m in re.finditer(r"\[write\] \d+ reads: records(?: \+ stage-4 plan)? ([0-9.]+) s, stage-4 DP batch \((\d+) jobs\) ([0-9.]+) s, finish \+ rank \+ SAM(?: text)? ([0-9.]+) s", g.stderr):
             plan += float(m.group(1)); jobs += int(m.group(2)); dp += float(m.group(3)); rest += float(m.group(4))
         n_rescued = sum(1 for line in open(d + "/out.sam") if not line.startswith("@"))
-        return {"workload": workload, "reads": n_reads, "ref_bp": int(ref.l_pac), "gpu_equals_reference": same, "sam_lines_reference": n_rescued,
+        return {"workload": workload, "reads": n_reads, "unseeded_stretch": unseeded, "ref_bp": int(ref.l_pac), "gpu_equals_reference": same, "sam_lines_reference": n_rescued,
                 "index_build_s": round(t_index, 1), "setup_s": round(t_setup, 1), "reference_wall_s": round(t_ref, 2), "reference_threads": threads, "product_wall_s": round(t_gpu, 2),
                 "product_stage4": {"dp_jobs": jobs, "plan_s": round(plan, 3), "dp_batch_s": round(dp, 3), "finish_rank_sam_s": round(rest, 3),
                                    "share_of_product_wall": round((plan + dp) / max(t_gpu, 1e-6), 4)},

@@ -61,8 +61,12 @@ def _write_part(args):
             seed_all = 0 if L < seed_len else 1 + (L - seed_len) // seed_step
             assert seed_all == int(B.seed_all[r])
             slot_of = {int(B.seed_id[s]): s for s in range(int(B.seed_off[r]), int(B.seed_off[r + 1]))}
+            un = _SHARED.get("unseeded")              # (share of the reads, share of a read's seeds): a stretch in the middle of such a read without any seed hit
+            un_lo = un_hi = 0
+            if un and (r * 2654435761 % 1000) < 1000 * un[0]:
+                un_lo = int(seed_all * 0.4); un_hi = un_lo + max(1, int(seed_all * un[1]))
             for sd in range(1, seed_all + 1):
-                s = slot_of.get(sd)
+                s = slot_of.get(sd) if not (un_lo <= sd < un_hi) else None
                 hits = []
                 if s is not None:
                     for k in range(int(B.hit_off[s]), int(B.hit_off[s + 1])):
@@ -76,7 +80,7 @@ def _write_part(args):
 _SHARED = {}
 
 
-def write_reads(path, B, seed_len=50, seed_step=25, workers=1):
+def write_reads(path, B, seed_len=50, seed_step=25, workers=1, unseeded=None):
     """reads.fa + reads.fa.seed.gem.map for batch B (names r0, r1, ...).  workers > 1: the reads are split over forked
     worker processes (the batch is shared copy-on-write), their part files concatenated in order."""
     import os
@@ -84,6 +88,8 @@ def write_reads(path, B, seed_len=50, seed_step=25, workers=1):
     n = B.n_reads
     workers = max(1, min(workers, n // 64 if n >= 128 else 1))
     _SHARED["B"] = B
+    if unseeded:
+        _SHARED["unseeded"] = unseeded
     if int(getattr(B, "n_cig", 0)) > 0x7fffffff:    # the CIGARs lie back to back in hit order (tools/simhits.c)
         import numpy as np
         cn = np.asarray(B.h_cig_n[:B.n_hits], np.int64)
