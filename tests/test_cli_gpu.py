@@ -21,6 +21,19 @@ def test_sam_identical_to_reference(name, tmp_path):
     assert G.strip_pg(p.stdout) == G.strip_pg(gold)
 
 
+@pytest.mark.parametrize("shape", ["0", "1", "2"])
+def test_every_shape_of_the_chaining_kernels(shape, tmp_path):
+    """The chaining kernels exist with 2 432 / 3 392 / 5 120 LDS words per wave at 4 / 3 / 2 waves per SIMD and a batch picks one by its mean
+    read length (chain_shape, hp_align_api.hip); LAMSA_HP_CHAIN_SHAPE forces one.  What runs out of LDS and what through HBM differs between
+    them (cluster capacity, line sets, gap tables); the SAM must not."""
+    for name in ("c3_ont", "c4_pb20k", "c5_sv", "c10_rearr_ont"):
+        d = tmp_path / name; d.mkdir()
+        ref, reads, args, gold = G.stage_scenario(name, str(d))
+        p = subprocess.run([BIN, "aln", "-N", "-R", "0"] + args + [ref, reads], capture_output=True, text=True, env=dict(os.environ, LAMSA_HP_CHAIN_SHAPE=shape))
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert G.strip_pg(p.stdout) == G.strip_pg(gold), (name, shape)
+
+
 def test_small_batches(tmp_path):
     ref, reads, args, gold = G.stage_scenario("c2_pacbio", str(tmp_path))
     p = subprocess.run([BIN, "aln", "-N", "-R", "0", "--batch", "4"] + args + [ref, reads], capture_output=True, text=True)
