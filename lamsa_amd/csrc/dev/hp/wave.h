@@ -145,27 +145,6 @@ HP_INL void shr1(Lane<int> &x, int fill) { x.v = dpp<0x138>(fill, x.v); }
 // the same round the wave: lane 0 receives lane 63's (wave_ror:1)
 HP_INL void ror1(Lane<int> &x) { x.v = dpp<0x13C>(x.v, x.v); }
 
-// ---- the same inside every 16-lane row of the wave (a DPP "row"): four independent groups of 16 lanes, one DP job each (hp_stripdp.h)
-// every lane of a row receives the row's maximum
-HP_INL void row16_allmax(Lane<int> &x) {
-    int v = x.v;
-    HP_MAX_DPP(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "row_mirror row_mask:0xf bank_mask:0xf");
-    x.v = v;
-}
-// exclusive prefix maximum along every row; lane 0 of a row receives `ident` (which must be <= every input)
-HP_INL void row16_scan_max_excl(Lane<int> &x, int ident) {
-    int v = x.v;
-    HP_MAX_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
-    HP_MAX_DPP(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
-    x.v = dpp<0x111>(ident, v);                        // row_shr:1: the inclusive scan one lane up; lane 0 of a row keeps `ident`
-}
-// every lane receives the value of the lane below it in its row; lane 0 of a row receives `fill`
-HP_INL void row16_shr1(Lane<int> &x, int fill) { x.v = dpp<0x111>(fill, x.v); }
 
 // exclusive prefix sum over lanes (lane 0 receives 0)
 HP_INL void scan_add_excl(Lane<int> &x) {

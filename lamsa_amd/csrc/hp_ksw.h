@@ -1045,6 +1045,7 @@ HP_NOINL ExtRes ksw_extend_band(Ctx &cx, int qlen, Seq q, int tlen, Seq t, int w
                 ka[l] = l >= l0 ? run : HP_PK_IDENT; kb[l] = l < l0 ? run : HP_PK_IDENT;
             }
             // F along the row: the exclusive prefix maximum over the lanes before this one in column order
+            // (one scan while the window has not moved, the lanes then being in column order as they are, was measured: no gain)
             const int topA = wv::scan_max_excl_top(ka, HP_PK_IDENT);
             wv::scan_max_excl(kb, HP_PK_IDENT);
             wv::Lane<int> best;

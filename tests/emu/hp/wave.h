@@ -74,12 +74,6 @@ HP_INL int scan_max_excl_top(Lane<int> &x, int ident) {
 
 HP_INL void shr1(Lane<int> &x, int fill) { for (int l = 63; l > 0; --l) x.v[l] = x.v[l - 1]; x.v[0] = fill; }
 HP_INL void ror1(Lane<int> &x) { const int top = x.v[63]; for (int l = 63; l > 0; --l) x.v[l] = x.v[l - 1]; x.v[0] = top; }
-// the same inside every 16-lane row
-HP_INL void row16_allmax(Lane<int> &x) { for (int r = 0; r < 64; r += 16) { int m = x.v[r]; for (int l = 1; l < 16; ++l) m = x.v[r + l] > m ? x.v[r + l] : m; for (int l = 0; l < 16; ++l) x.v[r + l] = m; } }
-HP_INL void row16_scan_max_excl(Lane<int> &x, int ident) {
-    for (int r = 0; r < 64; r += 16) { int run = 0; for (int l = 0; l < 16; ++l) { const int cur = x.v[r + l]; x.v[r + l] = l == 0 ? ident : run; run = l == 0 ? cur : (cur > run ? cur : run); } }
-}
-HP_INL void row16_shr1(Lane<int> &x, int fill) { for (int r = 0; r < 64; r += 16) { for (int l = 15; l > 0; --l) x.v[r + l] = x.v[r + l - 1]; x.v[r] = fill; } }
 HP_INL void scan_add_excl(Lane<int> &x) {
     int run = 0;
     for (int l = 0; l < 64; ++l) { const int cur = x.v[l]; x.v[l] = run; run += cur; }
