@@ -265,7 +265,7 @@ HP_NOINL GapRest gaps_one_by_one(ReadCtx &r, int G, int32_t *gp, int GA, int32_t
 #define HP_GAP_MCAP_RT(cap) (cap)            // survivors of a gap a lane takes; the tests' CPU build lowers it
 #endif
 // HP_STAT slots: 0 lines by cluster, 1 lines by seed range, 2 gaps in lanes, 3 of them from START, 4 gaps through the wave-wide routine, 5 of them through memory,
-// 6-8 lines in clusters of <= 6 / <= 16 / more hits, 9 junction jobs published by hp_stripdp.h (per lane), 10 an uncovered region at the read's end
+// 6-8 lines in clusters of <= 6 / <= 16 / more hits, 9 wave jobs published (hp_phase.h), 10 an uncovered region at the read's end
 // (hp_align.h), 11-13 the F_INSERT classes and the MULTI re-update of the k-mer split mapper (hp_split.h), 14 inter-lines, 15 dumped edge clusters
 // The +-MULTI hits of the large clusters a read's lines have visited so far (ascending hit order, as in C.csrt): the ~20 lines of the read's
 // true locus share one cluster of several hundred hits, of which a few dozen are left for the mini DPs -- the first line lists them, the
