@@ -220,6 +220,128 @@ HP_INL int read_gap(const ReadCtx &r, int s1, int s2, const uint8_t **p)
 }
 
 // ---------------------------------------------------------------- frag_extend, :332-410
+#ifndef HP_FRAG_BLOCK_MIN
+#define HP_FRAG_BLOCK_MIN 3                  // fewer steps than this are walked one by one (the tests' CPU build sets it to 1 and to a large number)
+#endif
+HP_INL int seed_at_after_block(const HP_G int32_t *g_seed, int i, int step, int nb) { return g_seed[i + step * (nb - 1)]; }
+
+// One seed step of the loop :360-400, as the reference runs it: the gap between seed `last` and seed s (its CIGAR computed ahead by the lane-DP
+// launch, or ksw_global2 here), then seed s's own CIGAR, each through merge_cigar.
+HP_INL bool frag_step(ReadCtx &r, const FLines &F, int frag, int i, int chr, CigV &fc, int64_t &ref_end, int &re, int &last)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    const int32_t *seed = F.fr_seed + F.fr_seed_off[frag];
+    const int s = seed[i];
+    {   const int32_t *gt = F.gt ? F.gt + 4 * (F.fr_seed_off[frag] + i) : nullptr;
+        if (gt && gt[3] && F.jarena) {                                          // the gap's CIGAR was computed ahead (hp_lanedp.h)
+            const uint8_t *qp0; const int len1p = read_gap(r, last, s, &qp0);
+            const bool ok = merge_cigar(r, fc, &ref_end, &re, chr, F.jarena + gt[0], gt[1], gt[2], len1p) &&
+                            (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
+            last = s;
+            return ok;
+        }
+    }
+    const size_t m2 = arena_mark(cx.tmp);
+    // get_ref_intv, :98
+    const int64_t start = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
+    int32_t len2 = (int32_t)(r.h_pos[s] - 1 - start);
+    uint8_t *tb = nullptr;
+    if (len2 <= 0) len2 = 0;
+    else {
+        tb = (uint8_t *)arena_alloc(cx, (size_t)len2 + 16);
+        if (!tb || !ref_fetch(r, r.h_chr[last], start, &len2, tb)) return false;
+    }
+    const uint8_t *qp; const int len1 = read_gap(r, last, s, &qp);
+    CigV g;
+    if (!cig_alloc(cx, g, len1 + len2 + 8)) return false;
+    ksw_global(cx, len1, seq_fwd(qp), len2, seq_fwd(tb ? tb : qp), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &g);
+    const bool ok = merge_cigar(r, fc, &ref_end, &re, chr, g.c, g.n, len2, len1) &&
+                    (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
+    last = s;
+    arena_release(cx.tmp, m2);
+    return ok;
+}
+
+// Up to 32 seed steps of that loop at once, a PIECE (a gap's CIGAR, a seed's CIGAR) per lane, when every piece is there, is not empty and both
+// begins and ends with a match, and so does what has been merged so far: merge_cigar then never repairs a boundary (:256-263 look for a short
+// indel on either side of it), every piece's first element is added to the element on top (_push_cigar) and the rest is appended as it is.
+// That is a concatenation: piece k's elements go to where the pieces before it end (a prefix sum of n - 1), the lengths of the first elements
+// are summed over each run of pieces up to the next one that has more than one element, and the sum goes into the element on top of that run.
+// A fragment of an error-poor read is ~50 seeds of "50M" with "50M" between them -- walked one after the other that was ~8 dependent round
+// trips per seed and most of the fill kernel's time on the 1 %-error workloads (profiles/r04_fill_glue.txt).  Returns the steps taken (0: not
+// this way); `top` = the element on top of fc, kept by the caller.
+HP_INL int frag_steps_block(ReadCtx &r, const FLines &F, int frag, int i, int step, int n_steps, CigV &fc, int64_t &ref_end, int &re, int &last, cig_t &top)
+{
+    Ctx &cx = r.cx;
+    const lamsa_hp_para *P = cx.P;
+    if (!F.gt || !F.jarena || fc.n < 1 || (top & 0xf) != C_M) return 0;
+    const int fro = F.fr_seed_off[frag];
+    const HP_G int32_t *g_seed = (const HP_G int32_t *)(F.fr_seed + fro);
+    const HP_G int32_t *g_gt = (const HP_G int32_t *)(F.gt + 4 * (size_t)fro);
+    const HP_G cig_t *g_ja = (const HP_G cig_t *)F.jarena, *g_cig = (const HP_G cig_t *)r.cig;
+    const int nb = n_steps < 32 ? n_steps : 32, K = 2 * nb;
+    const int seed_len = P->seed_len, seed_step = P->seed_step, seed_inv = P->seed_inv;
+    const int plus = r.h_strand[last] == 1, base_off = plus ? 0 : r.last_len;
+    wv::Lane<int> n, wf, wl, rl, ql, cw; wv::Lane<long long> src;
+    WAVE_FOR(l) {
+        n[l] = 0; wf[l] = 0; wl[l] = 0; rl[l] = 0; ql[l] = 0; cw[l] = 0; src[l] = 0;
+        if (l < K) {
+            const int j = l >> 1, idx = i + step * j;
+            const int s = g_seed[idx], prev = j == 0 ? last : g_seed[idx - step];
+            if (!(l & 1)) {                                                     // the gap in front of seed s
+                int g[4]; hp_load16(g_gt + 4 * (size_t)idx, g);
+                if (g[3]) {
+                    const int a = base_off + sid(r, r.n_seed[prev]) * seed_step - seed_inv, e = base_off + (sid(r, r.n_seed[s]) - 1) * seed_step;      // read_gap
+                    n[l] = g[1]; src[l] = (long long)(g_ja + g[0]); rl[l] = g[2]; ql[l] = e > a ? e - a : 0;
+                } else n[l] = -1;                                               // not computed ahead
+            } else {                                                            // seed s itself
+                n[l] = r.h_cig_n[s]; src[l] = (long long)(g_cig + r.h_cig_off[s]); rl[l] = seed_len + r.h_len_dif[s]; ql[l] = seed_len; cw[l] = n[l];
+            }
+            if (n[l] > 0) { const HP_G cig_t *w = (const HP_G cig_t *)src[l]; wf[l] = w[0]; wl[l] = w[n[l] - 1]; }
+        }
+    }
+    {
+        wv::Lane<int> bad;
+        WAVE_FOR(l) { bad[l] = l < K && (n[l] <= 0 || (wf[l] & 0xf) != C_M || (wl[l] & 0xf) != C_M); }
+        if (wv::ballot(bad)) return 0;
+    }
+    wv::Lane<int> adv, S, big;
+    WAVE_FOR(l) { adv[l] = l < K ? n[l] - 1 : 0; S[l] = l < K ? (wf[l] >> 4) : 0; big[l] = l < K && n[l] >= 2; }
+    const int n_new = wv::reduce_sum(adv);
+    if (fc.n + n_new > fc.cap) return 0;                                        // (the walk one by one flags it)
+    wv::Lane<int> base = adv;
+    wv::scan_add_excl(base);                                                    // elements appended by the pieces before this one
+    { wv::Lane<int> h = S; wv::scan_add_excl(h); WAVE_FOR(l) { S[l] += h[l]; } }    // inclusive sum of the first elements' lengths
+    const unsigned long long mb = wv::ballot(big);
+    // the run behind piece k: up to and with the next piece of several elements (or the block's last piece)
+    wv::Lane<int> e_of;
+    WAVE_FOR(l) { const unsigned long long above = l < 63 ? (mb >> (l + 1)) << (l + 1) : 0ull; e_of[l] = above ? __builtin_ctzll(above) : K - 1; }
+    const wv::Lane<int> S_e = wv::gather(S, e_of);
+    HP_G cig_t *out = (HP_G cig_t *)fc.c;
+    const int B0 = fc.n - 1;
+    const int e0 = mb ? __builtin_ctzll(mb) : K - 1;
+    const cig_t top_new = top + (cig_t)(wv::bcast(S, e0) << 4);
+    wv::Lane<int> adj;
+    WAVE_FOR(l) {
+        adj[l] = 0;
+        if (l == 0) out[B0] = top_new;
+        if (big[l]) {
+            adj[l] = wl[l] + ((S_e[l] - S[l]) << 4);
+            const HP_G cig_t *w = (const HP_G cig_t *)src[l];
+            HP_G cig_t *o = out + B0 + base[l];
+            for (int t = 1; t < n[l] - 1; ++t) o[t] = w[t];
+            o[n[l] - 1] = adj[l];
+        }
+    }
+    top = mb ? (cig_t)wv::bcast(adj, 63 - __builtin_clzll(mb)) : top_new;
+    fc.n += n_new;
+    ref_end += wv::reduce_sum(rl); re += wv::reduce_sum(ql); r.cs_words += wv::reduce_sum(cw);
+    last = seed_at_after_block(g_seed, i, step, nb);
+    wv::sync();
+    return nb;
+}
+
 HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
 {
     Ctx &cx = r.cx;
@@ -230,7 +352,10 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
     const size_t mark = arena_mark(cx.tmp);
     CigV fc;
     int cap = 0;                                          // seed CIGARs + gap CIGARs (gap = seed_step - seed_len bases + indels)
-    for (int i = 0; i < seed_n; ++i) cap += r.h_cig_n[seed[i]] + 2 * iabs(P->seed_step) + 64;
+    {   const HP_G int32_t *g_seed = (const HP_G int32_t *)seed;
+        for (int b0 = 0; b0 < seed_n; b0 += 64) { wv::Lane<int> c; WAVE_FOR(l) { c[l] = b0 + l < seed_n ? (int)r.h_cig_n[g_seed[b0 + l]] : 0; } cap += wv::reduce_sum(c); }
+        cap += seed_n * (2 * iabs(P->seed_step) + 64);
+    }
     if (!cig_alloc(cx, fc, cap + 16)) return false;
     int i, rs, re, last;
     if (strand == 1) { i = seed_n - 1; last = seed[i]; rs = (sid(r, r.n_seed[last]) - 1) * P->seed_step + 1; }
@@ -241,35 +366,17 @@ HP_NOINL bool frag_extend_multi(ReadCtx &r, const FLines &F, int frag, Rec &res)
     int64_t ref_end = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
     const int step = strand == 1 ? -1 : 1;
     bool ok = true;
-    for (i += step; i >= 0 && i < seed_n && ok; i += step) {
-        const int s = seed[i];
-        const size_t m2 = arena_mark(cx.tmp);
-        {   const int32_t *gt = F.gt ? F.gt + 4 * (F.fr_seed_off[frag] + i) : nullptr;
-            if (gt && gt[3] && F.jarena) {                                      // the gap's CIGAR was computed ahead (hp_lanedp.h)
-                const uint8_t *qp0; const int len1p = read_gap(r, last, s, &qp0);
-                ok = merge_cigar(r, fc, &ref_end, &re, chr, F.jarena + gt[0], gt[1], gt[2], len1p) &&
-                     (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
-                last = s;
-                continue;
-            }
+    i += step;
+    while (i >= 0 && i < seed_n && ok) {
+        const int left = step == 1 ? seed_n - i : i + 1;                         // steps to go
+        if (left >= HP_FRAG_BLOCK_MIN && fc.n > 0) {
+            cig_t top = ((const HP_G cig_t *)fc.c)[fc.n - 1];
+            const int took = frag_steps_block(r, F, frag, i, step, left, fc, ref_end, re, last, top);
+            if (took) { HP_STAT(24); i += step * took; continue; }
         }
-        // get_ref_intv, :98
-        const int64_t start = r.h_pos[last] + P->seed_len - 1 + r.h_len_dif[last];
-        int32_t len2 = (int32_t)(r.h_pos[s] - 1 - start);
-        uint8_t *tb = nullptr;
-        if (len2 <= 0) len2 = 0;
-        else {
-            tb = (uint8_t *)arena_alloc(cx, (size_t)len2 + 16);
-            if (!tb || !ref_fetch(r, r.h_chr[last], start, &len2, tb)) { ok = false; break; }
-        }
-        const uint8_t *qp; const int len1 = read_gap(r, last, s, &qp);
-        CigV g;
-        if (!cig_alloc(cx, g, len1 + len2 + 8)) { ok = false; break; }
-        ksw_global(cx, len1, seq_fwd(qp), len2, seq_fwd(tb ? tb : qp), P->del_gapo, P->del_gape, P->ins_gapo, P->ins_gape, P->band_w, &g);
-        ok = merge_cigar(r, fc, &ref_end, &re, chr, g.c, g.n, len2, len1) &&
-             (r.cs_words += r.h_cig_n[s], merge_cigar(r, fc, &ref_end, &re, chr, r.cig + r.h_cig_off[s], r.h_cig_n[s], P->seed_len + r.h_len_dif[s], P->seed_len));
-        last = s;
-        arena_release(cx.tmp, m2);
+        const int one_by_one = left < 32 ? left : 32;                            // this stretch as the reference walks it
+        HP_STAT(25);
+        for (int t = 0; t < one_by_one && ok; ++t) { ok = frag_step(r, F, frag, i, chr, fc, ref_end, re, last); i += step; }
     }
     if (ok) ok = merge_cigar(r, res.cig, &res.refend, &res.readend, chr, fc.c, fc.n, (int)(ref_end - ref_start + 1), re - rs + 1);
     arena_release(cx.tmp, mark);

@@ -12,6 +12,8 @@ int g_emu_gap_mcap = 1 << 30;          // tests: gaps with more survivors than t
 #define HP_GAP_MCAP_RT(cap) (g_emu_gap_mcap < (cap) ? g_emu_gap_mcap : (cap))
 int g_emu_wj_small = 0;                // tests: the ordinary slab of a wave job in bytes (0: as large as a big one), so that small inputs have jobs that need a big slab
 int g_emu_wave_jobs = 1;               // tests: 0 = no wave-per-job launch (hp_wavejob.h): the fill runs the junctions beyond a lane job and the end extensions itself
+int g_emu_frag_block_min = 3;      // tests: fragments with fewer seed steps to go than this are merged step by step (hp_fill.h: frag_steps_block); 1 << 30: never in blocks
+#define HP_FRAG_BLOCK_MIN g_emu_frag_block_min
 int g_emu_pk = 1;                      // tests: 0 = extensions of 63 .. 254 query bases take the int32 register sets instead of the packed int16 routine (hp_ksw.h)
 #define HP_PK_RT g_emu_pk
 #include <vector>
@@ -99,6 +101,7 @@ extern "C" void emu_set_gap_caps(int tab_cap, int mcap) { g_emu_gaptab_cap = tab
 extern "C" void emu_set_wave_jobs(int on) { g_emu_wave_jobs = on; }
 extern "C" void emu_set_wj_small(int bytes) { g_emu_wj_small = bytes; }
 extern "C" void emu_set_pk(int on) { g_emu_pk = on; }
+extern "C" void emu_set_frag_block_min(int n) { g_emu_frag_block_min = n > 0 ? n : 3; }
 extern "C" long long emu_stat(int i) { return g_emu_stat[i & 31]; }
 extern "C" void emu_dplog_on(int on) { g_emu_dplog_on = on; g_emu_dplog.clear(); }
 extern "C" long long emu_dplog(long long *buf, long long cap) { long long n = (long long)g_emu_dplog.size(); for (long long i = 0; i < n && i < cap; ++i) buf[i] = g_emu_dplog[i]; return n; }

@@ -445,7 +445,7 @@ def end_extension_from_oracle(jobs, lp, head, w, h0):
     return dict(score=want["score"], qle=want["qle"], tle=want["tle"], cigars=cigs)
 
 
-def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None, wave_jobs=True, wj_small=0):
+def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit_cap=0, cl_cap=0, lane_dp=True, gaptab_cap=0, gap_mcap=0, stats=None, wave_jobs=True, wj_small=0, frag_block_min=0):
     """Per-read result streams from the device sources compiled with the CPU lane emulation.
     phased: scale-1 batches go through the launches of hp_phase.h (the product's main pass) instead of the one-kernel path.
     cl_cap: clusters of more hits than this take the HBM path of the main chaining pass instead of the LDS one (hp_cluster.h).
@@ -456,7 +456,7 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     from lamsa_amd.hp import HpRef, HpBatch
     E = emu()
     E.emu_set_phased(1 if phased else 0); E.emu_set_unit_cap(int(unit_cap)); E.emu_set_cl_cap(int(cl_cap)); E.emu_set_lane_dp(1 if lane_dp else 0)
-    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_set_wave_jobs(1 if wave_jobs else 0); E.emu_set_wj_small(int(wj_small)); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
+    E.emu_set_gap_caps(int(gaptab_cap), int(gap_mcap)); E.emu_set_wave_jobs(1 if wave_jobs else 0); E.emu_set_wj_small(int(wj_small)); E.emu_set_frag_block_min(int(frag_block_min)); E.emu_stat_reset(); E.emu_stat.restype = C.c_longlong
     n = batch.n_reads
     hb = hp_batch_struct(batch, HpBatch)
     hr = HpRef(batch.pac.ctypes.data, int(batch.l_pac), len(batch.seq_len), batch.seq_off.ctypes.data, batch.seq_len.ctypes.data)
@@ -467,7 +467,7 @@ def emu_streams(batch, hp_para, scale=1, slab_bytes=256 << 20, phased=True, unit
     E.emu_align_batch(C.byref(hp_para), C.byref(hr), C.byref(hb), scale, slab_bytes, stream.ctypes.data, cap, C.byref(nw), off.ctypes.data, ln.ctypes.data, st.ctypes.data)
     if stats is not None:
         stats[:] = [int(E.emu_stat(i)) for i in range(32)]
-    E.emu_set_gap_caps(0, 0); E.emu_set_wave_jobs(1); E.emu_set_wj_small(0)
+    E.emu_set_gap_caps(0, 0); E.emu_set_wave_jobs(1); E.emu_set_wj_small(0); E.emu_set_frag_block_min(0)
     return split_streams(stream, off[:n], ln[:n]), st[:n].copy()
 
 
