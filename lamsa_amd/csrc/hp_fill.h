@@ -38,6 +38,32 @@ HP_FN bool ref_fetch(ReadCtx &r, int chr, int64_t start0, int32_t *len, uint8_t 
     const int32_t n = *len;
     r.t_bases += n > 0 ? n : 0;
     const uint8_t *pac = r.ref.pac;
+    if (n >= 256 && ((uintptr_t)dst & 3) == 0) {
+        // a long window (the NM / AS pass over a whole record, an end extension): four bases per lane -- the two packed bytes they lie in, one
+        // 32-bit store -- and two such passes requested together; a base per lane was 157 dependent load-store rounds for a 10-kbp record
+        const HP_G uint8_t *gp = (const HP_G uint8_t *)pac;
+        const int sh0 = (int)(k0 & 3) << 1;
+        int32_t b = 0;
+        for (; b + 512 <= n; b += 512) {
+            wv::Lane<int> w0, w1;
+            WAVE_FOR(l) {
+                const int64_t ka = (k0 + b + 4 * l) >> 2, kb = (k0 + b + 256 + 4 * l) >> 2;
+                w0[l] = ((int)gp[ka] << 8) | (sh0 ? (int)gp[ka + 1] : 0);
+                w1[l] = ((int)gp[kb] << 8) | (sh0 ? (int)gp[kb + 1] : 0);
+            }
+            WAVE_FOR(l) {
+                const int x = w0[l] >> (8 - sh0), y = w1[l] >> (8 - sh0);        // the four bases, first one in bits 7..6
+                *(HP_G uint32_t *)((HP_G uint8_t *)dst + b + 4 * l) = (uint32_t)((x >> 6 & 3) | (x >> 4 & 3) << 8 | (x >> 2 & 3) << 16 | (x & 3) << 24);
+                *(HP_G uint32_t *)((HP_G uint8_t *)dst + b + 256 + 4 * l) = (uint32_t)((y >> 6 & 3) | (y >> 4 & 3) << 8 | (y >> 2 & 3) << 16 | (y & 3) << 24);
+            }
+        }
+        for (; b < n; b += 64) {
+            WAVE_FOR(l) {
+                const int32_t i = b + l;
+                if (i < n) { const int64_t k = k0 + i; dst[i] = pac[k >> 2] >> ((~k & 3) << 1) & 3; }
+            }
+        }
+    } else
     for (int32_t b = 0; b < n; b += 64) {
         WAVE_FOR(l) {
             const int32_t i = b + l;
@@ -1019,18 +1045,31 @@ HP_NOINL bool res_aux(ReadCtx &r, LineRes &la)
             {
                 wv::Lane<int> rend, delta, ism;
                 WAVE_FOR(l) { rend[l] = rs[l] + rinc[l]; delta[l] = fs[l] - rs[l]; ism[l] = mlen[l] > 0; }
-                for (int q0 = 0; q0 < r_tot; q0 += 64) {
-                    wv::Lane<int> e;
-                    WAVE_FOR(l) { e[l] = 0; }
+                // four passes of 64 bases in flight: their searches are independent (lane gathers pipeline) and their eight loads are requested
+                // together -- one pass at a time waited ~2 us for its two bytes, 157 times per 10-kbp record
+                enum { RA_U = 4 };
+                for (int q0 = 0; q0 < r_tot; q0 += 64 * RA_U) {
+                    wv::Lane<int> e[RA_U];
+#pragma unroll
+                    for (int u = 0; u < RA_U; ++u) { WAVE_FOR(l) { e[u][l] = 0; } }
 #pragma unroll
                     for (int step = 32; step >= 1; step >>= 1) {
-                        wv::Lane<int> probe;
-                        WAVE_FOR(l) { probe[l] = e[l] + step - 1; }
-                        const wv::Lane<int> v = wv::gather(rend, probe);
-                        WAVE_FOR(l) { if (v[l] <= q0 + l) e[l] += step; }        // e = elements that end at or before this base
+#pragma unroll
+                        for (int u = 0; u < RA_U; ++u) {
+                            wv::Lane<int> probe;
+                            WAVE_FOR(l) { probe[l] = e[u][l] + step - 1; }
+                            const wv::Lane<int> v = wv::gather(rend, probe);
+                            WAVE_FOR(l) { if (v[l] <= q0 + 64 * u + l) e[u][l] += step; }        // e = elements that end at or before this base
+                        }
                     }
-                    const wv::Lane<int> dv = wv::gather(delta, e), mv = wv::gather(ism, e);
-                    WAVE_FOR(l) { const int q = q0 + l; if (q < r_tot && mv[l]) mm[l] += gread[read_i + q] != gref[ref_i + q + dv[l]]; }
+                    wv::Lane<int> a[RA_U], b[RA_U];
+#pragma unroll
+                    for (int u = 0; u < RA_U; ++u) {
+                        const wv::Lane<int> dv = wv::gather(delta, e[u]), mv = wv::gather(ism, e[u]);
+                        WAVE_FOR(l) { const int q = q0 + 64 * u + l; a[u][l] = 0; b[u][l] = 0; if (q < r_tot && mv[l]) { a[u][l] = gread[read_i + q]; b[u][l] = gref[ref_i + q + dv[l]] + 256; } }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RA_U; ++u) { WAVE_FOR(l) { mm[l] += b[u][l] != 0 && a[u][l] != b[u][l] - 256; } }
                 }
             }
             const int mms = wv::reduce_sum(mm);
